@@ -1,0 +1,145 @@
+"""The oracle against the committed reference goldens (tests/golden, made by tools/make_golden.py).
+
+CPU-only.  Pins oracle/multislice_oracle.py to the reference to <= 1e-12 relative.
+"""
+import numpy as np
+import pytest
+
+from oracle import multislice_oracle as orc
+from conftest import rel_l2
+
+TOL = 1e-12
+
+
+def test_g1_grid(golden):
+    g = golden("g1_grid")
+    for box, e in zip(g["boxes"], g["expect"]):
+        xs, ys, zs, lx, ly, lz = orc.grid_from_box(box, 0.1, 0.5)
+        assert (len(xs), len(ys), len(zs)) == tuple(int(v) for v in e[:3])
+        assert xs[1] - xs[0] == e[3] and ys[1] - ys[0] == e[4]
+        assert (zs[1] - zs[0] if len(zs) > 1 else 0.5) == e[5]
+
+
+def test_g2_wavelength_sigma(golden):
+    g = golden("g2_wavelength")
+    for e, l, s in zip(g["eV"], g["wavelength"], g["sigma"]):
+        assert abs(orc.wavelength(e) - l) <= 1e-15 * l
+        assert abs(orc.interaction_sigma(e) - s) <= 1e-15 * s
+    # 100 keV values
+    assert abs(orc.wavelength(100e3) - 0.0370144) < 1e-7
+    assert abs(orc.interaction_sigma(100e3) - 9.24396e-4) < 1e-9
+
+
+def test_g3_form_factor(golden):
+    g = golden("g3_formfactor")
+    for Z, f in zip(g["Z"], g["f"]):
+        assert rel_l2(orc.form_factor(g["qsq"], int(Z)), f) < TOL
+
+
+@pytest.mark.parametrize("name", ["g4_potential_64", "g4_potential_96x80"])
+def test_g4_potential(golden, name):
+    g = golden(name)
+    xs, ys, zs, *_ = orc.grid_from_box(g["box"], 0.1, 0.5)
+    V = orc.potential(xs, ys, zs, g["positions"], g["Z"], int(g["slice_axis"]))
+    assert V.shape == g["V"].shape
+    assert rel_l2(V, g["V"]) < TOL
+
+
+def test_k4_potential_integral(golden):
+    """K4: sum_xy V[:,:,s] = sum_{a in s} f_Z(0) / (dx^2 dy^2) -- the DC bin of the slice."""
+    g = golden("g4_potential_64")
+    xs, ys, zs, *_ = orc.grid_from_box(g["box"], 0.1, 0.5)
+    V = g["V"]
+    lo, hi = orc.slice_edges(zs)
+    dx, dy = xs[1] - xs[0], ys[1] - ys[0]
+    z = g["positions"][:, 2]
+    for s in range(len(zs)):
+        m = (z >= lo[s]) & (z < hi[s])
+        want = sum(orc.form_factor(np.zeros(1), int(Z))[0] for Z in g["Z"][m]) / (len(xs) * len(ys)) * (len(xs) * len(ys))
+        got = V[:, :, s].sum() * (dx ** 2 * dy ** 2)
+        assert abs(got - want) <= 1e-10 * max(1.0, abs(want))
+
+
+def test_g5_probes(golden):
+    g = golden("g5_probes")
+    xs, ys, pp, eV = g["xs"], g["ys"], g["positions"], float(g["eV"])
+    for mrad in (0, 5, 30):
+        base = orc.probe_array(xs, ys, mrad, eV)
+        assert rel_l2(base, g[f"base_{mrad}"]) < TOL
+        assert rel_l2(orc.batched_probes(base, xs, ys, pp), g[f"batch_{mrad}"]) < TOL
+    assert orc.probe_array(xs, ys, 0, eV).dtype == np.float64      # Q5: plane wave is real ones
+    g2 = golden("g5_probes_96x80")
+    b = orc.batched_probes(orc.probe_array(g2["xs"], g2["ys"], 30, eV), g2["xs"], g2["ys"], g2["positions"])
+    assert rel_l2(b, g2["batch_30"]) < TOL
+
+
+def test_k6_probe_peak_position(golden):
+    """Q3/K6: the probe 'at p' peaks at (L/2 - p) mod L."""
+    g = golden("g5_probes")
+    xs, ys = g["xs"], g["ys"]
+    nx, ny = len(xs), len(ys)
+    dx, dy = xs[1] - xs[0], ys[1] - ys[0]
+    for arr, (px, py) in zip(g["batch_30"], g["positions"]):
+        i, j = np.unravel_index(np.argmax(np.abs(arr)), arr.shape)
+        ex = ((nx // 2) * dx - px) % (nx * dx)
+        ey = ((ny // 2) * dy - py) % (ny * dy)
+        assert min(abs(i * dx - ex), nx * dx - abs(i * dx - ex)) <= dx
+        assert min(abs(j * dy - ey), ny * dy - abs(j * dy - ey)) <= dy
+
+
+@pytest.mark.parametrize("name", ["g6_propagate_64_single", "g6_propagate_64_batch",
+                                  "g6_propagate_64_plane", "g6_propagate_96x80_batch"])
+def test_g6_propagate(golden, name):
+    g = golden(name)
+    xs, ys, zs, eV = g["xs"], g["ys"], g["zs"], float(g["eV"])
+    pr = orc.batched_probes(orc.probe_array(xs, ys, float(g["mrad"]), eV), xs, ys, g["positions"])
+    ex = orc.propagate(pr, g["V"], xs, ys, zs, eV)
+    assert rel_l2(ex, g["exit"]) < TOL
+    # K2: |t| = |P| = 1 -> the norm of every probe is conserved
+    assert np.allclose((np.abs(ex) ** 2).sum(axis=(1, 2)), (np.abs(pr) ** 2).sum(axis=(1, 2)), rtol=1e-12)
+
+
+@pytest.mark.parametrize("name", ["g7_calculator_64", "g7_calculator_32_default_probe"])
+def test_g7_calculator(golden, name):
+    g = golden(name)
+    pp = [tuple(p) for p in g["probe_positions"]]
+    o = orc.run_frames(g["box"], g["positions"], g["Z"], float(g["aperture"]), float(g["eV"]), pp)
+    assert o["wavefunction_data"].shape == g["wavefunction_data"].shape
+    assert rel_l2(o["wavefunction_data"], g["wavefunction_data"]) < TOL
+    kx, ky, t = orc.wf_axes(len(o["xs"]), len(o["ys"]), 0.1, g["positions"].shape[0], 0.005)
+    assert np.array_equal(kx, g["kxs"]) and np.array_equal(ky, g["kys"]) and np.allclose(t, g["time"], rtol=0, atol=0)
+
+
+def test_g8_tacaw(golden):
+    g = golden("g8_tacaw_32")
+    f, inten = orc.tacaw(g["wavefunction_data"], g["time"])
+    assert np.allclose(f, g["frequencies"], rtol=1e-15)
+    assert rel_l2(inten, g["intensity"]) < TOL
+    assert rel_l2(orc.tacaw_spectrum(inten, 0), g["spectrum0"]) < TOL
+    assert rel_l2(orc.tacaw_spectrum(inten, None), g["spectrum_all"]) < TOL
+    assert rel_l2(orc.tacaw_diffraction(inten, 0), g["diffraction0"]) < TOL
+    assert rel_l2(orc.tacaw_diffraction(inten, None), g["diffraction_all"]) < TOL
+    # K5: the DC bin of the mean-subtracted time FFT is zero (fftshifted index T//2)
+    T = len(g["time"])
+    assert inten[:, T // 2].max() <= 1e-20 * inten.max()
+    with pytest.raises(ValueError):
+        orc.tacaw(g["wavefunction_data"], g["time"], layer_index=3)
+
+
+def test_g9_haadf(golden):
+    g = golden("g9_haadf_32")
+    gx, gy, adf = orc.haadf(g["wavefunction_data"], g["kxs"], g["kys"], g["probe_positions"], float(g["eV"]),
+                            float(g["collection_angle"]))
+    assert adf.shape == g["adf"].shape
+    assert rel_l2(adf, g["adf"]) < 1e-6      # the reference accumulates this image in float32
+
+
+def test_k1_vacuum_plane_wave():
+    """K1: V=0, plane wave -> Psi = nx*ny at DC (fftshifted centre), 0 elsewhere."""
+    xs = np.linspace(0, 3.2, 32, endpoint=False); ys = xs.copy(); zs = np.linspace(0, 2.0, 4, endpoint=False)
+    pr = orc.batched_probes(orc.probe_array(xs, ys, 0, 100e3), xs, ys, [(1.6, 1.6)])
+    ex = orc.propagate(pr, np.zeros((32, 32, 4)), xs, ys, zs, 100e3)
+    d = orc.diffraction(ex)[0]
+    assert abs(d[16, 16] - 32 * 32) < 1e-9
+    d[16, 16] = 0
+    assert np.abs(d).max() < 1e-9
