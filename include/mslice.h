@@ -1,0 +1,169 @@
+/*
+ * libmslice -- C ABI of the MI355X (gfx950) multislice engine.
+ *
+ * This is the drop-in boundary of the hot path.  The reference (h-walk/PySlice) has no
+ * native layer: its path is Python calling torch/numpy ops.  Every entry point below
+ * therefore replaces the *body* of one reference Python function; the reference-side
+ * binding a maintainer would add is the ctypes stub shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C types only; every function returns 0 on success or a negative msl_status;
+ *     no C++ exception crosses the ABI; msl_last_error() gives the message.
+ *   - caller owns every host buffer; the library owns all device buffers for the life of
+ *     the handle and keeps no host pointer after a call returns.
+ *   - one handle == one HIP device + one HIP stream; a handle is not thread-safe, distinct
+ *     handles (one per GPU / per process) are independent.
+ *   - arithmetic is complex64 / float32 on the device ("c64" below = interleaved float
+ *     re,im).  Setup scalars are taken as double and reduced on the host.
+ *   - wave-function layout everywhere: [probe][x][y] with y fastest (reference axis order,
+ *     src/multislice/multislice.py:285-294).
+ */
+#ifndef MSLICE_H
+#define MSLICE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSL_ABI_VERSION 1
+
+typedef struct msl_handle msl_handle;
+
+typedef enum {
+    MSL_OK = 0,
+    MSL_ERR_INVALID = -1,     /* bad argument / shape (Python wrapper raises ValueError)   */
+    MSL_ERR_HIP = -2,         /* HIP runtime failure (RuntimeError)                        */
+    MSL_ERR_UNSUPPORTED = -3, /* e.g. grid length with a prime factor the FFT cannot do    */
+    MSL_ERR_STATE = -4,       /* call order violated (e.g. propagate before potential)     */
+    MSL_ERR_NOMEM = -5
+} msl_status;
+
+/* Grid + beam description.  Replaces the scalars MultisliceCalculator.setup() derives
+ * (src/multislice/calculators.py:144-161) and Propagate() derives
+ * (src/multislice/multislice.py:258-275). */
+typedef struct {
+    int32_t nx, ny, nz;        /* grid: len(xs), len(ys), number of slices                 */
+    double  dx, dy;            /* xs[1]-xs[0], ys[1]-ys[0]   (potentials.py:228-229)       */
+    double  dz;                /* slice spacing used by the Fresnel propagator (multislice.py:266) */
+    double  wavelength;        /* Angstrom           (multislice.py:41-42)                 */
+    double  sigma;             /* interaction parameter (multislice.py:258-260)            */
+    int32_t n_probes;          /* P                                                         */
+    int32_t n_frames;          /* T_local: frame slots of the (P,T_local,nx,ny) result; 0 = no result buffer */
+    int32_t device;            /* HIP device ordinal                                        */
+    int32_t keep_potential;    /* 1: also keep V (nz,nx,ny) float32 for msl_download(MSL_BUF_POTENTIAL) */
+    int32_t fft_path;          /* 0 = auto (fast kernels when the size allows), 1 = generic LDS Stockham only */
+    int32_t reserved[7];
+} msl_config;
+
+typedef enum {
+    MSL_BUF_PROBES = 0,        /* (P,nx,ny) c64     initial probes psi_0                    */
+    MSL_BUF_EXIT = 1,          /* (P,nx,ny) c64     real-space exit waves of the last msl_propagate */
+    MSL_BUF_POTENTIAL = 2,     /* (nz,nx,ny) f32    V of the last msl_build_potential (slice-major!) */
+    MSL_BUF_TRANSMISSION = 3,  /* (nz,nx,ny) c64    exp(i sigma V)                           */
+    MSL_BUF_WAVEFUNCTION = 4,  /* (P,T_local,nx,ny) c64  fftshift(fft2(exit)) per frame slot */
+    MSL_BUF_INTENSITY = 5,     /* (P,T,nx,ny) f32   TACAW |FFT_t|^2 of the last msl_tacaw    */
+    MSL_BUF_FORMFACTOR = 6     /* (n_species,nx,ny) f32 Kirkland f_Z(q^2) of the last potential build */
+} msl_buffer;
+
+typedef struct {
+    uint64_t slice_steps;      /* probes x slices propagated since create/reset             */
+    uint64_t frames;           /* frames propagated                                         */
+    uint64_t algorithmic_bytes;/* 32 B x nx x ny per slice-step (+ V/t and epilogue terms)  */
+    double   ms_potential;     /* device time (HIP events) spent in potential builds        */
+    double   ms_propagate;     /* ... in slice loops (+ epilogue)                           */
+    double   ms_tacaw;
+    uint64_t slice_kernel_launches; /* launches of the dominant slice-loop kernels         */
+    double   ms_slice_kernels; /* device time of those launches only (HIP events on the handle's stream) */
+    uint64_t row_launches;     /* row-pass launches (ifft_y, x t, fft_y, x Py) and their device time */
+    double   ms_row;
+    uint64_t col_launches;     /* column-pass launches (fft_x, x Px, ifft_x) and their device time   */
+    double   ms_col;
+} msl_counters;
+
+int  msl_abi_version(void);
+/* Message of the last failure on this handle (or of the last failed msl_create when h==NULL). */
+const char* msl_last_error(const msl_handle* h);
+
+/* Create / destroy.  Replaces the allocation side of MultisliceCalculator.setup()
+ * (calculators.py:154-161: base probe, wavefunction_data zeros). */
+int  msl_create(const msl_config* cfg, msl_handle** out);
+int  msl_destroy(msl_handle* h);
+
+/* Kirkland parameter table, 103 elements x 3 terms x (a,b,c,d), row-major doubles.
+ * Replaces loadKirkland() (potentials.py:134-185). */
+int  msl_set_kirkland(msl_handle* h, const double* abcd_103x3x4);
+
+/* Slice bin edges [lo[s], hi[s]) along the beam axis, nz doubles each.
+ * Replaces the slice_min/slice_max rule of Potential.__init__ (potentials.py:302-307). */
+int  msl_set_slices(msl_handle* h, const double* lo, const double* hi);
+
+/* Change the beam after create: recomputes the Fresnel tables and, when a potential V is held
+ * (keep_potential), re-derives exp(i sigma V).  Lets Potential() (which knows no beam energy,
+ * potentials.py:188) be built first and Propagate() (multislice.py:258-275) supply the beam. */
+int  msl_set_beam(msl_handle* h, double wavelength, double sigma, double dz);
+
+/* Re-size the probe batch (re-allocates the (P,nx,ny) working buffers; probes must be set again). */
+int  msl_resize_probes(msl_handle* h, int32_t n_probes);
+
+/* Build the P shifted probes on the device: psi0[p] = ifft2(mask * exp(2 pi i (kx px + ky py)) * centre-shift).
+ * mrad == 0 gives plane waves (ones).  xy = P x 2 doubles (Angstrom).
+ * Replaces Probe.__init__ + create_batched_probes (multislice.py:112-124, 198-235). */
+int  msl_set_probes(msl_handle* h, double mrad, const double* xy, int32_t n_probes);
+
+/* Upload arbitrary initial waves (P,nx,ny) c64 (used when a caller hands Propagate() a
+ * Probe built from its own array, multislice.py:104-109). */
+int  msl_upload_probes(msl_handle* h, const float* c64, int32_t n_probes);
+
+/* Shift an arbitrary base probe (nx,ny) c64 to P positions: psi0[p] = ifft2(fft2(base) * ramp_p).
+ * Replaces create_batched_probes for probes built from a caller array (multislice.py:216-227). */
+int  msl_shift_probes(msl_handle* h, const float* base_c64, const double* xy, int32_t n_probes);
+
+/* Projected Kirkland potential + transmission functions of one MD frame.
+ * pos = n x 3 doubles, Z = n atomic numbers (1..103); ax1/ax2 = in-plane axes, axs = slice axis.
+ * Replaces Potential.__init__ (potentials.py:188-348) and the per-slice exp(i sigma V) of
+ * Propagate (multislice.py:281-282). */
+int  msl_build_potential(msl_handle* h, const double* pos, const int32_t* Z, int64_t n_atoms,
+                         int32_t ax1, int32_t ax2, int32_t axs);
+
+/* Upload a caller-made potential V (nz,nx,ny) float32 slice-major and derive exp(i sigma V)
+ * (Propagate() accepts any Potential object, multislice.py:237). */
+int  msl_upload_potential(msl_handle* h, const float* V_nz_nx_ny);
+
+/* Slice loop for all probes against the current potential: nz transmissions, nz-1 Fresnel steps.
+ * Leaves real-space exit waves in MSL_BUF_EXIT.  Replaces Propagate() (multislice.py:237-299). */
+int  msl_propagate(msl_handle* h);
+
+/* Slice loop + fused epilogue fftshift(fft2(exit)) written into frame slot `slot` of the
+ * (P,T_local,nx,ny) result.  Replaces _process_frame_worker_torch after the potential
+ * (calculators.py:281-290) and the scatter loop (calculators.py:185-186). */
+int  msl_propagate_frame(msl_handle* h, int32_t slot);
+
+/* TACAW: intensity[p,w,kx,ky] = | fftshift_t fft_t( Psi - <Psi>_t ) |^2 over a (B,T,npix) c64 device
+ * array.  src == NULL uses the handle's own wavefunction buffer (B=P, T=T_local, npix=nx*ny) and
+ * its own intensity buffer.  With src/dst given (device pointers, e.g. the output of an RCCL
+ * all-to-all held by the caller) the transform is applied to that memory.
+ * Replaces TACAWData.fft_from_wf_data (tacaw_data.py:89-104). */
+int  msl_tacaw(msl_handle* h, const void* d_src_c64, void* d_dst_f32, int64_t batch, int32_t T, int64_t npix);
+
+/* Copy a device buffer to the host (dst must hold `bytes` = full buffer size, see msl_buffer_bytes).
+ * For MSL_BUF_WAVEFUNCTION `first`/`count` select a probe range (count==0: all). */
+int  msl_download(msl_handle* h, msl_buffer what, void* dst, size_t bytes, int64_t first, int64_t count);
+size_t msl_buffer_bytes(const msl_handle* h, msl_buffer what);
+/* Raw device pointer of a library buffer, for zero-copy use by the caller's collective (RCCL). */
+void* msl_device_ptr(msl_handle* h, msl_buffer what);
+
+int  msl_synchronize(msl_handle* h);
+int  msl_get_counters(const msl_handle* h, msl_counters* out);
+int  msl_reset_counters(msl_handle* h);
+
+/* Batched 2-D FFT self-test entry (parity tests of the FFT kernels alone): in/out host (B,nx,ny) c64,
+ * dir=+1 forward / -1 inverse (1/(nx*ny) normalised), path as msl_config.fft_path. */
+int  msl_fft2_host(msl_handle* h, const float* in_c64, float* out_c64, int32_t batch, int32_t dir);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSLICE_H */

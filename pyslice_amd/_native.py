@@ -1,0 +1,275 @@
+"""ctypes binding of libmslice.so (include/mslice.h) -- the only door to the device.
+
+There is deliberately no CPU fallback: if the shared library is missing or no HIP device is
+present every call raises.  The NumPy oracle lives under oracle/ and is never imported here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmslice.so")
+
+MSL_OK, MSL_ERR_INVALID, MSL_ERR_HIP, MSL_ERR_UNSUPPORTED, MSL_ERR_STATE, MSL_ERR_NOMEM = 0, -1, -2, -3, -4, -5
+(BUF_PROBES, BUF_EXIT, BUF_POTENTIAL, BUF_TRANSMISSION, BUF_WAVEFUNCTION, BUF_INTENSITY, BUF_FORMFACTOR) = range(7)
+
+EXPORTS = [
+    "msl_abi_version", "msl_last_error", "msl_create", "msl_destroy", "msl_set_kirkland", "msl_set_slices",
+    "msl_set_beam", "msl_resize_probes", "msl_set_probes", "msl_upload_probes", "msl_shift_probes",
+    "msl_build_potential", "msl_upload_potential", "msl_propagate", "msl_propagate_frame", "msl_tacaw",
+    "msl_download", "msl_buffer_bytes", "msl_device_ptr", "msl_synchronize", "msl_get_counters",
+    "msl_reset_counters", "msl_fft2_host",
+]
+
+
+class MslConfig(C.Structure):
+    _fields_ = [("nx", C.c_int32), ("ny", C.c_int32), ("nz", C.c_int32),
+                ("dx", C.c_double), ("dy", C.c_double), ("dz", C.c_double),
+                ("wavelength", C.c_double), ("sigma", C.c_double),
+                ("n_probes", C.c_int32), ("n_frames", C.c_int32), ("device", C.c_int32),
+                ("keep_potential", C.c_int32), ("fft_path", C.c_int32), ("reserved", C.c_int32 * 7)]
+
+
+class MslCounters(C.Structure):
+    _fields_ = [("slice_steps", C.c_uint64), ("frames", C.c_uint64), ("algorithmic_bytes", C.c_uint64),
+                ("ms_potential", C.c_double), ("ms_propagate", C.c_double), ("ms_tacaw", C.c_double),
+                ("slice_kernel_launches", C.c_uint64), ("ms_slice_kernels", C.c_double),
+                ("row_launches", C.c_uint64), ("ms_row", C.c_double),
+                ("col_launches", C.c_uint64), ("ms_col", C.c_double)]
+
+
+_lib = None
+
+
+def load():
+    """Load libmslice.so once; raise loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP extension has not been built "
+            "(run `python -c 'import __graft_entry__ as g; g.build()'` or `python -m pyslice_amd.build_native`). "
+            "pyslice_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+    sig = {
+        "msl_abi_version": (C.c_int, []),
+        "msl_last_error": (C.c_char_p, [vp]),
+        "msl_create": (C.c_int, [C.POINTER(MslConfig), C.POINTER(vp)]),
+        "msl_destroy": (C.c_int, [vp]),
+        "msl_set_kirkland": (C.c_int, [vp, vp]),
+        "msl_set_slices": (C.c_int, [vp, vp, vp]),
+        "msl_set_beam": (C.c_int, [vp, dbl, dbl, dbl]),
+        "msl_resize_probes": (C.c_int, [vp, i32]),
+        "msl_set_probes": (C.c_int, [vp, dbl, vp, i32]),
+        "msl_upload_probes": (C.c_int, [vp, vp, i32]),
+        "msl_shift_probes": (C.c_int, [vp, vp, vp, i32]),
+        "msl_build_potential": (C.c_int, [vp, vp, vp, i64, i32, i32, i32]),
+        "msl_upload_potential": (C.c_int, [vp, vp]),
+        "msl_propagate": (C.c_int, [vp]),
+        "msl_propagate_frame": (C.c_int, [vp, i32]),
+        "msl_tacaw": (C.c_int, [vp, vp, vp, i64, i32, i64]),
+        "msl_download": (C.c_int, [vp, C.c_int, vp, C.c_size_t, i64, i64]),
+        "msl_buffer_bytes": (C.c_size_t, [vp, C.c_int]),
+        "msl_device_ptr": (vp, [vp, C.c_int]),
+        "msl_synchronize": (C.c_int, [vp]),
+        "msl_get_counters": (C.c_int, [vp, C.POINTER(MslCounters)]),
+        "msl_reset_counters": (C.c_int, [vp]),
+        "msl_fft2_host": (C.c_int, [vp, vp, vp, i32, i32]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _raise(rc, msg):
+    if rc == MSL_ERR_INVALID:
+        raise ValueError(msg)
+    if rc == MSL_ERR_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    if rc == MSL_ERR_NOMEM:
+        raise MemoryError(msg)
+    raise RuntimeError(msg)
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Engine:
+    """One libmslice handle: one HIP device, one stream, all device buffers of one grid."""
+
+    def __init__(self, nx, ny, nz, dx, dy, dz, wavelength, sigma, n_probes=1, n_frames=0, device=0,
+                 keep_potential=False, fft_path=0):
+        self._lib = load()
+        self._h = C.c_void_p()
+        cfg = MslConfig(nx=int(nx), ny=int(ny), nz=int(nz), dx=float(dx), dy=float(dy), dz=float(dz),
+                        wavelength=float(wavelength), sigma=float(sigma), n_probes=int(n_probes),
+                        n_frames=int(n_frames), device=int(device), keep_potential=int(bool(keep_potential)),
+                        fft_path=int(fft_path))
+        rc = self._lib.msl_create(C.byref(cfg), C.byref(self._h))
+        if rc != MSL_OK:
+            msg = (self._lib.msl_last_error(None) or b"msl_create failed").decode()
+            self._h = C.c_void_p()
+            _raise(rc, msg)
+        self.nx, self.ny, self.nz = int(nx), int(ny), int(nz)
+        self.n_probes, self.n_frames, self.device = int(n_probes), int(n_frames), int(device)
+        self.keep_potential = bool(keep_potential)
+
+    # -- lifetime
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.msl_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != MSL_OK:
+            _raise(rc, (self._lib.msl_last_error(self._h) or b"libmslice error").decode())
+
+    # -- setup
+    def set_kirkland(self, table):
+        t = np.ascontiguousarray(table, dtype=np.float64)
+        if t.size != 103 * 12:
+            raise ValueError(f"Kirkland table must hold 103x3x4 values, got shape {t.shape}")
+        self._chk(self._lib.msl_set_kirkland(self._h, _ptr(t)))
+
+    def set_slices(self, lo, hi):
+        lo = np.ascontiguousarray(lo, dtype=np.float64)
+        hi = np.ascontiguousarray(hi, dtype=np.float64)
+        if lo.shape != (self.nz,) or hi.shape != (self.nz,):
+            raise ValueError(f"slice edges must have shape ({self.nz},)")
+        self._chk(self._lib.msl_set_slices(self._h, _ptr(lo), _ptr(hi)))
+
+    def set_beam(self, wavelength, sigma, dz):
+        self._chk(self._lib.msl_set_beam(self._h, float(wavelength), float(sigma), float(dz)))
+
+    def resize_probes(self, n_probes):
+        self._chk(self._lib.msl_resize_probes(self._h, int(n_probes)))
+        self.n_probes = int(n_probes)
+
+    def set_probes(self, mrad, xy):
+        xy = np.ascontiguousarray(xy, dtype=np.float64).reshape(-1, 2)
+        self._chk(self._lib.msl_set_probes(self._h, float(mrad), _ptr(xy), xy.shape[0]))
+
+    def upload_probes(self, arr):
+        a = np.ascontiguousarray(arr, dtype=np.complex64)
+        if a.ndim == 2:
+            a = a[None]
+        if a.shape[1:] != (self.nx, self.ny):
+            raise ValueError(f"probe array must be (P,{self.nx},{self.ny}), got {a.shape}")
+        self._chk(self._lib.msl_upload_probes(self._h, _ptr(a), a.shape[0]))
+
+    def shift_probes(self, base, xy):
+        b = np.ascontiguousarray(base, dtype=np.complex64)
+        if b.shape != (self.nx, self.ny):
+            raise ValueError(f"base probe must be ({self.nx},{self.ny}), got {b.shape}")
+        xy = np.ascontiguousarray(xy, dtype=np.float64).reshape(-1, 2)
+        self._chk(self._lib.msl_shift_probes(self._h, _ptr(b), _ptr(xy), xy.shape[0]))
+
+    # -- per frame
+    def build_potential(self, positions, Z, slice_axis=2):
+        pos = np.ascontiguousarray(positions, dtype=np.float64)
+        if pos.ndim != 2 or pos.shape[1] != 3:
+            raise ValueError(f"positions must be (n_atoms,3), got {pos.shape}")
+        z = np.ascontiguousarray(Z, dtype=np.int32)
+        if z.shape != (pos.shape[0],):
+            raise ValueError("one atomic number per atom required")
+        axes = [0, 1, 2]
+        if slice_axis not in axes:
+            raise ValueError(f"slice_axis must be 0, 1 or 2, got {slice_axis}")
+        axes.remove(slice_axis)
+        self._chk(self._lib.msl_build_potential(self._h, _ptr(pos), _ptr(z), pos.shape[0], axes[0], axes[1], slice_axis))
+
+    def upload_potential(self, V_nz_nx_ny):
+        v = np.ascontiguousarray(V_nz_nx_ny, dtype=np.float32)
+        if v.shape != (self.nz, self.nx, self.ny):
+            raise ValueError(f"potential must be ({self.nz},{self.nx},{self.ny}), got {v.shape}")
+        self._chk(self._lib.msl_upload_potential(self._h, _ptr(v)))
+
+    def propagate(self):
+        self._chk(self._lib.msl_propagate(self._h))
+
+    def propagate_frame(self, slot):
+        self._chk(self._lib.msl_propagate_frame(self._h, int(slot)))
+
+    def tacaw(self, src_ptr=None, dst_ptr=None, batch=0, T=0, npix=0):
+        self._chk(self._lib.msl_tacaw(self._h, C.c_void_p(src_ptr) if src_ptr else None,
+                                      C.c_void_p(dst_ptr) if dst_ptr else None, int(batch), int(T), int(npix)))
+
+    # -- results
+    def buffer_bytes(self, what):
+        return int(self._lib.msl_buffer_bytes(self._h, int(what)))
+
+    def device_ptr(self, what):
+        return self._lib.msl_device_ptr(self._h, int(what)) or 0
+
+    def download(self, what, dtype, shape, first=0, count=0):
+        out = np.empty(shape, dtype=dtype)
+        self._chk(self._lib.msl_download(self._h, int(what), _ptr(out), out.nbytes, int(first), int(count)))
+        return out
+
+    def probes(self):
+        return self.download(BUF_PROBES, np.complex64, (self.n_probes, self.nx, self.ny))
+
+    def exit_waves(self):
+        return self.download(BUF_EXIT, np.complex64, (self.n_probes, self.nx, self.ny))
+
+    def potential(self):
+        return self.download(BUF_POTENTIAL, np.float32, (self.nz, self.nx, self.ny))
+
+    def transmission(self):
+        return self.download(BUF_TRANSMISSION, np.complex64, (self.nz, self.nx, self.ny))
+
+    def wavefunction(self, first=0, count=0):
+        n = count if count else self.n_probes
+        return self.download(BUF_WAVEFUNCTION, np.complex64, (n, self.n_frames, self.nx, self.ny), first, count)
+
+    def intensity(self, first=0, count=0):
+        n = count if count else self.n_probes
+        return self.download(BUF_INTENSITY, np.float32, (n, self.n_frames, self.nx, self.ny), first, count)
+
+    def form_factors(self, n_species):
+        return self.download(BUF_FORMFACTOR, np.float32, (n_species, self.nx, self.ny))
+
+    def synchronize(self):
+        self._chk(self._lib.msl_synchronize(self._h))
+
+    def counters(self) -> dict:
+        c = MslCounters()
+        self._chk(self._lib.msl_get_counters(self._h, C.byref(c)))
+        return {k: getattr(c, k) for k, _ in MslCounters._fields_}
+
+    def reset_counters(self):
+        self._chk(self._lib.msl_reset_counters(self._h))
+
+    def fft2(self, arr, direction=+1):
+        a = np.ascontiguousarray(arr, dtype=np.complex64)
+        if a.ndim == 2:
+            a = a[None]
+        if a.shape[1:] != (self.nx, self.ny):
+            raise ValueError(f"array must be (B,{self.nx},{self.ny}), got {a.shape}")
+        out = np.empty_like(a)
+        self._chk(self._lib.msl_fft2_host(self._h, _ptr(a), _ptr(out), a.shape[0], int(direction)))
+        return out
+
+
+class DeviceArray:
+    """Zero-copy view of a library device buffer for torch (``torch.as_tensor(DeviceArray(...), device='cuda')``)."""
+
+    def __init__(self, ptr, shape, typestr, owner=None):
+        self._owner = owner
+        self.__cuda_array_interface__ = {"shape": tuple(int(s) for s in shape), "typestr": typestr,
+                                         "data": (int(ptr), False), "version": 2, "strides": None}

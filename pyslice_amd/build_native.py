@@ -1,0 +1,50 @@
+"""Build pyslice_amd/libmslice.so for gfx950 with hipcc (in-tree, no JIT cache).
+
+    python -m pyslice_amd.build_native [--force]
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libmslice.so")
+SOURCES = ["mslice.hip"]
+DEPS = ["mslice.hip", "fft_generic.h", "fft_pow2.h", "potential.h", os.path.join("..", "..", "include", "mslice.h")]
+ARCH = "gfx950"
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (ROCm toolchain required to build libmslice.so)")
+
+
+def needs_build() -> bool:
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    for d in DEPS:
+        p = os.path.join(CSRC, d)
+        if os.path.exists(p) and os.path.getmtime(p) > t:
+            return True
+    return False
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    if not force and not needs_build():
+        return OUT
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", OUT] + SOURCES
+    if verbose:
+        print("[pyslice_amd] " + " ".join(cmd), flush=True)
+    subprocess.run(cmd, cwd=CSRC, check=True)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(OUT)

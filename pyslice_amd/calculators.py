@@ -1,0 +1,209 @@
+"""MultisliceCalculator -- host mirror of src/multislice/calculators.py (the drop-in boundary).
+
+`setup()` and `run()` keep the reference's signatures, defaults and the attributes callers read
+(calculators.py:96-161, 163-250).  The per-frame work -- projected potential, probes, slice loop,
+exit-wave FFT -- runs in the HIP library; the (P,T,nx,ny) result stays resident on the device
+until the end of `run()`, when it is packed into a WFData with the reference's field names,
+axis order, fftshift convention and (by default) dtype.
+
+Multi-GPU: when torch.distributed is initialised, MD frames are sharded in contiguous blocks over
+the ranks (one process per GPU); there is no collective on the data path, only one gather of the
+shards at the end (pyslice_amd/distributed.py).
+"""
+from __future__ import annotations
+
+import hashlib
+import logging
+import os
+import time
+from pathlib import Path
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+from . import _native, distributed
+from .multislice import Probe, interaction_sigma, wavelength
+from .potentials import TORCH_AVAILABLE, _as_tensor, _device_index, gridFromTrajectory, loadKirkland, slice_edges
+from .trajectory import Trajectory
+from .wf_data import WFData
+
+if TORCH_AVAILABLE:
+    import torch
+
+logger = logging.getLogger(__name__)
+
+
+class MultisliceCalculator:
+
+    def __init__(self, device=None, force_cpu=False, *, output="host", dtype="complex128", progress=True,
+                 gather="rank0"):
+        """
+        device / force_cpu: as the reference (calculators.py:41).  There is no CPU path here, so
+        force_cpu=True raises.  Keyword-only extras (not in the reference):
+          output   "host" (default; WFData.wavefunction_data is a CPU tensor like the reference) or
+                   "device" (zero-copy torch view of the library's (P,T,nx,ny) buffer, complex64)
+          dtype    "complex128" (default, reference dtype; upcast after download) or "complex64"
+          gather   multi-process runs: "rank0" (default), "all" or "none" (keep the local frame shard)
+        """
+        if force_cpu:
+            raise NotImplementedError("pyslice_amd has no CPU path (force_cpu=True): use the reference for CPU runs")
+        if output not in ("host", "device"):
+            raise ValueError("output must be 'host' or 'device'")
+        if dtype not in ("complex128", "complex64"):
+            raise ValueError("dtype must be 'complex128' or 'complex64'")
+        if gather not in ("rank0", "all", "none"):
+            raise ValueError("gather must be 'rank0', 'all' or 'none'")
+        self.device = device
+        self._output, self._dtype, self._progress, self._gather = output, dtype, progress, gather
+        self._engine = None
+        # reference calculators.py:70-76 (display names for Z <= 36)
+        self.element_map = {
+            1: 'H', 2: 'He', 3: 'Li', 4: 'Be', 5: 'B', 6: 'C', 7: 'N', 8: 'O', 9: 'F', 10: 'Ne', 11: 'Na', 12: 'Mg',
+            13: 'Al', 14: 'Si', 15: 'P', 16: 'S', 17: 'Cl', 18: 'Ar', 19: 'K', 20: 'Ca', 21: 'Sc', 22: 'Ti', 23: 'V',
+            24: 'Cr', 25: 'Mn', 26: 'Fe', 27: 'Co', 28: 'Ni', 29: 'Cu', 30: 'Zn', 31: 'Ga', 32: 'Ge', 33: 'As',
+            34: 'Se', 35: 'Br', 36: 'Kr'}
+
+    def _generate_cache_key(self, trajectory, aperture, voltage_eV, slice_thickness, sampling, probe_positions):
+        """reference calculators.py:78-94 (same recipe, so reference and build name the same directory)."""
+        params = {
+            'n_frames': trajectory.n_frames, 'n_atoms': trajectory.n_atoms,
+            'box_matrix': trajectory.box_matrix.tolist(), 'atom_types': trajectory.atom_types.tolist(),
+            'aperture': aperture, 'voltage_eV': voltage_eV, 'slice_thickness': slice_thickness,
+            'sampling': sampling, 'probe_positions': probe_positions, 'backend': 'pytorch'}
+        return hashlib.md5(str(sorted(params.items())).encode()).hexdigest()[:12]
+
+    def setup(
+        self,
+        trajectory: Trajectory,
+        aperture: float = 0.0,
+        voltage_eV: float = 60e3,
+        defocus: float = 0.0,
+        slice_thickness: float = 0.5,
+        sampling: float = 0.1,
+        probe_positions: Optional[List[Tuple[float, float]]] = None,
+        batch_size: int = 10,
+        save_path: Optional[Path] = None,
+        cleanup_temp_files: bool = False,
+        slice_axis: int = 2,
+    ):
+        """reference calculators.py:96-161 -- same arguments, same defaults, same attributes."""
+        self.trajectory = trajectory
+        self.aperture = aperture
+        self.voltage_eV = voltage_eV
+        self.defocus = defocus                  # stored, never applied -- as in the reference (:129)
+        self.slice_thickness = slice_thickness
+        self.sampling = sampling
+        self.probe_positions = probe_positions
+        self.save_path = save_path
+        self.cleanup_temp_files = cleanup_temp_files
+        self.slice_axis = slice_axis
+
+        cache_key = self._generate_cache_key(trajectory, aperture, voltage_eV, slice_thickness, sampling, probe_positions)
+        self.output_dir = Path("psi_data") / f"torch_{cache_key}"    # named, not created: the frame cache is opt-in
+
+        xs, ys, zs, lx, ly, lz = gridFromTrajectory(trajectory, sampling=sampling, slice_thickness=slice_thickness)
+        nx, ny, nz = len(xs), len(ys), len(zs)
+        self.xs, self.ys, self.zs = xs, ys, zs
+        self.lx, self.ly, self.lz = lx, ly, lz
+        self.nx, self.ny, self.nz = nx, ny, nz
+        self.dx = xs[1] - xs[0]
+        self.dy = ys[1] - ys[0]
+
+        if self.probe_positions is None:
+            self.probe_positions = [(lx / 2, ly / 2)]
+        self.base_probe = Probe(xs, ys, self.aperture, self.voltage_eV, device=self.device)
+
+        self.n_frames = trajectory.n_frames
+        self.n_probes = len(self.probe_positions)
+        self.wavefunction_data = None           # filled by run(); the device holds (P,T_local,nx,ny) meanwhile
+
+        # frame shard of this rank (contiguous block) and the device that serves it
+        self._rank, self._world = distributed.rank_world()
+        self._frames = distributed.shard_frames(self.n_frames, self._world, self._rank)
+        dev = self.device
+        if dev is None and self._world > 1:
+            dev = int(os.environ.get("LOCAL_RANK", self._rank))
+        # slice coordinates follow the slice axis (potentials.py:241-245); the Fresnel step uses zs (multislice.py:266)
+        slice_coords = np.asarray([xs, ys, zs][slice_axis], dtype=np.float64)
+        n_slices = len(slice_coords)
+        dz = zs[1] - zs[0] if nz > 1 else 0.5
+        if self._engine is not None:
+            self._engine.close()
+        self._engine = _native.Engine(nx, ny, n_slices, self.dx, self.dy, dz, wavelength(voltage_eV),
+                                      interaction_sigma(voltage_eV), n_probes=self.n_probes,
+                                      n_frames=max(1, len(self._frames)), device=_device_index(dev))
+        self._engine.set_kirkland(loadKirkland())
+        lo, hi = slice_edges(slice_coords)
+        self._engine.set_slices(lo, hi)
+        self._engine.set_probes(self.aperture, np.asarray(self.probe_positions, dtype=np.float64))
+        self._Z = np.asarray(trajectory.atom_types, dtype=np.int32)
+
+    def run(self) -> WFData:
+        """reference calculators.py:163-250: all frames, then pack WFData."""
+        if self._engine is None:
+            raise RuntimeError("call setup() before run()")
+        eng = self._engine
+        t0 = time.time()
+        frames = self._frames
+        bar = None
+        if self._progress and self._rank == 0:
+            try:
+                from tqdm import tqdm
+                bar = tqdm(total=len(frames), desc="Processing frames", unit="frame")
+            except ImportError:
+                bar = None
+        for slot, frame_idx in enumerate(frames):
+            eng.build_potential(self.trajectory.positions[frame_idx], self._Z, self.slice_axis)
+            eng.propagate_frame(slot)
+            if bar is not None:
+                bar.update(1)
+        eng.synchronize()
+        if bar is not None:
+            bar.close()
+        self.elapsed = time.time() - t0
+        logger.info(f"Simulation completed in {self.elapsed:.2f}s ({len(frames)} computed, 0 cached)")
+
+        # reference calculators.py:218-221 (quirk Q2: `sampling`, not dx; torch default float32)
+        kxs = np.fft.fftshift(np.fft.fftfreq(self.nx, self.sampling)).astype(np.float32)
+        kys = np.fft.fftshift(np.fft.fftfreq(self.ny, self.sampling)).astype(np.float32)
+        time_array = np.arange(self.n_frames) * self.trajectory.timestep
+        layer_array = np.array([0])
+
+        data, resident = self._collect()
+        self.wavefunction_data = data
+        wf = WFData(probe_positions=self.probe_positions, time=time_array, kxs=_as_tensor(kxs), kys=_as_tensor(kys),
+                    layer=layer_array, wavefunction_data=data, probe=self.base_probe)
+        # private riders: let TACAWData transform the device-resident copy without a host round trip
+        wf._engine = eng
+        wf._resident = resident
+        wf._output = self._output
+        return wf
+
+    # ------------------------------------------------------------------------------------------
+    def _collect(self):
+        """Pack the device-resident (P,T_local,nx,ny) into the reference's (P,T,nx,ny,1) array."""
+        eng = self._engine
+        P, nx, ny = self.n_probes, self.nx, self.ny
+        T_local = len(self._frames)
+        if self._world == 1 or self._gather == "none":
+            if self._output == "device":
+                ptr = eng.device_ptr(_native.BUF_WAVEFUNCTION)
+                view = torch.as_tensor(_native.DeviceArray(ptr, (P, eng.n_frames, nx, ny), "<c8", owner=eng),
+                                       device=f"cuda:{eng.device}")
+                return view[:, :T_local].unsqueeze(-1), T_local == eng.n_frames
+            local = eng.wavefunction()[:, :T_local]
+            out = local.astype(np.complex128) if self._dtype == "complex128" else local
+            return _as_tensor(np.ascontiguousarray(out[..., None])), T_local == eng.n_frames
+        # multi-process: one gather of the frame shards (no collective during the frames)
+        ptr = eng.device_ptr(_native.BUF_WAVEFUNCTION)
+        local = torch.as_tensor(_native.DeviceArray(ptr, (P, eng.n_frames, nx, ny), "<c8", owner=eng),
+                                device=f"cuda:{eng.device}")[:, :T_local]
+        full = distributed.gather_frames(local, self.n_frames, dst=None if self._gather == "all" else 0)
+        if full is None:
+            return None, False
+        if self._output == "device":
+            return full.unsqueeze(-1), False
+        full = full.cpu()
+        if self._dtype == "complex128":
+            full = full.to(torch.complex128)
+        return full.unsqueeze(-1), False

@@ -1,0 +1,251 @@
+// Generic batched line FFT for gfx950: LDS-resident Stockham autosort, mixed radix
+// {8,4,2,3,5,7,11,13}, arbitrary line stride.  This is the any-size path (non power-of-two
+// grids such as the reference's 501x491 test grid need it) and the on-device
+// cross-check for the register-resident power-of-two kernels in fft_pow2.h.
+//
+// One workgroup owns a tile of C lines of length N held as LDS[c][n] (float2).  A launch
+// performs:  load -> [FFT a] -> [x M1] -> [FFT b] -> store(x M2, scale, index shift, mode)
+// so the fused slice-loop passes (row: ifft_y, x t, fft_y, x Py;  column: fft_x, x Px, ifft_x)
+// and the potential / TACAW epilogues are single launches.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace msl {
+
+#define MSL_MAX_STAGES 16
+#define MSL_GEN_E 16            // complex values held per thread between the two barriers of a stage
+
+enum { MUL_NONE = 0, MUL_ARRAY = 1, MUL_VEC = 2 };
+enum { STORE_C64 = 0, STORE_POTENTIAL = 1, STORE_INTENSITY = 2 };
+
+struct LineJob {
+    const float2* in;
+    float2* out;
+    float* out_real;            // STORE_POTENTIAL: V (may be null);  STORE_INTENSITY: intensity
+    const float2* tw;           // W_N^j = exp(-2 pi i j / N), j < N (device)
+    const float2* m1;           // after FFT a
+    const float2* m2;           // at store
+    long long n_lines;
+    long long in_es, in_ls, in_is;     // element / line / image strides (float2 units)
+    long long out_es, out_ls, out_is;
+    long long m1_ls;            // MUL_ARRAY: m1[r*m1_ls + n]
+    long long m2_ls;
+    int N, C, lines_per_image;
+    int contiguous_lines;       // 1: neighbouring lines are neighbouring addresses (column / time pass)
+    int fft1, fft2;             // 0 none, +1 forward, -1 inverse (both unnormalised)
+    int m1_kind, m2_kind;
+    int store_mode;
+    int shift_n, shift_r;       // out index: ((n+shift_n)%N, (r+shift_r)%lines_per_image)
+    int n_stages;
+    int radix[MSL_MAX_STAGES];
+    int npad;                   // LDS line pitch (float2)
+    int tw_in_lds;
+    float scale;
+    float sigma;
+};
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+    return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x));
+}
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+// multiply by -i*s  (s=+1 forward rotation, s=-1 inverse)
+__device__ __forceinline__ float2 rot_mi(float2 a, float s) { return make_float2(s * a.y, -s * a.x); }
+
+template <int R>
+__device__ __forceinline__ void butterfly(float2 (&v)[R], float s) {
+    if constexpr (R == 2) {
+        float2 a = v[0], b = v[1];
+        v[0] = cadd(a, b); v[1] = csub(a, b);
+    } else if constexpr (R == 4) {
+        float2 t0 = cadd(v[0], v[2]), t1 = csub(v[0], v[2]);
+        float2 t2 = cadd(v[1], v[3]), t3 = rot_mi(csub(v[1], v[3]), s);
+        v[0] = cadd(t0, t2); v[1] = cadd(t1, t3); v[2] = csub(t0, t2); v[3] = csub(t1, t3);
+    } else if constexpr (R == 8) {
+        const float h = 0.70710678118654752440f;
+        float2 e[4] = {v[0], v[2], v[4], v[6]};
+        float2 o[4] = {v[1], v[3], v[5], v[7]};
+        butterfly<4>(e, s);
+        butterfly<4>(o, s);
+        // o[k] *= W8^k (forward: exp(-i pi k/4)); s flips the sign of the imaginary part
+        float2 w1 = make_float2(h, -s * h), w3 = make_float2(-h, -s * h);
+        o[1] = cmul(o[1], w1);
+        o[2] = rot_mi(o[2], s);
+        o[3] = cmul(o[3], w3);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[k] = cadd(e[k], o[k]); v[k + 4] = csub(e[k], o[k]); }
+    } else {
+        // small-prime DFT, O(R^2): X_q = sum_t v_t W_R^{q t}
+        float2 w[R];
+#pragma unroll
+        for (int m = 0; m < R; ++m) {
+            float sn, cs;
+            sincospif(2.0f * (float)m / (float)R, &sn, &cs);
+            w[m] = make_float2(cs, -s * sn);
+        }
+        float2 x[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            float2 acc = v[0];
+#pragma unroll
+            for (int t = 1; t < R; ++t) {
+                float2 p = cmul(v[t], w[(q * t) % R]);
+                acc = cadd(acc, p);
+            }
+            x[q] = acc;
+        }
+#pragma unroll
+        for (int q = 0; q < R; ++q) v[q] = x[q];
+    }
+}
+
+// One Stockham stage over the whole LDS tile, in place through registers.
+template <int R>
+__device__ __forceinline__ void stockham_stage(float2* tile, const float2* tw, int N, int npad, int C, int Ns,
+                                               float s, int tid, int nthreads) {
+    constexpr int ITERS = (MSL_GEN_E + R - 1) / R;
+    const int nb = N / R;                 // butterflies per line
+    const int total = nb * C;
+    const int twstep = N / (Ns * R);
+    float2 regs[ITERS][R];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        int idx = tid + it * nthreads;
+        if (idx < total) {
+            int c = idx / nb, j = idx - c * nb;
+            int k = j % Ns;
+            const float2* line = tile + (size_t)c * npad;
+            float2 v[R];
+#pragma unroll
+            for (int t = 0; t < R; ++t) v[t] = line[j + t * nb];
+#pragma unroll
+            for (int t = 1; t < R; ++t) {
+                float2 w = tw[((long long)k * t * twstep) % N];
+                w.y *= s;                 // table holds the forward (exp(-i..)) twiddles
+                v[t] = cmul(v[t], w);
+            }
+            butterfly<R>(v, s);
+#pragma unroll
+            for (int t = 0; t < R; ++t) regs[it][t] = v[t];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        int idx = tid + it * nthreads;
+        if (idx < total) {
+            int c = idx / nb, j = idx - c * nb;
+            int k = j % Ns;
+            float2* line = tile + (size_t)c * npad;
+            int base = (j - k) * R + k;
+#pragma unroll
+            for (int t = 0; t < R; ++t) line[base + t * Ns] = regs[it][t];
+        }
+    }
+    __syncthreads();
+}
+
+// RSET selects which radices a kernel instantiation carries (register pressure follows the
+// largest one): 0 = {2,4,8}, 1 = + {3,5,7}, 2 = + {11,13}.
+template <int RSET>
+__device__ __forceinline__ void tile_fft(float2* tile, const float2* tw, const LineJob& job, int C, int dir, int tid,
+                                         int nthreads) {
+    const float s = dir > 0 ? 1.0f : -1.0f;
+    int Ns = 1;
+    for (int st = 0; st < job.n_stages; ++st) {
+        const int R = job.radix[st];
+        switch (R) {
+            case 2: stockham_stage<2>(tile, tw, job.N, job.npad, C, Ns, s, tid, nthreads); break;
+            case 4: stockham_stage<4>(tile, tw, job.N, job.npad, C, Ns, s, tid, nthreads); break;
+            case 8: stockham_stage<8>(tile, tw, job.N, job.npad, C, Ns, s, tid, nthreads); break;
+            default:
+                if constexpr (RSET >= 1) {
+                    if (R == 3) stockham_stage<3>(tile, tw, job.N, job.npad, C, Ns, s, tid, nthreads);
+                    else if (R == 5) stockham_stage<5>(tile, tw, job.N, job.npad, C, Ns, s, tid, nthreads);
+                    else if (R == 7) stockham_stage<7>(tile, tw, job.N, job.npad, C, Ns, s, tid, nthreads);
+                }
+                if constexpr (RSET >= 2) {
+                    if (R == 11) stockham_stage<11>(tile, tw, job.N, job.npad, C, Ns, s, tid, nthreads);
+                    else if (R == 13) stockham_stage<13>(tile, tw, job.N, job.npad, C, Ns, s, tid, nthreads);
+                }
+                break;
+        }
+        Ns *= R;
+    }
+}
+
+template <int RSET>
+__global__ void __launch_bounds__(1024) line_fft_kernel(LineJob job) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float2* tile = reinterpret_cast<float2*>(smem_raw);
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    const int N = job.N, npad = job.npad;
+    const long long line0 = (long long)blockIdx.x * job.C;
+    const int C = (int)min((long long)job.C, job.n_lines - line0);
+    const float2* tw = job.tw;
+    if (job.tw_in_lds) {
+        float2* tws = tile + (size_t)job.C * npad;
+        for (int i = tid; i < N; i += nthreads) tws[i] = job.tw[i];
+        tw = tws;
+    }
+    const int elems = C * N;
+    // ---- load
+    for (int e = tid; e < elems; e += nthreads) {
+        int c, n;
+        if (job.contiguous_lines) { c = e % C; n = e / C; } else { n = e % N; c = e / N; }
+        long long l = line0 + c;
+        long long img = l / job.lines_per_image;
+        long long r = l - img * job.lines_per_image;
+        tile[(size_t)c * npad + n] = job.in[img * job.in_is + r * job.in_ls + (long long)n * job.in_es];
+    }
+    __syncthreads();
+    if (job.fft1) tile_fft<RSET>(tile, tw, job, C, job.fft1, tid, nthreads);
+    if (job.m1_kind != MUL_NONE) {
+        for (int e = tid; e < elems; e += nthreads) {
+            int n = e % N, c = e / N;
+            float2 m;
+            if (job.m1_kind == MUL_VEC) {
+                m = job.m1[n];
+            } else {
+                long long l = line0 + c;
+                long long r = l % job.lines_per_image;
+                m = job.m1[r * job.m1_ls + n];
+            }
+            float2* p = tile + (size_t)c * npad + n;
+            *p = cmul(*p, m);
+        }
+        __syncthreads();
+    }
+    if (job.fft2) tile_fft<RSET>(tile, tw, job, C, job.fft2, tid, nthreads);
+    // ---- store
+    for (int e = tid; e < elems; e += nthreads) {
+        int c, n;
+        if (job.contiguous_lines) { c = e % C; n = e / C; } else { n = e % N; c = e / N; }
+        long long l = line0 + c;
+        long long img = l / job.lines_per_image;
+        long long r = l - img * job.lines_per_image;
+        float2 v = tile[(size_t)c * npad + n];
+        if (job.m2_kind == MUL_VEC) v = cmul(v, job.m2[n]);
+        else if (job.m2_kind == MUL_ARRAY) v = cmul(v, job.m2[r * job.m2_ls + n]);
+        v.x *= job.scale; v.y *= job.scale;
+        int no = n + job.shift_n; if (no >= N) no -= N;
+        long long ro = r + job.shift_r; if (ro >= job.lines_per_image) ro -= job.lines_per_image;
+        long long o = img * job.out_is + ro * job.out_ls + (long long)no * job.out_es;
+        if (job.store_mode == STORE_C64) {
+            job.out[o] = v;
+        } else if (job.store_mode == STORE_POTENTIAL) {
+            // V = Re(ifft2(R)) / (dx^2 dy^2) (scale), t = exp(i sigma V)
+            if (job.out_real) job.out_real[o] = v.x;
+            float sn, cs;
+            sincosf(job.sigma * v.x, &sn, &cs);
+            job.out[o] = make_float2(cs, sn);
+        } else {
+            // TACAW: zero the DC bin (== subtracting the time mean before the FFT), |.|^2
+            float inten = (n == 0) ? 0.0f : fmaf(v.x, v.x, v.y * v.y);
+            job.out_real[o] = inten;
+        }
+    }
+}
+
+}  // namespace msl

@@ -1,0 +1,823 @@
+// libmslice: C-ABI HIP implementation of the multislice hot path for MI355X (gfx950).
+// Entry points are declared in include/mslice.h (each cites the reference function it replaces).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mslice.h"
+#include "fft_generic.h"
+#include "potential.h"
+
+using namespace msl;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct FftPlan {
+    int N = 0;
+    int n_stages = 0;
+    int radix[MSL_MAX_STAGES] = {0};
+    float2* tw = nullptr;       // device twiddles
+    bool ok = false;
+};
+
+enum LaunchKind { K_ROW = 0, K_COL = 1, K_OTHER = 2, K_NKINDS = 3 };
+
+struct EventSet {
+    std::vector<hipEvent_t> ev;
+    std::vector<int> kind;      // kind[i] = kind of the launch between ev[i] and ev[i+1]
+    int used = 0;               // number of events recorded
+    bool pending = false;
+};
+
+}  // namespace
+
+struct msl_handle {
+    msl_config cfg{};
+    hipStream_t stream = nullptr;
+    std::string err;
+    // plans
+    FftPlan plan_x, plan_y, plan_t;
+    // device buffers
+    float2* psi0 = nullptr;
+    float2* psi = nullptr;
+    float2* trans = nullptr;
+    float* V = nullptr;
+    float2* wf = nullptr;
+    float* intensity = nullptr;
+    size_t intensity_elems = 0;
+    float2* pxt = nullptr;      // exp(-i pi lambda dz kx^2)/nx
+    float2* pyt = nullptr;
+    double* d_abcd = nullptr;
+    double* d_lo = nullptr;
+    double* d_hi = nullptr;
+    bool have_kirkland = false, have_slices = false, have_probes = false, have_potential = false, have_exit = false;
+    int frames_done = 0;
+    // potential scratch (grown on demand)
+    size_t atom_cap = 0;
+    double* d_pos = nullptr;
+    int* d_Z = nullptr;
+    int* d_key = nullptr;
+    int* d_order = nullptr;
+    double* d_u1 = nullptr;
+    double* d_u2 = nullptr;
+    float2* d_ex = nullptr;
+    float2* d_ey = nullptr;
+    int* d_counts = nullptr;
+    int* d_start = nullptr;
+    int* d_z2s = nullptr;
+    int* d_species = nullptr;
+    float* d_ff = nullptr;
+    int ff_species_cap = 0;
+    int n_species = 0;
+    double* d_xy = nullptr;
+    // counters
+    msl_counters ctr{};
+    double ms_kind[K_NKINDS] = {0, 0, 0};
+    uint64_t n_kind[K_NKINDS] = {0, 0, 0};
+    std::vector<EventSet> ring;
+    int ring_pos = 0;
+    EventSet* cur = nullptr;
+    int lds_limit = 160 * 1024;
+};
+
+namespace {
+
+int fail(msl_handle* h, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(h, expr)                                                                              \
+    do {                                                                                             \
+        hipError_t _e = (expr);                                                                      \
+        if (_e != hipSuccess)                                                                        \
+            return fail(h, MSL_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+template <typename T>
+int dalloc(msl_handle* h, T** p, size_t n) {
+    if (*p) { (void)hipFree(*p); *p = nullptr; }
+    if (n == 0) return MSL_OK;
+    hipError_t e = hipMalloc((void**)p, n * sizeof(T));
+    if (e != hipSuccess) { *p = nullptr; return fail(h, MSL_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", n * sizeof(T), hipGetErrorString(e)); }
+    return MSL_OK;
+}
+
+bool factorize(int N, FftPlan& pl) {
+    static const int cand[] = {8, 4, 2, 3, 5, 7, 11, 13};
+    pl.N = N; pl.n_stages = 0;
+    int n = N;
+    for (int r : cand) {
+        while (n % r == 0 && n > 1) {
+            if (pl.n_stages >= MSL_MAX_STAGES) return false;
+            pl.radix[pl.n_stages++] = r;
+            n /= r;
+        }
+    }
+    return n == 1;
+}
+
+int make_plan(msl_handle* h, FftPlan& pl, int N) {
+    if (pl.ok && pl.N == N) return MSL_OK;
+    pl.ok = false;
+    if (N < 1) return fail(h, MSL_ERR_INVALID, "FFT length %d", N);
+    if (!factorize(N, pl))
+        return fail(h, MSL_ERR_UNSUPPORTED, "FFT length %d has a prime factor > 13 (no Bluestein path yet)", N);
+    if ((size_t)N * 8 * 2 > (size_t)h->lds_limit)
+        return fail(h, MSL_ERR_UNSUPPORTED, "FFT length %d does not fit the LDS-resident kernel", N);
+    std::vector<float2> tw(N);
+    for (int j = 0; j < N; ++j) {
+        double a = -2.0 * M_PI * (double)j / (double)N;
+        tw[j] = make_float2((float)cos(a), (float)sin(a));
+    }
+    int rc = dalloc(h, &pl.tw, (size_t)N);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpyAsync(pl.tw, tw.data(), N * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    pl.ok = true;
+    return MSL_OK;
+}
+
+// ---- per-launch event timing -------------------------------------------------------------
+int resolve_set(msl_handle* h, EventSet& s) {
+    if (!s.pending) return MSL_OK;
+    if (s.used >= 2) {
+        HIPCHK(h, hipEventSynchronize(s.ev[s.used - 1]));
+        for (int i = 0; i + 1 < s.used; ++i) {
+            float ms = 0.f;
+            HIPCHK(h, hipEventElapsedTime(&ms, s.ev[i], s.ev[i + 1]));
+            int k = s.kind[i];
+            h->ms_kind[k] += ms;
+            h->n_kind[k] += 1;
+        }
+    }
+    s.used = 0; s.pending = false;
+    return MSL_OK;
+}
+
+int begin_timed(msl_handle* h, int max_launches) {
+    if (h->ring.empty()) h->ring.resize(4);
+    EventSet& s = h->ring[h->ring_pos];
+    h->ring_pos = (h->ring_pos + 1) % (int)h->ring.size();
+    int rc = resolve_set(h, s);
+    if (rc) return rc;
+    while ((int)s.ev.size() < max_launches + 1) {
+        hipEvent_t e;
+        HIPCHK(h, hipEventCreate(&e));
+        s.ev.push_back(e);
+    }
+    s.kind.assign(max_launches + 1, K_OTHER);
+    s.used = 0;
+    HIPCHK(h, hipEventRecord(s.ev[s.used++], h->stream));
+    s.pending = true;
+    h->cur = &s;
+    return MSL_OK;
+}
+
+int mark_launch(msl_handle* h, int kind) {
+    EventSet* s = h->cur;
+    if (!s || s->used >= (int)s->ev.size()) return MSL_OK;
+    s->kind[s->used - 1] = kind;
+    HIPCHK(h, hipEventRecord(s->ev[s->used++], h->stream));
+    return MSL_OK;
+}
+
+int resolve_all(msl_handle* h) {
+    for (auto& s : h->ring) { int rc = resolve_set(h, s); if (rc) return rc; }
+    h->cur = nullptr;
+    return MSL_OK;
+}
+
+// ---- generic line-FFT launch ----------------------------------------------------------------
+struct LineArgs {
+    const float2* in = nullptr; float2* out = nullptr; float* out_real = nullptr;
+    long long n_lines = 0; int lines_per_image = 1;
+    long long in_es = 1, in_ls = 0, in_is = 0, out_es = 1, out_ls = 0, out_is = 0;
+    int contiguous_lines = 0;
+    int fft1 = 0, fft2 = 0;
+    int m1_kind = MUL_NONE, m2_kind = MUL_NONE; const float2* m1 = nullptr; const float2* m2 = nullptr;
+    long long m1_ls = 0, m2_ls = 0;
+    int store_mode = STORE_C64; int shift_n = 0, shift_r = 0; float scale = 1.f; float sigma = 0.f;
+};
+
+int launch_lines(msl_handle* h, const FftPlan& pl, const LineArgs& a, int kind) {
+    LineJob job{};
+    job.in = a.in; job.out = a.out; job.out_real = a.out_real; job.tw = pl.tw; job.m1 = a.m1; job.m2 = a.m2;
+    job.n_lines = a.n_lines; job.in_es = a.in_es; job.in_ls = a.in_ls; job.in_is = a.in_is;
+    job.out_es = a.out_es; job.out_ls = a.out_ls; job.out_is = a.out_is; job.m1_ls = a.m1_ls; job.m2_ls = a.m2_ls;
+    job.N = pl.N; job.lines_per_image = a.lines_per_image; job.contiguous_lines = a.contiguous_lines;
+    job.fft1 = a.fft1; job.fft2 = a.fft2; job.m1_kind = a.m1_kind; job.m2_kind = a.m2_kind;
+    job.store_mode = a.store_mode; job.shift_n = a.shift_n; job.shift_r = a.shift_r;
+    job.n_stages = pl.n_stages; for (int i = 0; i < pl.n_stages; ++i) job.radix[i] = pl.radix[i];
+    job.scale = a.scale; job.sigma = a.sigma;
+    const int N = pl.N;
+    const int max_elems = MSL_GEN_E * 1024;
+    int C;
+    if (a.contiguous_lines) C = 16; else C = std::max(1, std::min(16, 8192 / N));
+    C = (int)std::min<long long>(C, a.n_lines);
+    job.npad = a.contiguous_lines ? N + 1 : N;
+    auto lds_need = [&](int c, bool tw) { return (size_t)c * job.npad * 8 + (tw ? (size_t)N * 8 : 0); };
+    while (C > 1 && ((long long)C * N > max_elems || lds_need(C, false) > (size_t)h->lds_limit)) C >>= 1;
+    if ((long long)C * N > max_elems || lds_need(C, false) > (size_t)h->lds_limit)
+        return fail(h, MSL_ERR_UNSUPPORTED, "line length %d too long for the LDS kernel", N);
+    job.C = C;
+    job.tw_in_lds = lds_need(C, true) <= (size_t)h->lds_limit ? 1 : 0;
+    size_t lds = lds_need(C, job.tw_in_lds != 0);
+    int nthreads = (int)(((long long)C * N + MSL_GEN_E - 1) / MSL_GEN_E);
+    nthreads = std::min(1024, std::max(64, (nthreads + 63) / 64 * 64));
+    long long tiles = (a.n_lines + C - 1) / C;
+    if (tiles > 0x7fffffffLL) return fail(h, MSL_ERR_UNSUPPORTED, "too many FFT tiles");
+    int rset = 0;
+    for (int i = 0; i < pl.n_stages; ++i) {
+        if (pl.radix[i] == 3 || pl.radix[i] == 5 || pl.radix[i] == 7) rset = std::max(rset, 1);
+        if (pl.radix[i] > 8) rset = 2;
+    }
+    if (rset == 0) hipLaunchKernelGGL(line_fft_kernel<0>, dim3((unsigned)tiles), dim3(nthreads), lds, h->stream, job);
+    else if (rset == 1) hipLaunchKernelGGL(line_fft_kernel<1>, dim3((unsigned)tiles), dim3(nthreads), lds, h->stream, job);
+    else hipLaunchKernelGGL(line_fft_kernel<2>, dim3((unsigned)tiles), dim3(nthreads), lds, h->stream, job);
+    HIPCHK(h, hipGetLastError());
+    return mark_launch(h, kind);
+}
+
+// row pass over (images x nx) rows of length ny; column pass over (images x ny) columns of length nx
+LineArgs row_args(const msl_handle* h, const float2* in, float2* out, int images) {
+    LineArgs a;
+    a.in = in; a.out = out;
+    a.n_lines = (long long)images * h->cfg.nx; a.lines_per_image = h->cfg.nx;
+    a.in_es = a.out_es = 1; a.in_ls = a.out_ls = h->cfg.ny; a.in_is = a.out_is = (long long)h->cfg.nx * h->cfg.ny;
+    a.contiguous_lines = 0;
+    return a;
+}
+LineArgs col_args(const msl_handle* h, const float2* in, float2* out, int images) {
+    LineArgs a;
+    a.in = in; a.out = out;
+    a.n_lines = (long long)images * h->cfg.ny; a.lines_per_image = h->cfg.ny;
+    a.in_es = a.out_es = h->cfg.ny; a.in_ls = a.out_ls = 1; a.in_is = a.out_is = (long long)h->cfg.nx * h->cfg.ny;
+    a.contiguous_lines = 1;
+    return a;
+}
+
+int fft2_inplace(msl_handle* h, float2* buf, int images, int dir, float scale) {
+    LineArgs r = row_args(h, buf, buf, images);
+    r.fft1 = dir;
+    int rc = launch_lines(h, h->plan_y, r, K_OTHER);
+    if (rc) return rc;
+    LineArgs c = col_args(h, buf, buf, images);
+    c.fft1 = dir; c.scale = scale;
+    return launch_lines(h, h->plan_x, c, K_OTHER);
+}
+
+int ensure_atoms(msl_handle* h, size_t n) {
+    if (n <= h->atom_cap) return MSL_OK;
+    size_t cap = std::max<size_t>(n, h->atom_cap * 3 / 2 + 1024);
+    int rc;
+    if ((rc = dalloc(h, &h->d_pos, cap * 3))) return rc;
+    if ((rc = dalloc(h, &h->d_Z, cap))) return rc;
+    if ((rc = dalloc(h, &h->d_key, cap))) return rc;
+    if ((rc = dalloc(h, &h->d_order, cap))) return rc;
+    if ((rc = dalloc(h, &h->d_u1, cap))) return rc;
+    if ((rc = dalloc(h, &h->d_u2, cap))) return rc;
+    if ((rc = dalloc(h, &h->d_ex, cap * (size_t)h->cfg.nx))) return rc;
+    if ((rc = dalloc(h, &h->d_ey, cap * (size_t)h->cfg.ny))) return rc;
+    h->atom_cap = cap;
+    return MSL_OK;
+}
+
+// The slice loop (generic kernels).  fused_slot < 0: leave real-space exit waves in psi.
+int slice_loop(msl_handle* h, int fused_slot) {
+    const msl_config& c = h->cfg;
+    const int P = c.n_probes, nz = c.nz;
+    const size_t npix = (size_t)c.nx * c.ny;
+    HIPCHK(h, hipMemcpyAsync(h->psi, h->psi0, (size_t)P * npix * sizeof(float2), hipMemcpyDeviceToDevice, h->stream));
+    int rc = begin_timed(h, 2 * nz + 2);
+    if (rc) return rc;
+    const bool fused = fused_slot >= 0;
+    for (int z = 0; z < nz; ++z) {
+        const bool last = (z == nz - 1);
+        LineArgs r = row_args(h, h->psi, h->psi, P);
+        r.fft1 = (z > 0) ? -1 : 0;
+        r.m1_kind = MUL_ARRAY; r.m1 = h->trans + (size_t)z * npix; r.m1_ls = c.ny;
+        if (!last) { r.fft2 = +1; r.m2_kind = MUL_VEC; r.m2 = h->pyt; }
+        else if (fused) { r.fft2 = +1; }
+        if ((rc = launch_lines(h, h->plan_y, r, K_ROW))) return rc;
+        if (!last) {
+            LineArgs k = col_args(h, h->psi, h->psi, P);
+            k.fft1 = +1; k.m1_kind = MUL_VEC; k.m1 = h->pxt; k.fft2 = -1;
+            if ((rc = launch_lines(h, h->plan_x, k, K_COL))) return rc;
+        }
+    }
+    if (fused) {
+        // epilogue: fft along x, fftshift both axes, scatter into (P, T_local, nx, ny)
+        LineArgs k = col_args(h, h->psi, h->wf + (size_t)fused_slot * npix, P);
+        k.fft1 = +1;
+        k.out_is = (long long)c.n_frames * npix;
+        k.shift_n = c.nx / 2; k.shift_r = c.ny / 2;
+        if ((rc = launch_lines(h, h->plan_x, k, K_OTHER))) return rc;
+    }
+    h->cur = nullptr;
+    h->ctr.slice_steps += (uint64_t)P * nz;
+    h->ctr.frames += 1;
+    h->ctr.algorithmic_bytes += (uint64_t)P * nz * 32ull * npix + (uint64_t)nz * 8ull * npix + (fused ? (uint64_t)P * 16ull * npix : 0ull);
+    return MSL_OK;
+}
+
+// Fresnel propagator, separable: P[kx,ky] = exp(-i pi lambda dz kx^2) * exp(-i pi lambda dz ky^2)
+// (multislice.py:273-275), with the 1/(nx ny) of the inverse FFT folded in.
+int fill_propagator(msl_handle* h) {
+    const msl_config& c = h->cfg;
+    auto fill = [&](float2* dst, int n, double d) -> int {
+        std::vector<float2> v(n);
+        for (int m = 0; m < n; ++m) {
+            int f = (m < (n + 1) / 2) ? m : m - n;
+            double k = f * (1.0 / (n * d));
+            double ph = -M_PI * c.wavelength * c.dz * k * k;
+            v[m] = make_float2((float)(cos(ph) / n), (float)(sin(ph) / n));
+        }
+        HIPCHK(h, hipMemcpyAsync(dst, v.data(), n * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        return MSL_OK;
+    };
+    int rc = fill(h->pxt, c.nx, c.dx);
+    if (rc) return rc;
+    return fill(h->pyt, c.ny, c.dy);
+}
+
+}  // namespace
+
+extern "C" {
+
+int msl_abi_version(void) { return MSL_ABI_VERSION; }
+
+const char* msl_last_error(const msl_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int msl_create(const msl_config* cfg, msl_handle** out) {
+    if (!cfg || !out) return fail(nullptr, MSL_ERR_INVALID, "msl_create: null argument");
+    *out = nullptr;
+    if (cfg->nx < 2 || cfg->ny < 2 || cfg->nz < 1 || cfg->n_probes < 1 || cfg->n_frames < 0)
+        return fail(nullptr, MSL_ERR_INVALID, "msl_create: bad grid nx=%d ny=%d nz=%d P=%d T=%d", cfg->nx, cfg->ny, cfg->nz,
+                    cfg->n_probes, cfg->n_frames);
+    if (!(cfg->dx > 0) || !(cfg->dy > 0) || !(cfg->wavelength > 0))
+        return fail(nullptr, MSL_ERR_INVALID, "msl_create: dx, dy, wavelength must be positive");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0)
+        return fail(nullptr, MSL_ERR_HIP, "msl_create: no HIP device available (%s)", hipGetErrorString(e));
+    if (cfg->device < 0 || cfg->device >= ndev)
+        return fail(nullptr, MSL_ERR_INVALID, "msl_create: device %d out of range (have %d)", cfg->device, ndev);
+    msl_handle* h = new (std::nothrow) msl_handle();
+    if (!h) return fail(nullptr, MSL_ERR_NOMEM, "msl_create: out of host memory");
+    h->cfg = *cfg;
+    auto bail = [&](int rc) { g_create_error = h->err; msl_destroy(h); return rc; };
+    if (hipSetDevice(cfg->device) != hipSuccess) return bail(fail(h, MSL_ERR_HIP, "hipSetDevice(%d) failed", cfg->device));
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(h, MSL_ERR_HIP, "hipStreamCreate failed"));
+    (void)hipFuncSetAttribute((const void*)line_fft_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
+    (void)hipFuncSetAttribute((const void*)line_fft_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
+    (void)hipFuncSetAttribute((const void*)line_fft_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
+    int rc;
+    if ((rc = make_plan(h, h->plan_x, cfg->nx))) return bail(rc);
+    if ((rc = make_plan(h, h->plan_y, cfg->ny))) return bail(rc);
+    const size_t npix = (size_t)cfg->nx * cfg->ny;
+    if ((rc = dalloc(h, &h->psi0, npix * cfg->n_probes))) return bail(rc);
+    if ((rc = dalloc(h, &h->psi, npix * cfg->n_probes))) return bail(rc);
+    if ((rc = dalloc(h, &h->trans, npix * cfg->nz))) return bail(rc);
+    if (cfg->keep_potential && (rc = dalloc(h, &h->V, npix * cfg->nz))) return bail(rc);
+    if (cfg->n_frames > 0) {
+        if ((rc = dalloc(h, &h->wf, npix * cfg->n_probes * cfg->n_frames))) return bail(rc);
+        if (hipMemsetAsync(h->wf, 0, npix * cfg->n_probes * cfg->n_frames * sizeof(float2), h->stream) != hipSuccess)
+            return bail(fail(h, MSL_ERR_HIP, "memset failed"));
+    }
+    if ((rc = dalloc(h, &h->pxt, (size_t)cfg->nx))) return bail(rc);
+    if ((rc = dalloc(h, &h->pyt, (size_t)cfg->ny))) return bail(rc);
+    if ((rc = dalloc(h, &h->d_lo, (size_t)cfg->nz))) return bail(rc);
+    if ((rc = dalloc(h, &h->d_hi, (size_t)cfg->nz))) return bail(rc);
+    if ((rc = dalloc(h, &h->d_abcd, (size_t)103 * 12))) return bail(rc);
+    if ((rc = dalloc(h, &h->d_z2s, (size_t)104))) return bail(rc);
+    if ((rc = dalloc(h, &h->d_species, (size_t)104))) return bail(rc);
+    if ((rc = dalloc(h, &h->d_xy, (size_t)2 * cfg->n_probes))) return bail(rc);
+    if ((rc = fill_propagator(h))) return bail(rc);
+    *out = h;
+    return MSL_OK;
+}
+
+int msl_destroy(msl_handle* h) {
+    if (!h) return MSL_OK;
+    (void)hipSetDevice(h->cfg.device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (auto& s : h->ring) for (auto e : s.ev) (void)hipEventDestroy(e);
+    void* bufs[] = {h->psi0, h->psi, h->trans, h->V, h->wf, h->intensity, h->pxt, h->pyt, h->d_abcd, h->d_lo, h->d_hi,
+                    h->d_pos, h->d_Z, h->d_key, h->d_order, h->d_u1, h->d_u2, h->d_ex, h->d_ey, h->d_counts, h->d_start,
+                    h->d_z2s, h->d_species, h->d_ff, h->d_xy, h->plan_x.tw, h->plan_y.tw, h->plan_t.tw};
+    for (void* b : bufs) if (b) (void)hipFree(b);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return MSL_OK;
+}
+
+int msl_set_kirkland(msl_handle* h, const double* abcd) {
+    if (!h || !abcd) return fail(h, MSL_ERR_INVALID, "msl_set_kirkland: null argument");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipMemcpyAsync(h->d_abcd, abcd, 103 * 12 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->have_kirkland = true;
+    h->n_species = 0;
+    return MSL_OK;
+}
+
+int msl_set_slices(msl_handle* h, const double* lo, const double* hi) {
+    if (!h || !lo || !hi) return fail(h, MSL_ERR_INVALID, "msl_set_slices: null argument");
+    for (int s = 0; s < h->cfg.nz; ++s)
+        if (!(hi[s] > lo[s]) || (s > 0 && lo[s] < lo[s - 1]))
+            return fail(h, MSL_ERR_INVALID, "msl_set_slices: edges must be increasing with hi>lo (slice %d)", s);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipMemcpyAsync(h->d_lo, lo, h->cfg.nz * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_hi, hi, h->cfg.nz * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->have_slices = true;
+    return MSL_OK;
+}
+
+int msl_set_beam(msl_handle* h, double wavelength, double sigma, double dz) {
+    if (!h) return fail(h, MSL_ERR_INVALID, "null handle");
+    if (!(wavelength > 0)) return fail(h, MSL_ERR_INVALID, "msl_set_beam: wavelength must be positive");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    h->cfg.wavelength = wavelength; h->cfg.sigma = sigma; h->cfg.dz = dz;
+    int rc = fill_propagator(h);
+    if (rc) return rc;
+    if (h->have_potential) {
+        if (!h->V) return fail(h, MSL_ERR_STATE, "msl_set_beam: potential present but V not kept (keep_potential=0); rebuild the potential");
+        const size_t n = (size_t)h->cfg.nx * h->cfg.ny * h->cfg.nz;
+        hipLaunchKernelGGL(transmission_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->trans, h->V,
+                           (long long)n, (float)sigma);
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    return MSL_OK;
+}
+
+int msl_resize_probes(msl_handle* h, int32_t n_probes) {
+    if (!h) return fail(h, MSL_ERR_INVALID, "null handle");
+    if (n_probes < 1) return fail(h, MSL_ERR_INVALID, "msl_resize_probes: need at least one probe");
+    if (h->wf && n_probes != h->cfg.n_probes) return fail(h, MSL_ERR_STATE, "msl_resize_probes: handle owns a (P,T,nx,ny) result buffer");
+    if (n_probes == h->cfg.n_probes) return MSL_OK;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const size_t npix = (size_t)h->cfg.nx * h->cfg.ny;
+    int rc;
+    if ((rc = dalloc(h, &h->psi0, npix * n_probes))) return rc;
+    if ((rc = dalloc(h, &h->psi, npix * n_probes))) return rc;
+    if ((rc = dalloc(h, &h->d_xy, (size_t)2 * n_probes))) return rc;
+    h->cfg.n_probes = n_probes;
+    h->have_probes = false; h->have_exit = false;
+    return MSL_OK;
+}
+
+int msl_shift_probes(msl_handle* h, const float* base, const double* xy, int32_t n_probes) {
+    if (!h || !base || !xy) return fail(h, MSL_ERR_INVALID, "msl_shift_probes: null argument");
+    if (n_probes != h->cfg.n_probes) return fail(h, MSL_ERR_INVALID, "msl_shift_probes: %d probes, handle has %d", n_probes, h->cfg.n_probes);
+    const msl_config& c = h->cfg;
+    HIPCHK(h, hipSetDevice(c.device));
+    const size_t npix = (size_t)c.nx * c.ny;
+    float2* bk = nullptr;
+    int rc = dalloc(h, &bk, npix);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpyAsync(bk, base, npix * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_xy, xy, 2 * sizeof(double) * n_probes, hipMemcpyHostToDevice, h->stream));
+    h->cur = nullptr;
+    rc = fft2_inplace(h, bk, 1, +1, 1.0f);
+    if (rc == MSL_OK) {
+        const long long total = (long long)npix * n_probes;
+        hipLaunchKernelGGL(probe_ramp_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, h->psi0, bk, h->d_xy,
+                           n_probes, c.nx, c.ny, 1.0 / (c.nx * c.dx), 1.0 / (c.ny * c.dy));
+        if (hipGetLastError() != hipSuccess) rc = fail(h, MSL_ERR_HIP, "probe_ramp_kernel launch failed");
+    }
+    if (rc == MSL_OK) rc = fft2_inplace(h, h->psi0, n_probes, -1, 1.0f / ((float)c.nx * (float)c.ny));
+    hipError_t e = hipStreamSynchronize(h->stream);
+    (void)hipFree(bk);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(h, MSL_ERR_HIP, "msl_shift_probes: %s", hipGetErrorString(e));
+    h->have_probes = true;
+    return MSL_OK;
+}
+
+int msl_set_probes(msl_handle* h, double mrad, const double* xy, int32_t n_probes) {
+    if (!h || !xy) return fail(h, MSL_ERR_INVALID, "msl_set_probes: null argument");
+    if (n_probes != h->cfg.n_probes) return fail(h, MSL_ERR_INVALID, "msl_set_probes: %d probes, handle has %d", n_probes, h->cfg.n_probes);
+    if (mrad < 0) return fail(h, MSL_ERR_INVALID, "msl_set_probes: negative aperture");
+    const msl_config& c = h->cfg;
+    HIPCHK(h, hipSetDevice(c.device));
+    HIPCHK(h, hipMemcpyAsync(h->d_xy, xy, 2 * sizeof(double) * n_probes, hipMemcpyHostToDevice, h->stream));
+    const long long total = (long long)c.nx * c.ny * n_probes;
+    const double lx = c.nx * c.dx, ly = c.ny * c.dy;
+    hipLaunchKernelGGL(probe_kspace_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, h->psi0, h->d_xy,
+                       n_probes, c.nx, c.ny, 1.0 / lx, 1.0 / ly, 1.0 / (c.nx * c.dx), 1.0 / (c.ny * c.dy),
+                       (mrad * 1e-3) / c.wavelength, mrad == 0 ? 1 : 0);
+    HIPCHK(h, hipGetLastError());
+    int rc = fft2_inplace(h, h->psi0, n_probes, -1, 1.0f / ((float)c.nx * (float)c.ny));
+    if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->have_probes = true;
+    return MSL_OK;
+}
+
+int msl_upload_probes(msl_handle* h, const float* c64, int32_t n_probes) {
+    if (!h || !c64) return fail(h, MSL_ERR_INVALID, "msl_upload_probes: null argument");
+    if (n_probes != h->cfg.n_probes) return fail(h, MSL_ERR_INVALID, "msl_upload_probes: %d probes, handle has %d", n_probes, h->cfg.n_probes);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipMemcpyAsync(h->psi0, c64, (size_t)n_probes * h->cfg.nx * h->cfg.ny * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->have_probes = true;
+    return MSL_OK;
+}
+
+int msl_build_potential(msl_handle* h, const double* pos, const int32_t* Z, int64_t n, int32_t ax1, int32_t ax2, int32_t axs) {
+    if (!h || (n > 0 && (!pos || !Z))) return fail(h, MSL_ERR_INVALID, "msl_build_potential: null argument");
+    if (!h->have_kirkland) return fail(h, MSL_ERR_STATE, "msl_build_potential: call msl_set_kirkland first");
+    if (!h->have_slices) return fail(h, MSL_ERR_STATE, "msl_build_potential: call msl_set_slices first");
+    if (n < 0 || n > 0x7fffffff) return fail(h, MSL_ERR_INVALID, "msl_build_potential: bad atom count");
+    int axes_seen = (1 << ax1) | (1 << ax2) | (1 << axs);
+    if (ax1 < 0 || ax1 > 2 || ax2 < 0 || ax2 > 2 || axs < 0 || axs > 2 || axes_seen != 7)
+        return fail(h, MSL_ERR_INVALID, "msl_build_potential: axes must be a permutation of 0,1,2");
+    const msl_config& c = h->cfg;
+    HIPCHK(h, hipSetDevice(c.device));
+    const size_t npix = (size_t)c.nx * c.ny;
+    // species present (sorted ascending, like np.unique)
+    int z2s[104];
+    for (int i = 0; i < 104; ++i) z2s[i] = -1;
+    for (int64_t a = 0; a < n; ++a) {
+        if (Z[a] < 1 || Z[a] > 103) return fail(h, MSL_ERR_INVALID, "msl_build_potential: atomic number %d out of 1..103", Z[a]);
+        z2s[Z[a]] = 0;
+    }
+    int species[104], nsp = 0;
+    for (int z = 1; z <= 103; ++z) if (z2s[z] == 0) { z2s[z] = nsp; species[nsp++] = z; }
+    int rc;
+    hipEvent_t e0, e1;
+    HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
+    HIPCHK(h, hipEventRecord(e0, h->stream));
+    if (nsp > h->ff_species_cap) {
+        if ((rc = dalloc(h, &h->d_ff, npix * nsp))) return rc;
+        h->ff_species_cap = nsp;
+    }
+    const int nkeys = c.nz * std::max(nsp, 1);
+    if ((rc = dalloc(h, &h->d_counts, (size_t)nkeys + 1))) return rc;
+    if ((rc = dalloc(h, &h->d_start, (size_t)nkeys + 1))) return rc;
+    if ((rc = ensure_atoms(h, (size_t)n))) return rc;
+    HIPCHK(h, hipMemsetAsync(h->d_counts, 0, ((size_t)nkeys + 1) * sizeof(int), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->trans, 0, npix * c.nz * sizeof(float2), h->stream));
+    if (n > 0 && nsp > 0) {
+        HIPCHK(h, hipMemcpyAsync(h->d_z2s, z2s, sizeof z2s, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->d_species, species, nsp * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->d_pos, pos, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->d_Z, Z, (size_t)n * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        const double lx = c.nx * c.dx, ly = c.ny * c.dy;
+        long long tot = (long long)npix * nsp;
+        hipLaunchKernelGGL(formfactor_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, h->d_ff, h->d_abcd,
+                           h->d_species, nsp, c.nx, c.ny, 1.0 / lx, 1.0 / ly);
+        hipLaunchKernelGGL(atom_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d_pos, h->d_Z,
+                           (long long)n, h->d_z2s, h->d_lo, h->d_hi, c.nz, nsp, ax1, ax2, axs, 1.0 / lx, 1.0 / ly, h->d_key,
+                           h->d_u1, h->d_u2, h->d_counts);
+        hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(64), 0, h->stream, h->d_counts, h->d_start, nkeys);
+        hipLaunchKernelGGL(bin_fill_kernel, dim3(nkeys), dim3(64), 0, h->stream, h->d_key, (long long)n, h->d_start, h->d_order);
+        HIPCHK(h, hipGetLastError());
+        int n_sorted = 0;
+        HIPCHK(h, hipMemcpyAsync(&n_sorted, h->d_start + nkeys, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (n_sorted > 0) {
+            long long tx = (long long)n_sorted * c.nx, ty = (long long)n_sorted * c.ny;
+            hipLaunchKernelGGL(phase_table_kernel, dim3((unsigned)((tx + 255) / 256)), dim3(256), 0, h->stream, h->d_ex, h->d_u1,
+                               h->d_order, n_sorted, c.nx);
+            hipLaunchKernelGGL(phase_table_kernel, dim3((unsigned)((ty + 255) / 256)), dim3(256), 0, h->stream, h->d_ey, h->d_u2,
+                               h->d_order, n_sorted, c.ny);
+            const int tiles_x = (c.nx + SF_TILE - 1) / SF_TILE, tiles_y = (c.ny + SF_TILE - 1) / SF_TILE;
+            hipLaunchKernelGGL(structure_factor_kernel, dim3(tiles_x * tiles_y, c.nz), dim3(256), 0, h->stream, h->trans, h->d_ex,
+                               h->d_ey, h->d_ff, h->d_start, nsp, c.nx, c.ny, tiles_y);
+            HIPCHK(h, hipGetLastError());
+        }
+    }
+    h->n_species = nsp;
+    // V_s = Re ifft2(R_s) / (dx^2 dy^2);  t_s = exp(i sigma V_s)  -- in place over the (nz,nx,ny) buffer
+    LineArgs r = row_args(h, h->trans, h->trans, c.nz);
+    r.fft1 = -1;
+    if ((rc = launch_lines(h, h->plan_y, r, K_OTHER))) return rc;
+    LineArgs k = col_args(h, h->trans, h->trans, c.nz);
+    k.fft1 = -1;
+    k.scale = (float)(1.0 / ((double)c.nx * c.ny) / (c.dx * c.dx * c.dy * c.dy));
+    k.store_mode = STORE_POTENTIAL; k.out_real = h->V; k.sigma = (float)c.sigma;
+    if ((rc = launch_lines(h, h->plan_x, k, K_OTHER))) return rc;
+    HIPCHK(h, hipEventRecord(e1, h->stream));
+    HIPCHK(h, hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
+    h->ctr.ms_potential += ms;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    h->have_potential = true;
+    return MSL_OK;
+}
+
+int msl_upload_potential(msl_handle* h, const float* V) {
+    if (!h || !V) return fail(h, MSL_ERR_INVALID, "msl_upload_potential: null argument");
+    const msl_config& c = h->cfg;
+    HIPCHK(h, hipSetDevice(c.device));
+    const size_t n = (size_t)c.nx * c.ny * c.nz;
+    float* dst = h->V;
+    float* tmp = nullptr;
+    if (!dst) { int rc = dalloc(h, &tmp, n); if (rc) return rc; dst = tmp; }
+    HIPCHK(h, hipMemcpyAsync(dst, V, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(transmission_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->trans, dst, (long long)n,
+                       (float)c.sigma);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (tmp) (void)hipFree(tmp);
+    h->have_potential = true;
+    return MSL_OK;
+}
+
+static int run_loop(msl_handle* h, int slot) {
+    if (!h) return fail(h, MSL_ERR_INVALID, "null handle");
+    if (!h->have_probes) return fail(h, MSL_ERR_STATE, "propagate: no probes (msl_set_probes / msl_upload_probes)");
+    if (!h->have_potential) return fail(h, MSL_ERR_STATE, "propagate: no potential (msl_build_potential / msl_upload_potential)");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    hipEvent_t e0, e1;
+    HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
+    HIPCHK(h, hipEventRecord(e0, h->stream));
+    int rc = slice_loop(h, slot);
+    if (rc) return rc;
+    HIPCHK(h, hipEventRecord(e1, h->stream));
+    HIPCHK(h, hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
+    h->ctr.ms_propagate += ms;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return MSL_OK;
+}
+
+int msl_propagate(msl_handle* h) {
+    int rc = run_loop(h, -1);
+    if (rc == MSL_OK) h->have_exit = true;
+    return rc;
+}
+
+int msl_propagate_frame(msl_handle* h, int32_t slot) {
+    if (!h) return fail(h, MSL_ERR_INVALID, "null handle");
+    if (!h->wf) return fail(h, MSL_ERR_STATE, "msl_propagate_frame: handle created with n_frames == 0");
+    if (slot < 0 || slot >= h->cfg.n_frames) return fail(h, MSL_ERR_INVALID, "msl_propagate_frame: slot %d out of range [0,%d)", slot, h->cfg.n_frames);
+    return run_loop(h, slot);
+}
+
+int msl_tacaw(msl_handle* h, const void* d_src, void* d_dst, int64_t batch, int32_t T, int64_t npix) {
+    if (!h) return fail(h, MSL_ERR_INVALID, "null handle");
+    const msl_config& c = h->cfg;
+    HIPCHK(h, hipSetDevice(c.device));
+    const float2* src = (const float2*)d_src;
+    float* dst = (float*)d_dst;
+    if (!src) {
+        if (!h->wf) return fail(h, MSL_ERR_STATE, "msl_tacaw: no wavefunction buffer");
+        src = h->wf; batch = c.n_probes; T = c.n_frames; npix = (int64_t)c.nx * c.ny;
+        size_t need = (size_t)batch * T * npix;
+        if (h->intensity_elems != need) {
+            int rc = dalloc(h, &h->intensity, need);
+            if (rc) return rc;
+            h->intensity_elems = need;
+        }
+        dst = h->intensity;
+    } else if (!dst) {
+        return fail(h, MSL_ERR_INVALID, "msl_tacaw: src given without dst");
+    }
+    if (T < 2) return fail(h, MSL_ERR_INVALID, "msl_tacaw: needs at least 2 frames (got %d)", T);
+    if (batch < 1 || npix < 1) return fail(h, MSL_ERR_INVALID, "msl_tacaw: bad batch/npix");
+    int rc = make_plan(h, h->plan_t, T);
+    if (rc) return rc;
+    hipEvent_t e0, e1;
+    HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
+    HIPCHK(h, hipEventRecord(e0, h->stream));
+    LineArgs a;
+    a.in = src; a.out = nullptr; a.out_real = dst;
+    a.n_lines = (long long)batch * npix; a.lines_per_image = (int)npix;
+    if (npix > 0x7fffffffLL) return fail(h, MSL_ERR_UNSUPPORTED, "msl_tacaw: npix too large");
+    a.in_es = a.out_es = npix; a.in_ls = a.out_ls = 1; a.in_is = a.out_is = (long long)T * npix;
+    a.contiguous_lines = 1; a.fft1 = +1; a.store_mode = STORE_INTENSITY; a.shift_n = T / 2;
+    h->cur = nullptr;
+    if ((rc = launch_lines(h, h->plan_t, a, K_OTHER))) return rc;
+    HIPCHK(h, hipEventRecord(e1, h->stream));
+    HIPCHK(h, hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
+    h->ctr.ms_tacaw += ms;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return MSL_OK;
+}
+
+size_t msl_buffer_bytes(const msl_handle* h, msl_buffer what) {
+    if (!h) return 0;
+    const msl_config& c = h->cfg;
+    const size_t npix = (size_t)c.nx * c.ny;
+    switch (what) {
+        case MSL_BUF_PROBES: case MSL_BUF_EXIT: return npix * c.n_probes * 8;
+        case MSL_BUF_POTENTIAL: return h->V ? npix * c.nz * 4 : 0;
+        case MSL_BUF_TRANSMISSION: return npix * c.nz * 8;
+        case MSL_BUF_WAVEFUNCTION: return h->wf ? npix * c.n_probes * c.n_frames * 8 : 0;
+        case MSL_BUF_INTENSITY: return h->intensity_elems * 4;
+        case MSL_BUF_FORMFACTOR: return npix * h->n_species * 4;
+    }
+    return 0;
+}
+
+void* msl_device_ptr(msl_handle* h, msl_buffer what) {
+    if (!h) return nullptr;
+    switch (what) {
+        case MSL_BUF_PROBES: return h->psi0;
+        case MSL_BUF_EXIT: return h->psi;
+        case MSL_BUF_POTENTIAL: return h->V;
+        case MSL_BUF_TRANSMISSION: return h->trans;
+        case MSL_BUF_WAVEFUNCTION: return h->wf;
+        case MSL_BUF_INTENSITY: return h->intensity;
+        case MSL_BUF_FORMFACTOR: return h->d_ff;
+    }
+    return nullptr;
+}
+
+int msl_download(msl_handle* h, msl_buffer what, void* dst, size_t bytes, int64_t first, int64_t count) {
+    if (!h || !dst) return fail(h, MSL_ERR_INVALID, "msl_download: null argument");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const char* src = (const char*)msl_device_ptr(h, what);
+    size_t total = msl_buffer_bytes(h, what);
+    if (!src || total == 0) return fail(h, MSL_ERR_STATE, "msl_download: buffer %d not available", (int)what);
+    if (what == MSL_BUF_EXIT && !h->have_exit) return fail(h, MSL_ERR_STATE, "msl_download: no exit waves (call msl_propagate)");
+    size_t off = 0, len = total;
+    if (count > 0) {
+        if (what != MSL_BUF_WAVEFUNCTION && what != MSL_BUF_INTENSITY)
+            return fail(h, MSL_ERR_INVALID, "msl_download: ranges only for wavefunction/intensity");
+        size_t per = total / h->cfg.n_probes;
+        if (first < 0 || first + count > h->cfg.n_probes) return fail(h, MSL_ERR_INVALID, "msl_download: probe range out of bounds");
+        off = per * first; len = per * count;
+    }
+    if (bytes != len) return fail(h, MSL_ERR_INVALID, "msl_download: dst holds %zu bytes, buffer slice is %zu", bytes, len);
+    HIPCHK(h, hipMemcpyAsync(dst, src + off, len, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return MSL_OK;
+}
+
+int msl_synchronize(msl_handle* h) {
+    if (!h) return fail(h, MSL_ERR_INVALID, "null handle");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return MSL_OK;
+}
+
+int msl_get_counters(const msl_handle* hc, msl_counters* out) {
+    msl_handle* h = const_cast<msl_handle*>(hc);
+    if (!h || !out) return fail(h, MSL_ERR_INVALID, "msl_get_counters: null argument");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    int rc = resolve_all(h);
+    if (rc) return rc;
+    h->ctr.slice_kernel_launches = h->n_kind[K_ROW] + h->n_kind[K_COL];
+    h->ctr.ms_slice_kernels = h->ms_kind[K_ROW] + h->ms_kind[K_COL];
+    h->ctr.row_launches = h->n_kind[K_ROW]; h->ctr.ms_row = h->ms_kind[K_ROW];
+    h->ctr.col_launches = h->n_kind[K_COL]; h->ctr.ms_col = h->ms_kind[K_COL];
+    *out = h->ctr;
+    return MSL_OK;
+}
+
+int msl_reset_counters(msl_handle* h) {
+    if (!h) return fail(h, MSL_ERR_INVALID, "null handle");
+    int rc = resolve_all(h);
+    if (rc) return rc;
+    h->ctr = msl_counters{};
+    for (int k = 0; k < K_NKINDS; ++k) { h->ms_kind[k] = 0; h->n_kind[k] = 0; }
+    return MSL_OK;
+}
+
+int msl_fft2_host(msl_handle* h, const float* in, float* out, int32_t batch, int32_t dir) {
+    if (!h || !in || !out) return fail(h, MSL_ERR_INVALID, "msl_fft2_host: null argument");
+    if (batch < 1 || (dir != 1 && dir != -1)) return fail(h, MSL_ERR_INVALID, "msl_fft2_host: bad batch/dir");
+    const msl_config& c = h->cfg;
+    HIPCHK(h, hipSetDevice(c.device));
+    const size_t n = (size_t)batch * c.nx * c.ny;
+    float2* buf = nullptr;
+    int rc = dalloc(h, &buf, n);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpyAsync(buf, in, n * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+    h->cur = nullptr;
+    rc = fft2_inplace(h, buf, batch, dir, dir < 0 ? 1.0f / ((float)c.nx * (float)c.ny) : 1.0f);
+    if (rc == MSL_OK) {
+        hipError_t e = hipMemcpyAsync(out, buf, n * sizeof(float2), hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) rc = fail(h, MSL_ERR_HIP, "msl_fft2_host copy back: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(buf);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,244 @@
+// Kirkland projected-potential rasteriser (reciprocal-space form) and probe builder for gfx950.
+//
+// Reference algorithm (src/multislice/potentials.py:253-342):
+//   R_s[kx,ky] = sum_Z f_Z(kx^2+ky^2) * sum_{a in Z, slice s} exp(-2 pi i (kx x_a + ky y_a))
+//   V_s = Re ifft2(R_s) / (dx^2 dy^2)
+// The double sum is a complex outer-product accumulation per (slice, species).  Phases are
+// formed as integer-frequency x fractional-coordinate products reduced in float64 (naive fp32
+// 2 pi k x loses ~2e-4 rad at k=5/A, x=100 A), then evaluated with sincospi.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace msl {
+
+__device__ __forceinline__ int signed_freq(int m, int n) { return (m < (n + 1) / 2) ? m : m - n; }
+
+// f_Z(q^2) on the (nx,ny) grid for each species present; reference potentials.py:79-96.
+// abcd: (103,3,4) doubles; species: n_species atomic numbers.
+__global__ void formfactor_kernel(float* __restrict__ ff, const double* __restrict__ abcd,
+                                  const int* __restrict__ species, int n_species, int nx, int ny,
+                                  double inv_lx, double inv_ly) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long npix = (long long)nx * ny;
+    if (i >= npix * n_species) return;
+    int sp = (int)(i / npix);
+    long long p = i - (long long)sp * npix;
+    int mx = (int)(p / ny), my = (int)(p - (long long)mx * ny);
+    double kx = signed_freq(mx, nx) * inv_lx, ky = signed_freq(my, ny) * inv_ly;
+    double q2 = kx * kx + ky * ky;
+    const double* t = abcd + (size_t)(species[sp] - 1) * 12;
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        s1 += t[j * 4 + 0] / (q2 + t[j * 4 + 1]);
+        s2 += t[j * 4 + 2] * exp(-t[j * 4 + 3] * q2);
+    }
+    ff[i] = (float)(s1 + s2);
+}
+
+// Per atom: species index, slice index -> sort key (or -1 when the atom belongs to no slice /
+// unknown species), and fractional in-plane coordinates.  Slice rule: potentials.py:302-307.
+__global__ void atom_prep_kernel(const double* __restrict__ pos, const int* __restrict__ Z, long long n,
+                                 const int* __restrict__ z_to_species, const double* __restrict__ lo,
+                                 const double* __restrict__ hi, int nz, int n_species, int ax1, int ax2, int axs,
+                                 double inv_l1, double inv_l2, int* __restrict__ key, double* __restrict__ u1,
+                                 double* __restrict__ u2, int* __restrict__ counts) {
+    long long a = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n) return;
+    double zc = pos[a * 3 + axs];
+    int zz = Z[a];
+    int sp = (zz >= 1 && zz <= 103) ? z_to_species[zz] : -1;
+    // binary search for the last slice with lo[s] <= zc, then test the reference's [lo,hi) masks
+    int s = -1;
+    if (zc >= lo[0]) {
+        int l = 0, r = nz - 1;
+        while (l < r) {
+            int m = (l + r + 1) >> 1;
+            if (lo[m] <= zc) l = m; else r = m - 1;
+        }
+        for (int c = l; c >= 0 && c >= l - 1; --c) {
+            if (zc >= lo[c] && zc < hi[c]) { s = c; break; }
+        }
+    }
+    int k = (s >= 0 && sp >= 0) ? s * n_species + sp : -1;
+    key[a] = k;
+    u1[a] = pos[a * 3 + ax1] * inv_l1;
+    u2[a] = pos[a * 3 + ax2] * inv_l2;
+    if (k >= 0) atomicAdd(&counts[k], 1);
+}
+
+// Exclusive scan of the (nz*n_species) bin counts; one workgroup, serial over a small array.
+__global__ void bin_scan_kernel(const int* __restrict__ counts, int* __restrict__ start, int nkeys) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        int acc = 0;
+        for (int i = 0; i < nkeys; ++i) { start[i] = acc; acc += counts[i]; }
+        start[nkeys] = acc;
+    }
+}
+
+// Stable compaction: one wave per key collects its atoms in original order (deterministic sums).
+__global__ void bin_fill_kernel(const int* __restrict__ key, long long n, const int* __restrict__ start,
+                                int* __restrict__ order) {
+    const int mykey = blockIdx.x;
+    const int lane = threadIdx.x;
+    int pos = start[mykey];
+    if (start[mykey + 1] == pos) return;
+    for (long long a0 = 0; a0 < n; a0 += 64) {
+        long long a = a0 + lane;
+        bool f = (a < n) && (key[a] == mykey);
+        unsigned long long m = __ballot(f);
+        if (f) order[pos + __popcll(m & ((1ull << lane) - 1ull))] = (int)a;
+        pos += __popcll(m);
+    }
+}
+
+// table[i][m] = exp(-2 pi i * f(m) * u[order[i]]),  f = signed FFT frequency index
+__global__ void phase_table_kernel(float2* __restrict__ table, const double* __restrict__ u,
+                                   const int* __restrict__ order, int n_sorted, int n) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)n_sorted * n) return;
+    int a = (int)(i / n), m = (int)(i - (long long)a * n);
+    double t = (double)signed_freq(m, n) * u[order[a]];
+    t -= rint(t);
+    float sn, cs;
+    sincospif((float)(-2.0 * t), &sn, &cs);
+    table[i] = make_float2(cs, sn);
+}
+
+// R[s][kx][ky] = sum_species ff[sp][kx][ky] * sum_{atoms of (s,sp)} ex[a][kx] * ey[a][ky]
+// 64x64 output tile per workgroup, 4x4 complex micro-tile per thread, atoms staged through LDS.
+#define SF_TILE 64
+#define SF_ATOMS 16
+__global__ void __launch_bounds__(256) structure_factor_kernel(float2* __restrict__ recip,
+                                                               const float2* __restrict__ ex,
+                                                               const float2* __restrict__ ey,
+                                                               const float* __restrict__ ff,
+                                                               const int* __restrict__ start, int n_species, int nx,
+                                                               int ny, int tiles_y) {
+    __shared__ float2 sx[SF_ATOMS][SF_TILE];
+    __shared__ float2 sy[SF_ATOMS][SF_TILE];
+    const int s = blockIdx.y;
+    const int tile = blockIdx.x;
+    const int kx0 = (tile / tiles_y) * SF_TILE, ky0 = (tile % tiles_y) * SF_TILE;
+    const int tid = threadIdx.x;
+    const int tx = tid & 15, ty = tid >> 4;
+    float2 total[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) total[i][j] = make_float2(0.f, 0.f);
+
+    for (int sp = 0; sp < n_species; ++sp) {
+        const int a_begin = start[s * n_species + sp], a_end = start[s * n_species + sp + 1];
+        if (a_begin == a_end) continue;
+        float2 acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = make_float2(0.f, 0.f);
+        for (int a0 = a_begin; a0 < a_end; a0 += SF_ATOMS) {
+            __syncthreads();
+            // stage SF_ATOMS x 64 phases of each axis (zero-fill past the segment / the grid edge)
+            for (int e = tid; e < SF_ATOMS * SF_TILE; e += 256) {
+                int a = e / SF_TILE, m = e % SF_TILE;
+                bool ok = (a0 + a) < a_end;
+                sx[a][m] = (ok && kx0 + m < nx) ? ex[(size_t)(a0 + a) * nx + kx0 + m] : make_float2(0.f, 0.f);
+                sy[a][m] = (ok && ky0 + m < ny) ? ey[(size_t)(a0 + a) * ny + ky0 + m] : make_float2(0.f, 0.f);
+            }
+            __syncthreads();
+#pragma unroll 4
+            for (int a = 0; a < SF_ATOMS; ++a) {
+                float2 vx[4], vy[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { vx[i] = sx[a][tx * 4 + i]; vy[i] = sy[a][ty * 4 + i]; }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc[i][j].x = fmaf(vx[i].x, vy[j].x, fmaf(-vx[i].y, vy[j].y, acc[i][j].x));
+                        acc[i][j].y = fmaf(vx[i].x, vy[j].y, fmaf(vx[i].y, vy[j].x, acc[i][j].y));
+                    }
+            }
+        }
+        const float* f = ff + (size_t)sp * nx * ny;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int kx = kx0 + tx * 4 + i;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int ky = ky0 + ty * 4 + j;
+                if (kx < nx && ky < ny) {
+                    float w = f[(size_t)kx * ny + ky];
+                    total[i][j].x = fmaf(w, acc[i][j].x, total[i][j].x);
+                    total[i][j].y = fmaf(w, acc[i][j].y, total[i][j].y);
+                }
+            }
+        }
+    }
+    float2* out = recip + (size_t)s * nx * ny;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int kx = kx0 + tx * 4 + i;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int ky = ky0 + ty * 4 + j;
+            if (kx < nx && ky < ny) out[(size_t)kx * ny + ky] = total[i][j];
+        }
+    }
+}
+
+// Reciprocal-space probes: psik[p][mx][my] = mask * exp(2 pi i (fx (hx/nx + px/Lx) + fy (hy/ny + py/Ly)))
+// so that ifft2(psik)[p] == create_batched_probes(Probe(...))[p]  (multislice.py:116-124, 216-227).
+// Plane wave (mrad == 0): psik = nx*ny at DC only (ones after the normalised inverse FFT).
+__global__ void probe_kspace_kernel(float2* __restrict__ psik, const double* __restrict__ xy, int P, int nx, int ny,
+                                    double inv_lx, double inv_ly, double kfreq_x, double kfreq_y, double radius,
+                                    int plane_wave) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long npix = (long long)nx * ny;
+    if (i >= npix * P) return;
+    int p = (int)(i / npix);
+    long long q = i - (long long)p * npix;
+    int mx = (int)(q / ny), my = (int)(q - (long long)mx * ny);
+    if (plane_wave) {
+        psik[i] = (mx == 0 && my == 0) ? make_float2((float)npix, 0.f) : make_float2(0.f, 0.f);
+        return;
+    }
+    int fx = signed_freq(mx, nx), fy = signed_freq(my, ny);
+    double kx = fx * kfreq_x, ky = fy * kfreq_y;       // fftfreq value = index * (1/(n*d))
+    bool inside = sqrt(kx * kx + ky * ky) < radius;
+    if (!inside) { psik[i] = make_float2(0.f, 0.f); return; }
+    double t = fx * ((double)(nx / 2) / nx + xy[2 * p] * inv_lx) + fy * ((double)(ny / 2) / ny + xy[2 * p + 1] * inv_ly);
+    t -= rint(t);
+    float sn, cs;
+    sincospif((float)(2.0 * t), &sn, &cs);
+    psik[i] = make_float2(cs, sn);
+}
+
+// psi0k[p][mx][my] = basek[mx][my] * exp(2 pi i (kx px + ky py))   (multislice.py:221-223)
+__global__ void probe_ramp_kernel(float2* __restrict__ out, const float2* __restrict__ basek,
+                                  const double* __restrict__ xy, int P, int nx, int ny, double inv_lx, double inv_ly) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long npix = (long long)nx * ny;
+    if (i >= npix * P) return;
+    int p = (int)(i / npix);
+    long long q = i - (long long)p * npix;
+    int mx = (int)(q / ny), my = (int)(q - (long long)mx * ny);
+    double t = signed_freq(mx, nx) * (xy[2 * p] * inv_lx) + signed_freq(my, ny) * (xy[2 * p + 1] * inv_ly);
+    t -= rint(t);
+    float sn, cs;
+    sincospif((float)(2.0 * t), &sn, &cs);
+    float2 b = basek[q];
+    out[i] = make_float2(b.x * cs - b.y * sn, b.x * sn + b.y * cs);
+}
+
+// t = exp(i sigma V) from an uploaded V (nz,nx,ny) float32
+__global__ void transmission_kernel(float2* __restrict__ t, const float* __restrict__ V, long long n, float sigma) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float sn, cs;
+    sincosf(sigma * V[i], &sn, &cs);
+    t[i] = make_float2(cs, sn);
+}
+
+}  // namespace msl

@@ -1,0 +1,138 @@
+"""TACAWData -- host mirror of src/postprocessing/tacaw_data.py.
+
+`TACAWData(wfdata, layer_index=None)` keeps the reference behaviour (re-classes itself and aliases
+`wfdata.__dict__`, quirk Q16) but the time->frequency transform
+    intensity[p,w,kx,ky] = | fftshift_t fft_t( Psi - <Psi>_t ) |^2          (tacaw_data.py:89-104)
+runs in the HIP library (msl_tacaw).  When the WFData came from MultisliceCalculator.run() the
+exit waves are still resident on the device and are transformed in place there; otherwise the
+array is staged through torch device memory.  The reductions below (spectrum, diffraction, ...)
+are thin index/sum operations on the final intensity array (tacaw_data.py:109-353).
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import numpy as np
+
+from . import _native
+from .potentials import TORCH_AVAILABLE, _as_tensor
+from .wf_data import WFData
+
+if TORCH_AVAILABLE:
+    import torch
+
+
+def _np(a):
+    return a.detach().cpu().numpy() if hasattr(a, "detach") else np.asarray(a)
+
+
+class TACAWData(WFData):
+    def __init__(self, WFData, layer_index: int = None):
+        # reference tacaw_data.py:39-42: alias the WFData's dict (in-place mutation of the source object)
+        self.__dict__ = WFData.__dict__
+        self.fft_from_wf_data(layer_index)
+
+    def fft_from_wf_data(self, layer_index: int = None):
+        if layer_index is None:
+            layer_index = len(self.layer) - 1
+        if layer_index < 0 or layer_index >= len(self.layer):
+            raise ValueError(f"layer_index {layer_index} out of range [0, {len(self.layer)-1}]")
+        n_freq = len(self.time)
+        dt = self.time[1] - self.time[0]
+        self.frequencies = np.fft.fftshift(np.fft.fftfreq(n_freq, d=dt))
+
+        eng = self.__dict__.get("_engine")
+        resident = eng is not None and self.__dict__.get("_resident", False) and len(self.layer) == 1
+        if resident:
+            eng.tacaw()
+            if self.__dict__.get("_output") == "device":
+                ptr = eng.device_ptr(_native.BUF_INTENSITY)
+                shape = (eng.n_probes, eng.n_frames, eng.nx, eng.ny)
+                self.intensity = torch.as_tensor(_native.DeviceArray(ptr, shape, "<f4", owner=eng), device=f"cuda:{eng.device}")
+            else:
+                self.intensity = _as_tensor(eng.intensity().astype(np.float64))
+            return
+        # WFData assembled elsewhere (gathered shards, user arrays): stage through torch device memory
+        if not TORCH_AVAILABLE or not torch.cuda.is_available():
+            raise RuntimeError("TACAWData needs the HIP device (no CPU path in pyslice_amd)")
+        wf = self.wavefunction_data
+        wf = wf if hasattr(wf, "dim") else torch.from_numpy(np.ascontiguousarray(wf))
+        layer = wf[:, :, :, :, layer_index]
+        P, T, nx, ny = layer.shape
+        dev = torch.device("cuda", torch.cuda.current_device())
+        src = layer.to(device=dev, dtype=torch.complex64).contiguous()
+        dst = torch.empty((P, T, nx, ny), dtype=torch.float32, device=dev)
+        torch.cuda.synchronize(dev)
+        helper = _native.Engine(2, 2, 1, 1.0, 1.0, 1.0, 1.0, 0.0, n_probes=1, n_frames=0, device=dev.index)
+        try:
+            helper.tacaw(src.data_ptr(), dst.data_ptr(), P, T, nx * ny)
+        finally:
+            helper.close()
+        self.intensity = dst.to(torch.float64).cpu()
+
+    # ---- reductions over intensity(P, F, kx, ky) ----------------------------------------------
+    def _inten(self):
+        return self.intensity
+
+    def spectrum(self, probe_index: int = None) -> np.ndarray:
+        """reference tacaw_data.py:109-143"""
+        I = self._inten()
+        if probe_index is None:
+            return np.mean([_np(I[i].sum(axis=(1, 2))) for i in range(len(self.probe_positions))], axis=0)
+        if probe_index >= len(self.probe_positions):
+            raise ValueError(f"Probe index {probe_index} out of range")
+        return _np(I[probe_index].sum(axis=(1, 2)))
+
+    def spectrum_image(self, frequency: float, probe_indices: Optional[List[int]] = None) -> np.ndarray:
+        """reference tacaw_data.py:145-179"""
+        fi = int(np.argmin(np.abs(self.frequencies - frequency)))
+        if probe_indices is None:
+            probe_indices = list(range(len(self.probe_positions)))
+        return np.array([_np(self._inten()[p, fi].sum()) for p in probe_indices])
+
+    def diffraction(self, probe_index: int = None) -> np.ndarray:
+        """reference tacaw_data.py:183-217"""
+        I = self._inten()
+        if probe_index is None:
+            return np.mean([_np(I[i].sum(axis=0)) for i in range(len(self.probe_positions))], axis=0)
+        if probe_index >= len(self.probe_positions):
+            raise ValueError(f"Probe index {probe_index} out of range")
+        return _np(I[probe_index].sum(axis=0))
+
+    def spectral_diffraction(self, frequency: float, probe_index: int = None) -> np.ndarray:
+        """reference tacaw_data.py:219-254"""
+        fi = int(np.argmin(np.abs(self.frequencies - frequency)))
+        I = self._inten()
+        if probe_index is None:
+            return np.mean([_np(I[i, fi]) for i in range(len(self.probe_positions))], axis=0)
+        if probe_index >= len(self.probe_positions):
+            raise ValueError(f"Probe index {probe_index} out of range")
+        return _np(I[probe_index, fi])
+
+    def masked_spectrum(self, mask: np.ndarray, probe_index: int = None) -> np.ndarray:
+        """reference tacaw_data.py:256-300 (its self.kx/self.ky lookup is broken, Q18; kxs/kys used here)"""
+        if mask.shape != (len(self.kxs), len(self.kys)):
+            raise ValueError(f"Mask shape {mask.shape} doesn't match k-space shape ({len(self.kxs)}, {len(self.kys)})")
+        I = self._inten()
+        m = torch.as_tensor(mask, dtype=I.dtype, device=I.device) if hasattr(I, "dim") else np.asarray(mask)
+        if probe_index is None:
+            return np.mean([_np((I[i] * m[None]).sum(axis=(1, 2))) for i in range(len(self.probe_positions))], axis=0)
+        if probe_index >= len(self.probe_positions):
+            raise ValueError(f"Probe index {probe_index} out of range")
+        return _np((I[probe_index] * m[None]).sum(axis=(1, 2)))
+
+    def dispersion(self, kx_path: np.ndarray, ky_path: np.ndarray, probe_index: int = None) -> np.ndarray:
+        """reference tacaw_data.py:302-353"""
+        kxs, kys = _np(self.kxs), _np(self.kys)
+        ix = np.array([int(np.argmin(np.abs(kxs - v))) for v in kx_path])
+        iy = np.array([int(np.argmin(np.abs(kys - v))) for v in ky_path])
+        out = np.zeros((len(self.frequencies), len(ix)))
+        I = self._inten()
+        for i, (a, b) in enumerate(zip(ix, iy)):
+            if probe_index is None:
+                out[:, i] = np.mean([_np(I[p, :, a, b]) for p in range(len(self.probe_positions))], axis=0)
+            else:
+                if probe_index >= len(self.probe_positions):
+                    raise ValueError(f"Probe index {probe_index} out of range")
+                out[:, i] = _np(I[probe_index, :, a, b])
+        return out

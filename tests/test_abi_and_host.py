@@ -1,0 +1,112 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/mslice.h declares,
+host logic (grid, slice edges, sharding) agrees with the oracle, and the product fails loudly
+without a GPU (no CPU fallback)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from pyslice_amd import build_native, _native
+    build_native.build()
+    return _native.load()
+
+
+def test_header_symbols_exported(lib):
+    from pyslice_amd import _native
+    hdr = open(os.path.join(REPO, "include", "mslice.h")).read()
+    declared = set(re.findall(r"\b(msl_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in mslice.h but not exported"
+    assert declared == set(_native.EXPORTS)
+    assert lib.msl_abi_version() == 1
+
+
+def test_struct_layouts_match_header(lib):
+    """ctypes mirrors of msl_config / msl_counters have the C sizes (guards silent ABI drift)."""
+    import ctypes as C
+    from pyslice_amd import _native
+    assert C.sizeof(_native.MslConfig) == 3 * 4 + 4 + 5 * 8 + 5 * 4 + 7 * 4     # 3 ints (+pad), 5 doubles, 5+7 ints
+    assert C.sizeof(_native.MslCounters) == 12 * 8
+
+
+def test_no_gpu_means_loud_failure(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from pyslice_amd import _native
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        _native.Engine(64, 64, 4, 0.1, 0.1, 0.5, 0.037, 1e-3)
+    import pyslice_amd as ps
+    xs = np.linspace(0, 6.4, 64, endpoint=False)
+    with pytest.raises(RuntimeError):
+        ps.Potential(xs, xs, np.array([0.0, 0.5]), np.zeros((1, 3)), [5])
+    with pytest.raises(NotImplementedError):
+        ps.MultisliceCalculator(force_cpu=True)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(REPO, "pyslice_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(root, f)).read()
+                assert "multislice_oracle" not in src and "from oracle" not in src and "import oracle" not in src, f
+
+
+def test_host_grid_and_edges_match_oracle(golden):
+    from oracle import multislice_oracle as orc
+    import pyslice_amd as ps
+    from pyslice_amd.potentials import slice_edges
+    g = golden("g1_grid")
+    for box in g["boxes"]:
+        tr = ps.Trajectory(np.array([5, 7]), np.zeros((1, 2, 3)), np.zeros((1, 2, 3)), box, 0.005)
+        got = ps.gridFromTrajectory(tr, 0.1, 0.5)
+        want = orc.grid_from_box(box, 0.1, 0.5)
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b)
+        lo, hi = slice_edges(got[2])
+        olo, ohi = orc.slice_edges(want[2])
+        assert np.array_equal(lo, olo) and np.array_equal(hi, ohi)
+
+
+def test_host_constants_match_golden(golden):
+    from pyslice_amd.multislice import interaction_sigma, wavelength
+    g = golden("g2_wavelength")
+    for e, l, s in zip(g["eV"], g["wavelength"], g["sigma"]):
+        assert wavelength(e) == l and interaction_sigma(e) == s
+
+
+def test_kirkland_table_and_names():
+    import pyslice_amd as ps
+    t = ps.loadKirkland()
+    assert t.shape == (103, 3, 4) and t.dtype == np.float64
+    assert ps.getZfromElementName("B") == 5 and ps.getZfromElementName("N") == 7 and ps.getZfromElementName("Au") == 79
+
+
+def test_trajectory_validation_messages():
+    import pyslice_amd as ps
+    with pytest.raises(ValueError, match="positions must be"):
+        ps.Trajectory(np.array([5]), np.zeros((1, 1, 2)), np.zeros((1, 1, 3)), np.eye(3), 0.005)
+    with pytest.raises(ValueError, match="Atom count mismatch"):
+        ps.Trajectory(np.array([5, 7]), np.zeros((1, 1, 3)), np.zeros((1, 1, 3)), np.eye(3), 0.005)
+    with pytest.raises(ValueError, match="box_matrix"):
+        ps.Trajectory(np.array([5]), np.zeros((1, 1, 3)), np.zeros((1, 1, 3)), np.eye(2), 0.005)
+
+
+def test_synthetic_workload_grids():
+    from pyslice_amd.synthetic import box_for_grid, synthetic_trajectory, stem_probe_grid
+    import pyslice_amd as ps
+    for n, nz in [(256, 50), (512, 100), (1024, 200), (2048, 400)]:
+        tr = ps.Trajectory(np.array([5]), np.zeros((1, 1, 3)), np.zeros((1, 1, 3)), box_for_grid(n, nz), 0.005)
+        xs, ys, zs, *_ = ps.gridFromTrajectory(tr)
+        assert (len(xs), len(ys), len(zs)) == (n, n, nz)
+    tr = synthetic_trajectory(64, 6, 3, seed=2)
+    assert tr.positions.shape[0] == 3 and (tr.positions[:, :, 2] >= 0).all()
+    assert stem_probe_grid(8).shape == (64, 2)
