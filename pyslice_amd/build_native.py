@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libmslice.so")
 SOURCES = ["mslice.hip"]
-DEPS = ["mslice.hip", "fft_generic.h", "fft_pow2.h", "potential.h", os.path.join("..", "..", "include", "mslice.h")]
+DEPS = ["mslice.hip", "fft_generic.h", "fft_pow2.h", "fft_regs.h", "potential.h", os.path.join("..", "..", "include", "mslice.h")]
 ARCH = "gfx950"
 
 
@@ -38,7 +38,7 @@ def needs_build() -> bool:
 def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not needs_build():
         return OUT
-    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", OUT] + SOURCES
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fno-slp-vectorize", "-shared", "-fPIC", "-o", OUT] + SOURCES
     if verbose:
         print("[pyslice_amd] " + " ".join(cmd), flush=True)
     subprocess.run(cmd, cwd=CSRC, check=True)

@@ -1,0 +1,246 @@
+// Register-resident four-step FFT passes for square power-of-two line lengths N = R*R
+// (R = 32 -> 1024, R = 16 -> 256) on gfx950.  These are the roofline-judged kernels of the slice
+// loop (reference Propagate, src/multislice/multislice.py:278-294):
+//
+//   row pass     per row (p,x):    [ifft_y] -> x t_z[x,:] -> [fft_y] -> [x Py]      one HBM read + write
+//   column pass  per column (p,ky): fft_x -> x Px -> ifft_x                          one HBM read + write
+//
+// A line of N = R*R points lives in a group of R lanes, R registers per lane, element index
+// n = reg*R + lane -- both before and after a transform (four-step: register FFT over `reg`,
+// twiddle W_N^{lane*k1}, lane<->register transpose through LDS, register FFT).  So a whole
+// ifft -> multiply -> fft chain never leaves registers except for the two transposes, and HBM is
+// touched exactly once per pass with 8R-byte (row pass) or 128-byte (column pass) contiguous
+// segments.  Index algebra is unit-tested on the host (tools/fft_regs_host.cpp).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "fft_regs.h"
+
+namespace msl {
+
+__device__ __forceinline__ float2 cmulf(float2 a, float2 b) {
+    return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x));
+}
+__device__ __forceinline__ float2 cmulf_conj(float2 a, float2 b) {      // a * conj(b)
+    return make_float2(fmaf(a.x, b.x, a.y * b.y), fmaf(a.y, b.x, -a.x * b.y));
+}
+
+// LDS ordering inside one wave: DS instructions of a wave execute in order, so only the compiler
+// must be kept from reordering the accesses of the transpose.
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// workgroup barrier that drains LDS traffic only (global loads/stores stay in flight across it)
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// Multiply v[j] (j = J0..R-1) by tab[j*R + ln] (conjugated when CONJ) in chunks of 8 with a scheduling
+// barrier between chunks, so the compiler cannot hoist all R table loads at once (register pressure).
+template <int R, int J0, bool CONJ, typename TabPtr>
+__device__ __forceinline__ void mul_table(float2 (&v)[R], TabPtr tab, int ln) {
+    constexpr int CH = 8;
+#pragma unroll
+    for (int c = 0; c < R; c += CH) {
+        float2 w[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) if (c + j >= J0) w[j] = tab[(c + j) * R + ln];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) if (c + j >= J0) v[c + j] = CONJ ? cmulf_conj(v[c + j], w[j]) : cmulf(v[c + j], w[j]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// ---- four-step transform of one line held by an R-lane group ------------------------------------
+// tw: LDS table T[k1*R + lane] = exp(-2 pi i lane k1 / N) (forward); conjugated for INV.
+// Transpose through a float scratch of R*(R+1) words, real and imaginary parts one after the other
+// (row pass: halves the LDS footprint so more waves fit a CU).
+template <int R, bool INV>
+__device__ __forceinline__ void fourstep_split(float2 (&v)[R], float* scratch, const float2* tw, int ln) {
+    fft_regs<R, INV>(v);
+    mul_table<R, 1, INV>(v, tw, ln);
+#pragma unroll
+    for (int k1 = 0; k1 < R; ++k1) scratch[k1 * (R + 1) + ln] = v[k1].x;
+    wave_lds_fence();
+#pragma unroll
+    for (int n2 = 0; n2 < R; ++n2) v[n2].x = scratch[ln * (R + 1) + n2];
+    wave_lds_fence();
+#pragma unroll
+    for (int k1 = 0; k1 < R; ++k1) scratch[k1 * (R + 1) + ln] = v[k1].y;
+    wave_lds_fence();
+#pragma unroll
+    for (int n2 = 0; n2 < R; ++n2) v[n2].y = scratch[ln * (R + 1) + n2];
+    wave_lds_fence();
+    fft_regs<R, INV>(v);
+}
+
+// same with a complex scratch of R*(R+1) float2 (column pass: the tile is in LDS anyway)
+template <int R, bool INV>
+__device__ __forceinline__ void fourstep_c64(float2 (&v)[R], float2* scratch, const float2* tw, int ln) {
+    fft_regs<R, INV>(v);
+    mul_table<R, 1, INV>(v, tw, ln);
+#pragma unroll
+    for (int k1 = 0; k1 < R; ++k1) scratch[k1 * (R + 1) + ln] = v[k1];
+    wave_lds_fence();
+#pragma unroll
+    for (int n2 = 0; n2 < R; ++n2) v[n2] = scratch[ln * (R + 1) + n2];
+    wave_lds_fence();
+    fft_regs<R, INV>(v);
+}
+
+struct RowJob {
+    float2* psi;            // (P, nx, pitch) working waves, rows contiguous
+    const float2* trans;    // t_z (nx, ny) of this slice, or null
+    const float2* py;       // (ny) Fresnel factor along y with 1/ny folded in, or null
+    const float2* tw;       // (N) four-step twiddles T[k1*R + n2]
+    long long image_stride; // elements between probes
+    int pitch;              // elements between rows
+    int nx;                 // rows per image
+    int n_images;           // P
+    int do_ifft, do_fft;
+};
+
+// Row pass.  Workgroup = 256 threads = 256/R lines per iteration, persistent over line groups.
+// Line-group order is x-major, probe-minor, so the t_z rows one group needs are being read by the
+// neighbouring workgroups (other probes, same x) at the same time and stay in L2.
+template <int R>
+__global__ void __launch_bounds__(256, R == 32 ? 3 : 4) row_pass_kernel(RowJob job) {
+    constexpr int N = R * R;
+    constexpr int G = 256 / R;                       // lines per workgroup iteration
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float2* tw = reinterpret_cast<float2*>(smem_raw);                 // N float2
+    float* scratch_all = reinterpret_cast<float*>(tw + N);            // G * R*(R+1) floats
+    const int tid = threadIdx.x;
+    for (int i = tid; i < N; i += 256) tw[i] = job.tw[i];
+    __syncthreads();
+    const int grp = tid / R, ln = tid % R;
+    float* scratch = scratch_all + grp * (R * (R + 1));
+    const int xgroups = job.nx / G;
+    const long long n_groups = (long long)xgroups * job.n_images;
+    for (long long g = blockIdx.x; g < n_groups; g += gridDim.x) {
+        const int xg = (int)(g / job.n_images), p = (int)(g % job.n_images);
+        const int x = xg * G + grp;
+        float2* row = job.psi + (long long)p * job.image_stride + (long long)x * job.pitch;
+        float2 v[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) v[j] = row[j * R + ln];
+        if (job.do_ifft) fourstep_split<R, true>(v, scratch, tw, ln);
+        if (job.trans) {
+            const float2* trow = job.trans + (long long)x * N;
+            mul_table<R, 0, false>(v, trow, ln);
+        }
+        if (job.do_fft) {
+            fourstep_split<R, false>(v, scratch, tw, ln);
+            if (job.py) {
+                mul_table<R, 0, false>(v, job.py, ln);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < R; ++j) row[j * R + ln] = v[j];
+    }
+}
+
+struct ColJob {
+    const float2* in;       // (P, nx, pitch)
+    float2* out;            // same buffer for the slice loop; the (P,T,nx,ny) result for the epilogue
+    const float2* px;       // (nx) Fresnel factor along x with 1/nx folded in (mode 0)
+    const float2* tw;       // (N) four-step twiddles
+    long long in_image_stride, out_image_stride;
+    int in_pitch, out_pitch;
+    int ny;                 // columns per image
+    int n_images;
+    int flags;              // COL_FWD | COL_MULPX | COL_INV | COL_SHIFT (fftshifted scatter of both axes into `out`)
+    float scale;            // applied at the store (1/(nx ny) of a stand-alone inverse transform)
+};
+enum { COL_FWD = 1, COL_MULPX = 2, COL_INV = 4, COL_SHIFT = 8 };
+
+// Column pass.  Workgroup = 16*R threads owns a tile of 16 neighbouring columns (128-byte row
+// segments in HBM) x N rows: staged into LDS column-major, one R-lane group per column, results
+// staged back and stored as 128-byte segments.  Persistent over tiles with the next tile's loads in
+// flight in registers while the current one is transformed.
+template <int R>
+__global__ void __launch_bounds__(16 * R) col_pass_kernel(ColJob job) {
+    constexpr int N = R * R;
+    constexpr int NT = 16 * R;                        // threads
+    constexpr int CS = R * (R + 1) + 1;               // LDS column stride in float2 (odd*8 B: conflict-free staging)
+    constexpr int ROWS_PER_IT = NT / 8;               // 8 threads (16 B each) per 128-byte row segment
+    constexpr int NIT = N / ROWS_PER_IT;              // float4 per thread per tile
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float2* tw = reinterpret_cast<float2*>(smem_raw);                 // N
+    float2* px = tw + N;                                              // N
+    float2* cols = px + N;                                            // 16 * CS
+    const int tid = threadIdx.x;
+    for (int i = tid; i < N; i += NT) { tw[i] = job.tw[i]; px[i] = job.px ? job.px[i] : make_float2(1.f, 0.f); }
+    const int grp = tid / R, ln = tid % R;            // column handled in the transform phase
+    const int q = tid & 7, r0 = tid >> 3;             // staging role: column pair q, row r0 + ROWS_PER_IT*i
+    float2* mycol = cols + grp * CS;
+    const int tiles_per_image = job.ny / 16;
+    const long long n_tiles = (long long)tiles_per_image * job.n_images;
+    float4 stage[NIT];
+    long long tile = blockIdx.x;
+    if (tile < n_tiles) {
+        const long long p = tile / tiles_per_image, c0 = (tile % tiles_per_image) * 16;
+        const float2* src = job.in + p * job.in_image_stride + c0 + 2 * q;
+#pragma unroll
+        for (int i = 0; i < NIT; ++i)
+            stage[i] = *reinterpret_cast<const float4*>(src + (long long)(r0 + ROWS_PER_IT * i) * job.in_pitch);
+    }
+    __syncthreads();
+    for (; tile < n_tiles; tile += gridDim.x) {
+        // ---- registers -> LDS, column-major
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int x = r0 + ROWS_PER_IT * i;
+            cols[(2 * q) * CS + x] = make_float2(stage[i].x, stage[i].y);
+            cols[(2 * q + 1) * CS + x] = make_float2(stage[i].z, stage[i].w);
+        }
+        lds_barrier();
+        // ---- next tile's loads go out now and fly during the transform
+        const long long nxt = tile + gridDim.x;
+        if (nxt < n_tiles) {
+            const long long p = nxt / tiles_per_image, c0 = (nxt % tiles_per_image) * 16;
+            const float2* src = job.in + p * job.in_image_stride + c0 + 2 * q;
+#pragma unroll
+            for (int i = 0; i < NIT; ++i)
+                stage[i] = *reinterpret_cast<const float4*>(src + (long long)(r0 + ROWS_PER_IT * i) * job.in_pitch);
+        }
+        // ---- transform my column
+        {
+            float2 v[R];
+#pragma unroll
+            for (int j = 0; j < R; ++j) v[j] = mycol[j * R + ln];
+            wave_lds_fence();
+            if (job.flags & COL_FWD) fourstep_c64<R, false>(v, mycol, tw, ln);
+            if (job.flags & COL_MULPX) {
+                mul_table<R, 0, false>(v, px, ln);
+            }
+            if (job.flags & COL_INV) fourstep_c64<R, true>(v, mycol, tw, ln);
+            wave_lds_fence();
+#pragma unroll
+            for (int j = 0; j < R; ++j) mycol[j * R + ln] = v[j];
+        }
+        lds_barrier();
+        // ---- LDS -> registers -> HBM (128-byte segments)
+        {
+            const long long p = tile / tiles_per_image;
+            const int c0 = (int)(tile % tiles_per_image) * 16;
+            int cshift = c0, xshift = 0;
+            if (job.flags & COL_SHIFT) { cshift = (c0 + job.ny / 2) % job.ny; xshift = N / 2; }
+            float2* dst = job.out + p * job.out_image_stride + cshift + 2 * q;
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) {
+                const int x = r0 + ROWS_PER_IT * i;
+                float2 a = cols[(2 * q) * CS + x], b = cols[(2 * q + 1) * CS + x];
+                int xo = x + xshift;
+                if (xo >= N) xo -= N;
+                *reinterpret_cast<float4*>(dst + (long long)xo * job.out_pitch) =
+                    make_float4(a.x * job.scale, a.y * job.scale, b.x * job.scale, b.y * job.scale);
+            }
+            lds_barrier();                      // LDS is free for the next tile's staging from here on
+        }
+    }
+}
+
+}  // namespace msl

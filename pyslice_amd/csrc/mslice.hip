@@ -12,6 +12,7 @@
 
 #include "../../include/mslice.h"
 #include "fft_generic.h"
+#include "fft_pow2.h"
 #include "potential.h"
 
 using namespace msl;
@@ -45,6 +46,11 @@ struct msl_handle {
     std::string err;
     // plans
     FftPlan plan_x, plan_y, plan_t;
+    // four-step (register-resident) kernels: R = 32 (N=1024) or 16 (N=256); 0 = use the generic kernel
+    int Rx = 0, Ry = 0;
+    float2* tw4_x = nullptr;
+    float2* tw4_y = nullptr;
+    int n_cus = 256;
     // device buffers
     float2* psi0 = nullptr;
     float2* psi = nullptr;
@@ -270,11 +276,85 @@ LineArgs col_args(const msl_handle* h, const float2* in, float2* out, int images
     return a;
 }
 
-int fft2_inplace(msl_handle* h, float2* buf, int images, int dir, float scale) {
-    LineArgs r = row_args(h, buf, buf, images);
-    r.fft1 = dir;
-    int rc = launch_lines(h, h->plan_y, r, K_OTHER);
+// ---- four-step fast path ------------------------------------------------------------------------
+int fast_radix(int n) { return n == 1024 ? 32 : (n == 256 ? 16 : 0); }
+
+int make_tw4(msl_handle* h, float2** dst, int R) {
+    const int N = R * R;
+    std::vector<float2> t(N);
+    for (int k1 = 0; k1 < R; ++k1)
+        for (int n2 = 0; n2 < R; ++n2) {
+            double a = -2.0 * M_PI * (double)((k1 * n2) % N) / (double)N;
+            t[k1 * R + n2] = make_float2((float)cos(a), (float)sin(a));
+        }
+    int rc = dalloc(h, dst, (size_t)N);
     if (rc) return rc;
+    HIPCHK(h, hipMemcpyAsync(*dst, t.data(), N * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return MSL_OK;
+}
+
+template <int R>
+int launch_row_fast_r(msl_handle* h, const RowJob& job, int kind) {
+    constexpr int N = R * R, G = 256 / R;
+    const size_t lds = (size_t)N * 8 + (size_t)G * R * (R + 1) * 4;
+    const long long groups = (long long)(job.nx / G) * job.n_images;
+    const int per_cu = std::max(1, (int)((size_t)h->lds_limit / lds));
+    const int grid = (int)std::min<long long>(groups, (long long)h->n_cus * std::min(per_cu, 4));
+    hipLaunchKernelGGL(row_pass_kernel<R>, dim3(grid), dim3(256), lds, h->stream, job);
+    HIPCHK(h, hipGetLastError());
+    return mark_launch(h, kind);
+}
+
+template <int R>
+int launch_col_fast_r(msl_handle* h, const ColJob& job, int kind) {
+    constexpr int N = R * R, CS = R * (R + 1) + 1;
+    const size_t lds = ((size_t)2 * N + (size_t)16 * CS) * 8;
+    const long long tiles = (long long)(job.ny / 16) * job.n_images;
+    const int per_cu = std::max(1, (int)((size_t)h->lds_limit / lds));
+    const int grid = (int)std::min<long long>(tiles, (long long)h->n_cus * std::min(per_cu, 2));
+    hipLaunchKernelGGL(col_pass_kernel<R>, dim3(grid), dim3(16 * R), lds, h->stream, job);
+    HIPCHK(h, hipGetLastError());
+    return mark_launch(h, kind);
+}
+
+int launch_row_fast(msl_handle* h, const RowJob& job, int kind) {
+    return h->Ry == 32 ? launch_row_fast_r<32>(h, job, kind) : launch_row_fast_r<16>(h, job, kind);
+}
+int launch_col_fast(msl_handle* h, const ColJob& job, int kind) {
+    return h->Rx == 32 ? launch_col_fast_r<32>(h, job, kind) : launch_col_fast_r<16>(h, job, kind);
+}
+
+RowJob row_job(const msl_handle* h, float2* buf, int images) {
+    RowJob j{};
+    j.psi = buf; j.trans = nullptr; j.py = nullptr; j.tw = h->tw4_y;
+    j.image_stride = (long long)h->cfg.nx * h->cfg.ny; j.pitch = h->cfg.ny; j.nx = h->cfg.nx; j.n_images = images;
+    return j;
+}
+ColJob col_job(const msl_handle* h, const float2* in, float2* out, int images) {
+    ColJob j{};
+    j.in = in; j.out = out; j.px = nullptr; j.tw = h->tw4_x;
+    j.in_image_stride = j.out_image_stride = (long long)h->cfg.nx * h->cfg.ny;
+    j.in_pitch = j.out_pitch = h->cfg.ny; j.ny = h->cfg.ny; j.n_images = images; j.flags = 0; j.scale = 1.f;
+    return j;
+}
+
+int fft2_inplace(msl_handle* h, float2* buf, int images, int dir, float scale) {
+    int rc;
+    if (h->Ry) {
+        RowJob r = row_job(h, buf, images);
+        r.do_ifft = dir < 0; r.do_fft = dir > 0;
+        if ((rc = launch_row_fast(h, r, K_OTHER))) return rc;
+    } else {
+        LineArgs r = row_args(h, buf, buf, images);
+        r.fft1 = dir;
+        if ((rc = launch_lines(h, h->plan_y, r, K_OTHER))) return rc;
+    }
+    if (h->Rx) {
+        ColJob c = col_job(h, buf, buf, images);
+        c.flags = dir > 0 ? COL_FWD : COL_INV; c.scale = scale;
+        return launch_col_fast(h, c, K_OTHER);
+    }
     LineArgs c = col_args(h, buf, buf, images);
     c.fft1 = dir; c.scale = scale;
     return launch_lines(h, h->plan_x, c, K_OTHER);
@@ -307,25 +387,44 @@ int slice_loop(msl_handle* h, int fused_slot) {
     const bool fused = fused_slot >= 0;
     for (int z = 0; z < nz; ++z) {
         const bool last = (z == nz - 1);
-        LineArgs r = row_args(h, h->psi, h->psi, P);
-        r.fft1 = (z > 0) ? -1 : 0;
-        r.m1_kind = MUL_ARRAY; r.m1 = h->trans + (size_t)z * npix; r.m1_ls = c.ny;
-        if (!last) { r.fft2 = +1; r.m2_kind = MUL_VEC; r.m2 = h->pyt; }
-        else if (fused) { r.fft2 = +1; }
-        if ((rc = launch_lines(h, h->plan_y, r, K_ROW))) return rc;
+        if (h->Ry) {
+            RowJob r = row_job(h, h->psi, P);
+            r.do_ifft = z > 0; r.trans = h->trans + (size_t)z * npix;
+            r.do_fft = (!last || fused); r.py = last ? nullptr : h->pyt;
+            if ((rc = launch_row_fast(h, r, K_ROW))) return rc;
+        } else {
+            LineArgs r = row_args(h, h->psi, h->psi, P);
+            r.fft1 = (z > 0) ? -1 : 0;
+            r.m1_kind = MUL_ARRAY; r.m1 = h->trans + (size_t)z * npix; r.m1_ls = c.ny;
+            if (!last) { r.fft2 = +1; r.m2_kind = MUL_VEC; r.m2 = h->pyt; }
+            else if (fused) { r.fft2 = +1; }
+            if ((rc = launch_lines(h, h->plan_y, r, K_ROW))) return rc;
+        }
         if (!last) {
-            LineArgs k = col_args(h, h->psi, h->psi, P);
-            k.fft1 = +1; k.m1_kind = MUL_VEC; k.m1 = h->pxt; k.fft2 = -1;
-            if ((rc = launch_lines(h, h->plan_x, k, K_COL))) return rc;
+            if (h->Rx) {
+                ColJob k = col_job(h, h->psi, h->psi, P);
+                k.px = h->pxt; k.flags = COL_FWD | COL_MULPX | COL_INV;
+                if ((rc = launch_col_fast(h, k, K_COL))) return rc;
+            } else {
+                LineArgs k = col_args(h, h->psi, h->psi, P);
+                k.fft1 = +1; k.m1_kind = MUL_VEC; k.m1 = h->pxt; k.fft2 = -1;
+                if ((rc = launch_lines(h, h->plan_x, k, K_COL))) return rc;
+            }
         }
     }
     if (fused) {
         // epilogue: fft along x, fftshift both axes, scatter into (P, T_local, nx, ny)
-        LineArgs k = col_args(h, h->psi, h->wf + (size_t)fused_slot * npix, P);
-        k.fft1 = +1;
-        k.out_is = (long long)c.n_frames * npix;
-        k.shift_n = c.nx / 2; k.shift_r = c.ny / 2;
-        if ((rc = launch_lines(h, h->plan_x, k, K_OTHER))) return rc;
+        if (h->Rx) {
+            ColJob k = col_job(h, h->psi, h->wf + (size_t)fused_slot * npix, P);
+            k.flags = COL_FWD | COL_SHIFT; k.out_image_stride = (long long)c.n_frames * npix;
+            if ((rc = launch_col_fast(h, k, K_OTHER))) return rc;
+        } else {
+            LineArgs k = col_args(h, h->psi, h->wf + (size_t)fused_slot * npix, P);
+            k.fft1 = +1;
+            k.out_is = (long long)c.n_frames * npix;
+            k.shift_n = c.nx / 2; k.shift_r = c.ny / 2;
+            if ((rc = launch_lines(h, h->plan_x, k, K_OTHER))) return rc;
+        }
     }
     h->cur = nullptr;
     h->ctr.slice_steps += (uint64_t)P * nz;
@@ -389,6 +488,20 @@ int msl_create(const msl_config* cfg, msl_handle** out) {
     int rc;
     if ((rc = make_plan(h, h->plan_x, cfg->nx))) return bail(rc);
     if ((rc = make_plan(h, h->plan_y, cfg->ny))) return bail(rc);
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) h->n_cus = prop.multiProcessorCount;
+    }
+    if (cfg->fft_path == 0) {
+        // row kernel: rows of length ny, 256/R rows per workgroup;  column kernel: columns of length nx, 16 per tile
+        int ry = fast_radix(cfg->ny), rx = fast_radix(cfg->nx);
+        if (ry && cfg->nx % (256 / ry) == 0) { h->Ry = ry; if ((rc = make_tw4(h, &h->tw4_y, ry))) return bail(rc); }
+        if (rx && cfg->ny % 16 == 0 && cfg->ny >= 32) { h->Rx = rx; if ((rc = make_tw4(h, &h->tw4_x, rx))) return bail(rc); }
+        (void)hipFuncSetAttribute((const void*)row_pass_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
+        (void)hipFuncSetAttribute((const void*)row_pass_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
+        (void)hipFuncSetAttribute((const void*)col_pass_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
+        (void)hipFuncSetAttribute((const void*)col_pass_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
+    }
     const size_t npix = (size_t)cfg->nx * cfg->ny;
     if ((rc = dalloc(h, &h->psi0, npix * cfg->n_probes))) return bail(rc);
     if ((rc = dalloc(h, &h->psi, npix * cfg->n_probes))) return bail(rc);
@@ -419,7 +532,7 @@ int msl_destroy(msl_handle* h) {
     for (auto& s : h->ring) for (auto e : s.ev) (void)hipEventDestroy(e);
     void* bufs[] = {h->psi0, h->psi, h->trans, h->V, h->wf, h->intensity, h->pxt, h->pyt, h->d_abcd, h->d_lo, h->d_hi,
                     h->d_pos, h->d_Z, h->d_key, h->d_order, h->d_u1, h->d_u2, h->d_ex, h->d_ey, h->d_counts, h->d_start,
-                    h->d_z2s, h->d_species, h->d_ff, h->d_xy, h->plan_x.tw, h->plan_y.tw, h->plan_t.tw};
+                    h->d_z2s, h->d_species, h->d_ff, h->d_xy, h->plan_x.tw, h->plan_y.tw, h->plan_t.tw, h->tw4_x, h->tw4_y};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;

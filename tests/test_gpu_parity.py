@@ -39,7 +39,8 @@ def orc():
 
 # ------------------------------------------------------------------ FFT kernels alone
 @pytest.mark.parametrize("shape,batch", [((64, 64), 3), ((96, 80), 2), ((45, 63), 2), ((256, 256), 2), ((128, 512), 1),
-                                         ((1024, 1024), 2), ((2048, 2048), 1), ((330, 200), 1), ((2, 2), 1)])
+                                         ((1024, 1024), 2), ((2048, 2048), 1), ((330, 200), 1), ((2, 2), 1),
+                                         ((1024, 256), 3), ((256, 1024), 3), ((1024, 64), 2), ((40, 256), 2)])
 def test_fft2_matches_numpy(ps, shape, batch):
     from pyslice_amd import _native
     rng = np.random.default_rng(5)
@@ -51,6 +52,33 @@ def test_fft2_matches_numpy(ps, shape, batch):
     b = eng.fft2(f, -1)
     assert rel_l2(b, a) < 3e-6
     eng.close()
+
+
+@pytest.mark.parametrize("n,nz,P", [(256, 12, 5), (1024, 6, 3)])
+def test_fourstep_kernels_match_generic_kernels(ps, n, nz, P):
+    """The register-resident four-step passes (fft_path=0) against the generic LDS Stockham passes (fft_path=1)
+    on the same frame: potential, slice loop and fused exit-wave epilogue."""
+    from pyslice_amd import _native
+    from pyslice_amd.synthetic import synthetic_trajectory
+    from pyslice_amd.potentials import slice_edges
+    tr = synthetic_trajectory(n, nz, 1, seed=11)
+    xs, ys, zs, lx, ly, lz = ps.gridFromTrajectory(tr)
+    pp = np.random.default_rng(1).random((P, 2)) * [lx, ly]
+    outs = []
+    for path in (0, 1):
+        eng = _native.Engine(n, n, nz, xs[1] - xs[0], ys[1] - ys[0], zs[1] - zs[0], 0.0370144, 9.24396e-4,
+                             n_probes=P, n_frames=1, fft_path=path)
+        eng.set_kirkland(ps.loadKirkland())
+        eng.set_slices(*slice_edges(zs))
+        eng.set_probes(30.0, pp)
+        eng.build_potential(tr.positions[0], tr.atom_types.astype(np.int32))
+        eng.propagate()
+        ex = eng.exit_waves()
+        eng.propagate_frame(0)
+        outs.append((eng.probes(), ex, eng.wavefunction()))
+        eng.close()
+    for a, b in zip(outs[0], outs[1]):
+        assert rel_l2(a, b) < 5e-6
 
 
 def test_unsupported_length_fails_loudly(ps):
