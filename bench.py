@@ -154,6 +154,8 @@ def main():
             roof = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                     "avg_launch_us": round(avg_s * 1e6, 2), "launches": int(cnt),
+                    "row_pass_GBps": round(bytes_per_launch * rows[0] / (rows[1] * 1e-3) / 1e9, 1) if rows[1] else None,
+                    "col_pass_GBps": round(bytes_per_launch * cols[0] / (cols[1] * 1e-3) / 1e9, 1) if cols[1] else None,
                     "algorithmic_bytes_per_launch": bytes_per_launch,
                     "slice_loop_GBps_both_passes": round(32.0 * npix * P * nz * a.steps / (ctr["ms_slice_kernels"] * 1e-3) / 1e9, 1)
                     if ctr["ms_slice_kernels"] else None}

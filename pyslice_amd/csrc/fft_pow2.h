@@ -100,6 +100,7 @@ struct RowJob {
     int nx;                 // rows per image
     int n_images;           // P
     int do_ifft, do_fft;
+    int pchunk;             // probes per work item of the pipelined row kernel (t_z row reuse in registers)
 };
 
 // Row pass.  Workgroup = 256 threads = 256/R lines per iteration, persistent over line groups.
@@ -118,9 +119,16 @@ __global__ void __launch_bounds__(256, R == 32 ? 3 : 4) row_pass_kernel(RowJob j
     const int grp = tid / R, ln = tid % R;
     float* scratch = scratch_all + grp * (R * (R + 1));
     const int xgroups = job.nx / G;
-    const long long n_groups = (long long)xgroups * job.n_images;
-    for (long long g = blockIdx.x; g < n_groups; g += gridDim.x) {
-        const int xg = (int)(g / job.n_images), p = (int)(g % job.n_images);
+    // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 share an L2).  Give each XCD whole
+    // x-groups (all probes of the same rows) so a t_z row is fetched into one L2 once instead of into all 8.
+    const bool xcd_map = (xgroups % 8 == 0) && (gridDim.x % 8 == 0);
+    const long long n_groups = xcd_map ? (long long)(xgroups / 8) * job.n_images : (long long)xgroups * job.n_images;
+    const long long g0 = xcd_map ? blockIdx.x / 8 : blockIdx.x;
+    const long long gstep = xcd_map ? gridDim.x / 8 : gridDim.x;
+    for (long long g = g0; g < n_groups; g += gstep) {
+        int xg = (int)(g / job.n_images);
+        const int p = (int)(g % job.n_images);
+        if (xcd_map) xg = xg * 8 + (int)(blockIdx.x % 8);
         const int x = xg * G + grp;
         float2* row = job.psi + (long long)p * job.image_stride + (long long)x * job.pitch;
         float2 v[R];
@@ -139,6 +147,79 @@ __global__ void __launch_bounds__(256, R == 32 ? 3 : 4) row_pass_kernel(RowJob j
         }
 #pragma unroll
         for (int j = 0; j < R; ++j) row[j * R + ln] = v[j];
+    }
+}
+
+// Row pass, software-pipelined variant.  A work item is (x-group, chunk of `pchunk` probes): the t_z rows
+// of the x-group are loaded once into registers and reused for every probe of the chunk, so t_z costs
+// nx*ny*8*P/pchunk bytes per launch instead of depending on L2 luck.  The next line's wave data (HBM) is
+// in flight while the current one is transformed; Py comes from LDS.  ~230 VGPRs -> 2 waves per SIMD,
+// every wave keeps 8R^2 bytes of HBM loads outstanding all the time.
+template <int R>
+__global__ void __launch_bounds__(256, 2) row_pass_pf_kernel(RowJob job) {
+    constexpr int N = R * R;
+    constexpr int G = 256 / R;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float2* tw = reinterpret_cast<float2*>(smem_raw);                 // N
+    float2* pyl = tw + N;                                             // N
+    float* scratch_all = reinterpret_cast<float*>(pyl + N);           // G * R*(R+1) floats
+    const int tid = threadIdx.x;
+    for (int i = tid; i < N; i += 256) { tw[i] = job.tw[i]; pyl[i] = job.py ? job.py[i] : make_float2(1.f, 0.f); }
+    __syncthreads();
+    const int grp = tid / R, ln = tid % R;
+    float* scratch = scratch_all + grp * (R * (R + 1));
+    const int xgroups = job.nx / G;
+    const int PC = job.pchunk;
+    const int pchunks = (job.n_images + PC - 1) / PC;
+    const long long n_items = (long long)xgroups * pchunks;
+    // cursor over (item, k): item = xg*pchunks + pc, probe p = pc*PC + k
+    long long item = blockIdx.x;
+    int k = 0;
+    auto chunk_len = [&](long long it) { const int pc = (int)(it % pchunks); return min(PC, job.n_images - pc * PC); };
+    auto row_of = [&](long long it, int kk) {
+        const int xg = (int)(it / pchunks), pc = (int)(it % pchunks);
+        const int x = xg * G + grp;
+        return job.psi + (long long)(pc * PC + kk) * job.image_stride + (long long)x * job.pitch;
+    };
+    float2 vn[R];
+    if (item < n_items) {
+        const float2* r = row_of(item, 0);
+#pragma unroll
+        for (int j = 0; j < R; ++j) vn[j] = r[j * R + ln];
+    }
+    float2 tv[R];
+    while (item < n_items) {
+        float2 v[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) v[j] = vn[j];
+        float2* cur_row = row_of(item, k);
+        if (k == 0 && job.trans) {          // new x-group: its transmission rows first (L2), before the next HBM loads
+            const int x = (int)(item / pchunks) * G + grp;
+            const float2* trow = job.trans + (long long)x * N;
+#pragma unroll
+            for (int j = 0; j < R; ++j) tv[j] = trow[j * R + ln];
+        }
+        // advance the cursor and put the next line's loads in flight
+        long long nitem = item;
+        int nk = k + 1;
+        if (nk >= chunk_len(item)) { nitem = item + gridDim.x; nk = 0; }
+        if (nitem < n_items) {
+            const float2* r = row_of(nitem, nk);
+#pragma unroll
+            for (int j = 0; j < R; ++j) vn[j] = r[j * R + ln];
+        }
+        if (job.do_ifft) fourstep_split<R, true>(v, scratch, tw, ln);
+        if (job.trans) {
+#pragma unroll
+            for (int j = 0; j < R; ++j) v[j] = cmulf(v[j], tv[j]);
+        }
+        if (job.do_fft) {
+            fourstep_split<R, false>(v, scratch, tw, ln);
+            if (job.py) mul_table<R, 0, false>(v, pyl, ln);
+        }
+#pragma unroll
+        for (int j = 0; j < R; ++j) cur_row[j * R + ln] = v[j];
+        item = nitem; k = nk;
     }
 }
 

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -51,6 +52,9 @@ struct msl_handle {
     float2* tw4_x = nullptr;
     float2* tw4_y = nullptr;
     int n_cus = 256;
+    int row_pchunk = 0;         // 0 = auto (MSL_ROW_PCHUNK)
+    int row_variant = 1;        // 0: plain row kernel, 1: software-pipelined (MSL_ROW_VARIANT)
+    int pitch = 0;              // row pitch (elements) of psi0/psi; > ny de-aliases the column pass's 128-byte segments
     // device buffers
     float2* psi0 = nullptr;
     float2* psi = nullptr;
@@ -259,19 +263,20 @@ int launch_lines(msl_handle* h, const FftPlan& pl, const LineArgs& a, int kind) 
 }
 
 // row pass over (images x nx) rows of length ny; column pass over (images x ny) columns of length nx
-LineArgs row_args(const msl_handle* h, const float2* in, float2* out, int images) {
+LineArgs row_args(const msl_handle* h, const float2* in, float2* out, int images, int pitch) {
     LineArgs a;
     a.in = in; a.out = out;
     a.n_lines = (long long)images * h->cfg.nx; a.lines_per_image = h->cfg.nx;
-    a.in_es = a.out_es = 1; a.in_ls = a.out_ls = h->cfg.ny; a.in_is = a.out_is = (long long)h->cfg.nx * h->cfg.ny;
+    a.in_es = a.out_es = 1; a.in_ls = a.out_ls = pitch; a.in_is = a.out_is = (long long)h->cfg.nx * pitch;
     a.contiguous_lines = 0;
     return a;
 }
-LineArgs col_args(const msl_handle* h, const float2* in, float2* out, int images) {
+LineArgs col_args(const msl_handle* h, const float2* in, float2* out, int images, int in_pitch, int out_pitch) {
     LineArgs a;
     a.in = in; a.out = out;
     a.n_lines = (long long)images * h->cfg.ny; a.lines_per_image = h->cfg.ny;
-    a.in_es = a.out_es = h->cfg.ny; a.in_ls = a.out_ls = 1; a.in_is = a.out_is = (long long)h->cfg.nx * h->cfg.ny;
+    a.in_es = in_pitch; a.out_es = out_pitch; a.in_ls = a.out_ls = 1;
+    a.in_is = (long long)h->cfg.nx * in_pitch; a.out_is = (long long)h->cfg.nx * out_pitch;
     a.contiguous_lines = 1;
     return a;
 }
@@ -297,6 +302,23 @@ int make_tw4(msl_handle* h, float2** dst, int R) {
 template <int R>
 int launch_row_fast_r(msl_handle* h, const RowJob& job, int kind) {
     constexpr int N = R * R, G = 256 / R;
+    if (h->row_variant == 1) {
+        const size_t lds = (size_t)N * 16 + (size_t)G * R * (R + 1) * 4;
+        const int per_cu = std::max(1, std::min(2, (int)((size_t)h->lds_limit / lds)));
+        const long long slots = (long long)h->n_cus * per_cu;
+        // probes per work item: as many as possible (t_z reuse) while still giving every slot an item
+        RowJob j2 = job;
+        const long long xg = job.nx / G;
+        int pc = job.n_images;
+        while (pc > 1 && xg * ((job.n_images + pc - 1) / pc) < slots) pc = (pc + 1) / 2;
+        if (h->row_pchunk > 0) pc = std::min(h->row_pchunk, job.n_images);
+        j2.pchunk = pc;
+        const long long items = xg * ((job.n_images + pc - 1) / pc);
+        const int grid = (int)std::min<long long>(items, slots);
+        hipLaunchKernelGGL(row_pass_pf_kernel<R>, dim3(grid), dim3(256), lds, h->stream, j2);
+        HIPCHK(h, hipGetLastError());
+        return mark_launch(h, kind);
+    }
     const size_t lds = (size_t)N * 8 + (size_t)G * R * (R + 1) * 4;
     const long long groups = (long long)(job.nx / G) * job.n_images;
     const int per_cu = std::max(1, (int)((size_t)h->lds_limit / lds));
@@ -325,37 +347,37 @@ int launch_col_fast(msl_handle* h, const ColJob& job, int kind) {
     return h->Rx == 32 ? launch_col_fast_r<32>(h, job, kind) : launch_col_fast_r<16>(h, job, kind);
 }
 
-RowJob row_job(const msl_handle* h, float2* buf, int images) {
+RowJob row_job(const msl_handle* h, float2* buf, int images, int pitch) {
     RowJob j{};
     j.psi = buf; j.trans = nullptr; j.py = nullptr; j.tw = h->tw4_y;
-    j.image_stride = (long long)h->cfg.nx * h->cfg.ny; j.pitch = h->cfg.ny; j.nx = h->cfg.nx; j.n_images = images;
+    j.image_stride = (long long)h->cfg.nx * pitch; j.pitch = pitch; j.nx = h->cfg.nx; j.n_images = images;
     return j;
 }
-ColJob col_job(const msl_handle* h, const float2* in, float2* out, int images) {
+ColJob col_job(const msl_handle* h, const float2* in, float2* out, int images, int in_pitch, int out_pitch) {
     ColJob j{};
     j.in = in; j.out = out; j.px = nullptr; j.tw = h->tw4_x;
-    j.in_image_stride = j.out_image_stride = (long long)h->cfg.nx * h->cfg.ny;
-    j.in_pitch = j.out_pitch = h->cfg.ny; j.ny = h->cfg.ny; j.n_images = images; j.flags = 0; j.scale = 1.f;
+    j.in_image_stride = (long long)h->cfg.nx * in_pitch; j.out_image_stride = (long long)h->cfg.nx * out_pitch;
+    j.in_pitch = in_pitch; j.out_pitch = out_pitch; j.ny = h->cfg.ny; j.n_images = images; j.flags = 0; j.scale = 1.f;
     return j;
 }
 
-int fft2_inplace(msl_handle* h, float2* buf, int images, int dir, float scale) {
+int fft2_inplace(msl_handle* h, float2* buf, int images, int dir, float scale, int pitch) {
     int rc;
     if (h->Ry) {
-        RowJob r = row_job(h, buf, images);
+        RowJob r = row_job(h, buf, images, pitch);
         r.do_ifft = dir < 0; r.do_fft = dir > 0;
         if ((rc = launch_row_fast(h, r, K_OTHER))) return rc;
     } else {
-        LineArgs r = row_args(h, buf, buf, images);
+        LineArgs r = row_args(h, buf, buf, images, pitch);
         r.fft1 = dir;
         if ((rc = launch_lines(h, h->plan_y, r, K_OTHER))) return rc;
     }
     if (h->Rx) {
-        ColJob c = col_job(h, buf, buf, images);
+        ColJob c = col_job(h, buf, buf, images, pitch, pitch);
         c.flags = dir > 0 ? COL_FWD : COL_INV; c.scale = scale;
         return launch_col_fast(h, c, K_OTHER);
     }
-    LineArgs c = col_args(h, buf, buf, images);
+    LineArgs c = col_args(h, buf, buf, images, pitch, pitch);
     c.fft1 = dir; c.scale = scale;
     return launch_lines(h, h->plan_x, c, K_OTHER);
 }
@@ -381,19 +403,19 @@ int slice_loop(msl_handle* h, int fused_slot) {
     const msl_config& c = h->cfg;
     const int P = c.n_probes, nz = c.nz;
     const size_t npix = (size_t)c.nx * c.ny;
-    HIPCHK(h, hipMemcpyAsync(h->psi, h->psi0, (size_t)P * npix * sizeof(float2), hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->psi, h->psi0, (size_t)P * c.nx * h->pitch * sizeof(float2), hipMemcpyDeviceToDevice, h->stream));
     int rc = begin_timed(h, 2 * nz + 2);
     if (rc) return rc;
     const bool fused = fused_slot >= 0;
     for (int z = 0; z < nz; ++z) {
         const bool last = (z == nz - 1);
         if (h->Ry) {
-            RowJob r = row_job(h, h->psi, P);
+            RowJob r = row_job(h, h->psi, P, h->pitch);
             r.do_ifft = z > 0; r.trans = h->trans + (size_t)z * npix;
             r.do_fft = (!last || fused); r.py = last ? nullptr : h->pyt;
             if ((rc = launch_row_fast(h, r, K_ROW))) return rc;
         } else {
-            LineArgs r = row_args(h, h->psi, h->psi, P);
+            LineArgs r = row_args(h, h->psi, h->psi, P, h->pitch);
             r.fft1 = (z > 0) ? -1 : 0;
             r.m1_kind = MUL_ARRAY; r.m1 = h->trans + (size_t)z * npix; r.m1_ls = c.ny;
             if (!last) { r.fft2 = +1; r.m2_kind = MUL_VEC; r.m2 = h->pyt; }
@@ -402,11 +424,11 @@ int slice_loop(msl_handle* h, int fused_slot) {
         }
         if (!last) {
             if (h->Rx) {
-                ColJob k = col_job(h, h->psi, h->psi, P);
+                ColJob k = col_job(h, h->psi, h->psi, P, h->pitch, h->pitch);
                 k.px = h->pxt; k.flags = COL_FWD | COL_MULPX | COL_INV;
                 if ((rc = launch_col_fast(h, k, K_COL))) return rc;
             } else {
-                LineArgs k = col_args(h, h->psi, h->psi, P);
+                LineArgs k = col_args(h, h->psi, h->psi, P, h->pitch, h->pitch);
                 k.fft1 = +1; k.m1_kind = MUL_VEC; k.m1 = h->pxt; k.fft2 = -1;
                 if ((rc = launch_lines(h, h->plan_x, k, K_COL))) return rc;
             }
@@ -415,11 +437,11 @@ int slice_loop(msl_handle* h, int fused_slot) {
     if (fused) {
         // epilogue: fft along x, fftshift both axes, scatter into (P, T_local, nx, ny)
         if (h->Rx) {
-            ColJob k = col_job(h, h->psi, h->wf + (size_t)fused_slot * npix, P);
+            ColJob k = col_job(h, h->psi, h->wf + (size_t)fused_slot * npix, P, h->pitch, c.ny);
             k.flags = COL_FWD | COL_SHIFT; k.out_image_stride = (long long)c.n_frames * npix;
             if ((rc = launch_col_fast(h, k, K_OTHER))) return rc;
         } else {
-            LineArgs k = col_args(h, h->psi, h->wf + (size_t)fused_slot * npix, P);
+            LineArgs k = col_args(h, h->psi, h->wf + (size_t)fused_slot * npix, P, h->pitch, c.ny);
             k.fft1 = +1;
             k.out_is = (long long)c.n_frames * npix;
             k.shift_n = c.nx / 2; k.shift_r = c.ny / 2;
@@ -497,14 +519,24 @@ int msl_create(const msl_config* cfg, msl_handle** out) {
         int ry = fast_radix(cfg->ny), rx = fast_radix(cfg->nx);
         if (ry && cfg->nx % (256 / ry) == 0) { h->Ry = ry; if ((rc = make_tw4(h, &h->tw4_y, ry))) return bail(rc); }
         if (rx && cfg->ny % 16 == 0 && cfg->ny >= 32) { h->Rx = rx; if ((rc = make_tw4(h, &h->tw4_x, rx))) return bail(rc); }
+        { const char* e = getenv("MSL_ROW_VARIANT"); if (e) h->row_variant = atoi(e) ? 1 : 0; }
+        { const char* e = getenv("MSL_ROW_PCHUNK"); if (e) h->row_pchunk = atoi(e); }
+        (void)hipFuncSetAttribute((const void*)row_pass_pf_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
+        (void)hipFuncSetAttribute((const void*)row_pass_pf_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
         (void)hipFuncSetAttribute((const void*)row_pass_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
         (void)hipFuncSetAttribute((const void*)row_pass_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
         (void)hipFuncSetAttribute((const void*)col_pass_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
         (void)hipFuncSetAttribute((const void*)col_pass_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
     }
     const size_t npix = (size_t)cfg->nx * cfg->ny;
-    if ((rc = dalloc(h, &h->psi0, npix * cfg->n_probes))) return bail(rc);
-    if ((rc = dalloc(h, &h->psi, npix * cfg->n_probes))) return bail(rc);
+    {
+        const char* e = getenv("MSL_PITCH_PAD");
+        int pad = e ? atoi(e) : 16;
+        if (pad < 0 || (pad & 1)) pad = 16;
+        h->pitch = cfg->ny + ((h->Rx || h->Ry) ? pad : 0);
+    }
+    if ((rc = dalloc(h, &h->psi0, (size_t)cfg->nx * h->pitch * cfg->n_probes))) return bail(rc);
+    if ((rc = dalloc(h, &h->psi, (size_t)cfg->nx * h->pitch * cfg->n_probes))) return bail(rc);
     if ((rc = dalloc(h, &h->trans, npix * cfg->nz))) return bail(rc);
     if (cfg->keep_potential && (rc = dalloc(h, &h->V, npix * cfg->nz))) return bail(rc);
     if (cfg->n_frames > 0) {
@@ -589,8 +621,8 @@ int msl_resize_probes(msl_handle* h, int32_t n_probes) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     const size_t npix = (size_t)h->cfg.nx * h->cfg.ny;
     int rc;
-    if ((rc = dalloc(h, &h->psi0, npix * n_probes))) return rc;
-    if ((rc = dalloc(h, &h->psi, npix * n_probes))) return rc;
+    if ((rc = dalloc(h, &h->psi0, (size_t)h->cfg.nx * h->pitch * n_probes))) return rc;
+    if ((rc = dalloc(h, &h->psi, (size_t)h->cfg.nx * h->pitch * n_probes))) return rc;
     if ((rc = dalloc(h, &h->d_xy, (size_t)2 * n_probes))) return rc;
     h->cfg.n_probes = n_probes;
     h->have_probes = false; h->have_exit = false;
@@ -609,14 +641,14 @@ int msl_shift_probes(msl_handle* h, const float* base, const double* xy, int32_t
     HIPCHK(h, hipMemcpyAsync(bk, base, npix * sizeof(float2), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->d_xy, xy, 2 * sizeof(double) * n_probes, hipMemcpyHostToDevice, h->stream));
     h->cur = nullptr;
-    rc = fft2_inplace(h, bk, 1, +1, 1.0f);
+    rc = fft2_inplace(h, bk, 1, +1, 1.0f, c.ny);
     if (rc == MSL_OK) {
         const long long total = (long long)npix * n_probes;
         hipLaunchKernelGGL(probe_ramp_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, h->psi0, bk, h->d_xy,
-                           n_probes, c.nx, c.ny, 1.0 / (c.nx * c.dx), 1.0 / (c.ny * c.dy));
+                           n_probes, c.nx, c.ny, h->pitch, 1.0 / (c.nx * c.dx), 1.0 / (c.ny * c.dy));
         if (hipGetLastError() != hipSuccess) rc = fail(h, MSL_ERR_HIP, "probe_ramp_kernel launch failed");
     }
-    if (rc == MSL_OK) rc = fft2_inplace(h, h->psi0, n_probes, -1, 1.0f / ((float)c.nx * (float)c.ny));
+    if (rc == MSL_OK) rc = fft2_inplace(h, h->psi0, n_probes, -1, 1.0f / ((float)c.nx * (float)c.ny), h->pitch);
     hipError_t e = hipStreamSynchronize(h->stream);
     (void)hipFree(bk);
     if (rc) return rc;
@@ -635,10 +667,10 @@ int msl_set_probes(msl_handle* h, double mrad, const double* xy, int32_t n_probe
     const long long total = (long long)c.nx * c.ny * n_probes;
     const double lx = c.nx * c.dx, ly = c.ny * c.dy;
     hipLaunchKernelGGL(probe_kspace_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, h->psi0, h->d_xy,
-                       n_probes, c.nx, c.ny, 1.0 / lx, 1.0 / ly, 1.0 / (c.nx * c.dx), 1.0 / (c.ny * c.dy),
+                       n_probes, c.nx, c.ny, h->pitch, 1.0 / lx, 1.0 / ly, 1.0 / (c.nx * c.dx), 1.0 / (c.ny * c.dy),
                        (mrad * 1e-3) / c.wavelength, mrad == 0 ? 1 : 0);
     HIPCHK(h, hipGetLastError());
-    int rc = fft2_inplace(h, h->psi0, n_probes, -1, 1.0f / ((float)c.nx * (float)c.ny));
+    int rc = fft2_inplace(h, h->psi0, n_probes, -1, 1.0f / ((float)c.nx * (float)c.ny), h->pitch);
     if (rc) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->have_probes = true;
@@ -649,7 +681,8 @@ int msl_upload_probes(msl_handle* h, const float* c64, int32_t n_probes) {
     if (!h || !c64) return fail(h, MSL_ERR_INVALID, "msl_upload_probes: null argument");
     if (n_probes != h->cfg.n_probes) return fail(h, MSL_ERR_INVALID, "msl_upload_probes: %d probes, handle has %d", n_probes, h->cfg.n_probes);
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    HIPCHK(h, hipMemcpyAsync(h->psi0, c64, (size_t)n_probes * h->cfg.nx * h->cfg.ny * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpy2DAsync(h->psi0, (size_t)h->pitch * sizeof(float2), c64, (size_t)h->cfg.ny * sizeof(float2),
+                               (size_t)h->cfg.ny * sizeof(float2), (size_t)n_probes * h->cfg.nx, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->have_probes = true;
     return MSL_OK;
@@ -721,10 +754,10 @@ int msl_build_potential(msl_handle* h, const double* pos, const int32_t* Z, int6
     }
     h->n_species = nsp;
     // V_s = Re ifft2(R_s) / (dx^2 dy^2);  t_s = exp(i sigma V_s)  -- in place over the (nz,nx,ny) buffer
-    LineArgs r = row_args(h, h->trans, h->trans, c.nz);
+    LineArgs r = row_args(h, h->trans, h->trans, c.nz, c.ny);
     r.fft1 = -1;
     if ((rc = launch_lines(h, h->plan_y, r, K_OTHER))) return rc;
-    LineArgs k = col_args(h, h->trans, h->trans, c.nz);
+    LineArgs k = col_args(h, h->trans, h->trans, c.nz, c.ny, c.ny);
     k.fft1 = -1;
     k.scale = (float)(1.0 / ((double)c.nx * c.ny) / (c.dx * c.dx * c.dy * c.dy));
     k.store_mode = STORE_POTENTIAL; k.out_real = h->V; k.sigma = (float)c.sigma;
@@ -877,6 +910,12 @@ int msl_download(msl_handle* h, msl_buffer what, void* dst, size_t bytes, int64_
         off = per * first; len = per * count;
     }
     if (bytes != len) return fail(h, MSL_ERR_INVALID, "msl_download: dst holds %zu bytes, buffer slice is %zu", bytes, len);
+    if ((what == MSL_BUF_PROBES || what == MSL_BUF_EXIT) && h->pitch != h->cfg.ny) {
+        HIPCHK(h, hipMemcpy2DAsync(dst, (size_t)h->cfg.ny * sizeof(float2), src, (size_t)h->pitch * sizeof(float2),
+                                   (size_t)h->cfg.ny * sizeof(float2), (size_t)h->cfg.n_probes * h->cfg.nx, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        return MSL_OK;
+    }
     HIPCHK(h, hipMemcpyAsync(dst, src + off, len, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return MSL_OK;
@@ -923,7 +962,7 @@ int msl_fft2_host(msl_handle* h, const float* in, float* out, int32_t batch, int
     if (rc) return rc;
     HIPCHK(h, hipMemcpyAsync(buf, in, n * sizeof(float2), hipMemcpyHostToDevice, h->stream));
     h->cur = nullptr;
-    rc = fft2_inplace(h, buf, batch, dir, dir < 0 ? 1.0f / ((float)c.nx * (float)c.ny) : 1.0f);
+    rc = fft2_inplace(h, buf, batch, dir, dir < 0 ? 1.0f / ((float)c.nx * (float)c.ny) : 1.0f, c.ny);
     if (rc == MSL_OK) {
         hipError_t e = hipMemcpyAsync(out, buf, n * sizeof(float2), hipMemcpyDeviceToHost, h->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream);

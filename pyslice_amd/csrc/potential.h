@@ -192,7 +192,7 @@ __global__ void __launch_bounds__(256) structure_factor_kernel(float2* __restric
 // so that ifft2(psik)[p] == create_batched_probes(Probe(...))[p]  (multislice.py:116-124, 216-227).
 // Plane wave (mrad == 0): psik = nx*ny at DC only (ones after the normalised inverse FFT).
 __global__ void probe_kspace_kernel(float2* __restrict__ psik, const double* __restrict__ xy, int P, int nx, int ny,
-                                    double inv_lx, double inv_ly, double kfreq_x, double kfreq_y, double radius,
+                                    int pitch, double inv_lx, double inv_ly, double kfreq_x, double kfreq_y, double radius,
                                     int plane_wave) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     long long npix = (long long)nx * ny;
@@ -200,36 +200,38 @@ __global__ void probe_kspace_kernel(float2* __restrict__ psik, const double* __r
     int p = (int)(i / npix);
     long long q = i - (long long)p * npix;
     int mx = (int)(q / ny), my = (int)(q - (long long)mx * ny);
+    const long long o = ((long long)p * nx + mx) * pitch + my;
     if (plane_wave) {
-        psik[i] = (mx == 0 && my == 0) ? make_float2((float)npix, 0.f) : make_float2(0.f, 0.f);
+        psik[o] = (mx == 0 && my == 0) ? make_float2((float)npix, 0.f) : make_float2(0.f, 0.f);
         return;
     }
     int fx = signed_freq(mx, nx), fy = signed_freq(my, ny);
     double kx = fx * kfreq_x, ky = fy * kfreq_y;       // fftfreq value = index * (1/(n*d))
     bool inside = sqrt(kx * kx + ky * ky) < radius;
-    if (!inside) { psik[i] = make_float2(0.f, 0.f); return; }
+    if (!inside) { psik[o] = make_float2(0.f, 0.f); return; }
     double t = fx * ((double)(nx / 2) / nx + xy[2 * p] * inv_lx) + fy * ((double)(ny / 2) / ny + xy[2 * p + 1] * inv_ly);
     t -= rint(t);
     float sn, cs;
     sincospif((float)(2.0 * t), &sn, &cs);
-    psik[i] = make_float2(cs, sn);
+    psik[o] = make_float2(cs, sn);
 }
 
 // psi0k[p][mx][my] = basek[mx][my] * exp(2 pi i (kx px + ky py))   (multislice.py:221-223)
 __global__ void probe_ramp_kernel(float2* __restrict__ out, const float2* __restrict__ basek,
-                                  const double* __restrict__ xy, int P, int nx, int ny, double inv_lx, double inv_ly) {
+                                  const double* __restrict__ xy, int P, int nx, int ny, int pitch, double inv_lx, double inv_ly) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     long long npix = (long long)nx * ny;
     if (i >= npix * P) return;
     int p = (int)(i / npix);
     long long q = i - (long long)p * npix;
     int mx = (int)(q / ny), my = (int)(q - (long long)mx * ny);
+    const long long o = ((long long)p * nx + mx) * pitch + my;
     double t = signed_freq(mx, nx) * (xy[2 * p] * inv_lx) + signed_freq(my, ny) * (xy[2 * p + 1] * inv_ly);
     t -= rint(t);
     float sn, cs;
     sincospif((float)(2.0 * t), &sn, &cs);
     float2 b = basek[q];
-    out[i] = make_float2(b.x * cs - b.y * sn, b.x * sn + b.y * cs);
+    out[o] = make_float2(b.x * cs - b.y * sn, b.x * sn + b.y * cs);
 }
 
 // t = exp(i sigma V) from an uploaded V (nz,nx,ny) float32
