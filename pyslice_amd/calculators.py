@@ -177,6 +177,8 @@ class MultisliceCalculator:
         wf._engine = eng
         wf._resident = resident
         wf._output = self._output
+        if self._world > 1 and self._gather == "none":
+            wf._frame_shard = (self.n_frames, len(frames))      # lets TACAWData do the all-to-all itself
         return wf
 
     # ------------------------------------------------------------------------------------------

@@ -39,6 +39,9 @@ struct LineJob {
     int shift_n, shift_r;       // out index: ((n+shift_n)%N, (r+shift_r)%lines_per_image)
     int n_stages;
     int radix[MSL_MAX_STAGES];
+    int M;                      // transform length of the Stockham stages: N, or >= 2N-1 for Bluestein lines
+    const float2* chirp;        // Bluestein: w[n] = exp(-i pi n^2 / N), n < N
+    const float2* bfilt;        // Bluestein: FFT_M of the wrapped conj chirp, pre-divided by M
     int npad;                   // LDS line pitch (float2)
     int tw_in_lds;
     float scale;
@@ -149,30 +152,67 @@ __device__ __forceinline__ void stockham_stage(float2* tile, const float2* tw, i
 // RSET selects which radices a kernel instantiation carries (register pressure follows the
 // largest one): 0 = {2,4,8}, 1 = + {3,5,7}, 2 = + {11,13}.
 template <int RSET>
-__device__ __forceinline__ void tile_fft(float2* tile, const float2* tw, const LineJob& job, int C, int dir, int tid,
-                                         int nthreads) {
+__device__ __forceinline__ void tile_stages(float2* tile, const float2* tw, const LineJob& job, int C, int dir, int tid,
+                                            int nthreads) {
     const float s = dir > 0 ? 1.0f : -1.0f;
     int Ns = 1;
     for (int st = 0; st < job.n_stages; ++st) {
         const int R = job.radix[st];
         switch (R) {
-            case 2: stockham_stage<2>(tile, tw, job.N, job.npad, C, Ns, s, tid, nthreads); break;
-            case 4: stockham_stage<4>(tile, tw, job.N, job.npad, C, Ns, s, tid, nthreads); break;
-            case 8: stockham_stage<8>(tile, tw, job.N, job.npad, C, Ns, s, tid, nthreads); break;
+            case 2: stockham_stage<2>(tile, tw, job.M, job.npad, C, Ns, s, tid, nthreads); break;
+            case 4: stockham_stage<4>(tile, tw, job.M, job.npad, C, Ns, s, tid, nthreads); break;
+            case 8: stockham_stage<8>(tile, tw, job.M, job.npad, C, Ns, s, tid, nthreads); break;
             default:
                 if constexpr (RSET >= 1) {
-                    if (R == 3) stockham_stage<3>(tile, tw, job.N, job.npad, C, Ns, s, tid, nthreads);
-                    else if (R == 5) stockham_stage<5>(tile, tw, job.N, job.npad, C, Ns, s, tid, nthreads);
-                    else if (R == 7) stockham_stage<7>(tile, tw, job.N, job.npad, C, Ns, s, tid, nthreads);
+                    if (R == 3) stockham_stage<3>(tile, tw, job.M, job.npad, C, Ns, s, tid, nthreads);
+                    else if (R == 5) stockham_stage<5>(tile, tw, job.M, job.npad, C, Ns, s, tid, nthreads);
+                    else if (R == 7) stockham_stage<7>(tile, tw, job.M, job.npad, C, Ns, s, tid, nthreads);
                 }
                 if constexpr (RSET >= 2) {
-                    if (R == 11) stockham_stage<11>(tile, tw, job.N, job.npad, C, Ns, s, tid, nthreads);
-                    else if (R == 13) stockham_stage<13>(tile, tw, job.N, job.npad, C, Ns, s, tid, nthreads);
+                    if (R == 11) stockham_stage<11>(tile, tw, job.M, job.npad, C, Ns, s, tid, nthreads);
+                    else if (R == 13) stockham_stage<13>(tile, tw, job.M, job.npad, C, Ns, s, tid, nthreads);
                 }
                 break;
         }
         Ns *= R;
     }
+}
+
+// Line transform of logical length N.  Native when the stages run on N itself; otherwise Bluestein's
+// chirp-z: X[k] = w[k] * sum_n (x[n] w[n]) conj(w)[k-n], the convolution done with length-M FFTs in LDS
+// (any N up to 4096, e.g. the reference's 501 x 491 test grid, src/unittests/00_probe.py:7-8).
+template <int RSET>
+__device__ __forceinline__ void tile_fft(float2* tile, const float2* tw, const LineJob& job, int C, int dir, int tid,
+                                         int nthreads) {
+    if (job.M == job.N) { tile_stages<RSET>(tile, tw, job, C, dir, tid, nthreads); return; }
+    const int N = job.N, M = job.M, npad = job.npad;
+    for (int e = tid; e < C * M; e += nthreads) {
+        const int n = e % M, c = e / M;
+        float2 x = make_float2(0.f, 0.f);
+        if (n < N) {
+            x = tile[(size_t)c * npad + n];
+            if (dir < 0) x.y = -x.y;
+            x = cmul(x, job.chirp[n]);
+        }
+        tile[(size_t)c * npad + n] = x;
+    }
+    __syncthreads();
+    tile_stages<RSET>(tile, tw, job, C, +1, tid, nthreads);
+    for (int e = tid; e < C * M; e += nthreads) {
+        const int n = e % M, c = e / M;
+        float2* p = tile + (size_t)c * npad + n;
+        *p = cmul(*p, job.bfilt[n]);
+    }
+    __syncthreads();
+    tile_stages<RSET>(tile, tw, job, C, -1, tid, nthreads);
+    for (int e = tid; e < C * N; e += nthreads) {
+        const int n = e % N, c = e / N;
+        float2* p = tile + (size_t)c * npad + n;
+        float2 y = cmul(*p, job.chirp[n]);
+        if (dir < 0) y.y = -y.y;
+        *p = y;
+    }
+    __syncthreads();
 }
 
 template <int RSET>
@@ -186,7 +226,7 @@ __global__ void __launch_bounds__(1024) line_fft_kernel(LineJob job) {
     const float2* tw = job.tw;
     if (job.tw_in_lds) {
         float2* tws = tile + (size_t)job.C * npad;
-        for (int i = tid; i < N; i += nthreads) tws[i] = job.tw[i];
+        for (int i = tid; i < job.M; i += nthreads) tws[i] = job.tw[i];
         tw = tws;
     }
     const int elems = C * N;

@@ -234,8 +234,11 @@ struct ColJob {
     int n_images;
     int flags;              // COL_FWD | COL_MULPX | COL_INV | COL_SHIFT (fftshifted scatter of both axes into `out`)
     float scale;            // applied at the store (1/(nx ny) of a stand-alone inverse transform)
+    float sigma;            // COL_POTENTIAL: t = exp(i sigma V)
+    float* out_real;        // COL_POTENTIAL: optional V (same pitch / image stride as `out`)
 };
-enum { COL_FWD = 1, COL_MULPX = 2, COL_INV = 4, COL_SHIFT = 8 };
+// COL_POTENTIAL: epilogue of the potential build, V = Re(x)*scale, out = exp(i sigma V)  (potentials.py:336-342, multislice.py:282)
+enum { COL_FWD = 1, COL_MULPX = 2, COL_INV = 4, COL_SHIFT = 8, COL_POTENTIAL = 16 };
 
 // Column pass.  Workgroup = 16*R threads owns a tile of 16 neighbouring columns (128-byte row
 // segments in HBM) x N rows: staged into LDS column-major, one R-lane group per column, results
@@ -316,8 +319,19 @@ __global__ void __launch_bounds__(16 * R) col_pass_kernel(ColJob job) {
                 float2 a = cols[(2 * q) * CS + x], b = cols[(2 * q + 1) * CS + x];
                 int xo = x + xshift;
                 if (xo >= N) xo -= N;
-                *reinterpret_cast<float4*>(dst + (long long)xo * job.out_pitch) =
-                    make_float4(a.x * job.scale, a.y * job.scale, b.x * job.scale, b.y * job.scale);
+                if (job.flags & COL_POTENTIAL) {
+                    const float va = a.x * job.scale, vb = b.x * job.scale;
+                    if (job.out_real)
+                        *reinterpret_cast<float2*>(job.out_real + p * job.out_image_stride + cshift + 2 * q +
+                                                   (long long)xo * job.out_pitch) = make_float2(va, vb);
+                    float sa, ca, sb, cb;
+                    sincosf(job.sigma * va, &sa, &ca);
+                    sincosf(job.sigma * vb, &sb, &cb);
+                    *reinterpret_cast<float4*>(dst + (long long)xo * job.out_pitch) = make_float4(ca, sa, cb, sb);
+                } else {
+                    *reinterpret_cast<float4*>(dst + (long long)xo * job.out_pitch) =
+                        make_float4(a.x * job.scale, a.y * job.scale, b.x * job.scale, b.y * job.scale);
+                }
             }
             lds_barrier();                      // LDS is free for the next tile's staging from here on
         }

@@ -23,6 +23,9 @@ namespace {
 thread_local std::string g_create_error;
 
 struct FftPlan {
+    int M = 0;                  // length the Stockham stages run on (N, or a power of two >= 2N-1: Bluestein)
+    float2* chirp = nullptr;
+    float2* bfilt = nullptr;
     int N = 0;
     int n_stages = 0;
     int radix[MSL_MAX_STAGES] = {0};
@@ -140,23 +143,73 @@ bool factorize(int N, FftPlan& pl) {
     return n == 1;
 }
 
+// in-place radix-2 FFT in double on the host (Bluestein filter setup only)
+void host_fft_pow2(std::vector<double>& re, std::vector<double>& im) {
+    const int n = (int)re.size();
+    for (int i = 1, j = 0; i < n; ++i) {
+        int bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) { std::swap(re[i], re[j]); std::swap(im[i], im[j]); }
+    }
+    for (int len = 2; len <= n; len <<= 1) {
+        for (int i = 0; i < n; i += len)
+            for (int k = 0; k < len / 2; ++k) {
+                const double a = -2.0 * M_PI * k / len, c = cos(a), s = sin(a);
+                const int u = i + k, v = i + k + len / 2;
+                const double xr = re[v] * c - im[v] * s, xi = re[v] * s + im[v] * c;
+                re[v] = re[u] - xr; im[v] = im[u] - xi; re[u] += xr; im[u] += xi;
+            }
+    }
+}
+
 int make_plan(msl_handle* h, FftPlan& pl, int N) {
     if (pl.ok && pl.N == N) return MSL_OK;
     pl.ok = false;
     if (N < 1) return fail(h, MSL_ERR_INVALID, "FFT length %d", N);
-    if (!factorize(N, pl))
-        return fail(h, MSL_ERR_UNSUPPORTED, "FFT length %d has a prime factor > 13 (no Bluestein path yet)", N);
-    if ((size_t)N * 8 * 2 > (size_t)h->lds_limit)
-        return fail(h, MSL_ERR_UNSUPPORTED, "FFT length %d does not fit the LDS-resident kernel", N);
-    std::vector<float2> tw(N);
-    for (int j = 0; j < N; ++j) {
-        double a = -2.0 * M_PI * (double)j / (double)N;
+    int M = N;
+    bool native = factorize(N, pl);
+    if (!native) {
+        // Bluestein: convolution length = power of two >= 2N-1
+        M = 1;
+        while (M < 2 * N - 1) M <<= 1;
+        FftPlan tmp;
+        if (!factorize(M, tmp)) return fail(h, MSL_ERR_UNSUPPORTED, "FFT length %d: no plan", N);
+        pl.n_stages = tmp.n_stages;
+        for (int i = 0; i < tmp.n_stages; ++i) pl.radix[i] = tmp.radix[i];
+    }
+    pl.N = N; pl.M = M;
+    if ((size_t)M * 8 * 2 > (size_t)h->lds_limit)
+        return fail(h, MSL_ERR_UNSUPPORTED, "FFT length %d%s does not fit the LDS-resident kernel", N,
+                    native ? "" : " (Bluestein, prime factor > 13)");
+    std::vector<float2> tw(M);
+    for (int j = 0; j < M; ++j) {
+        double a = -2.0 * M_PI * (double)j / (double)M;
         tw[j] = make_float2((float)cos(a), (float)sin(a));
     }
-    int rc = dalloc(h, &pl.tw, (size_t)N);
+    int rc = dalloc(h, &pl.tw, (size_t)M);
     if (rc) return rc;
-    HIPCHK(h, hipMemcpyAsync(pl.tw, tw.data(), N * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(pl.tw, tw.data(), M * sizeof(float2), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (!native) {
+        std::vector<float2> chirp(N);
+        std::vector<double> br(M, 0.0), bi(M, 0.0);
+        for (int n = 0; n < N; ++n) {
+            const long long q = ((long long)n * n) % (2LL * N);
+            const double a = -M_PI * (double)q / (double)N;
+            chirp[n] = make_float2((float)cos(a), (float)sin(a));
+            br[n] = cos(a); bi[n] = -sin(a);                 // conj chirp
+            if (n) { br[M - n] = br[n]; bi[M - n] = bi[n]; }
+        }
+        host_fft_pow2(br, bi);
+        std::vector<float2> bf(M);
+        for (int j = 0; j < M; ++j) bf[j] = make_float2((float)(br[j] / M), (float)(bi[j] / M));
+        if ((rc = dalloc(h, &pl.chirp, (size_t)N))) return rc;
+        if ((rc = dalloc(h, &pl.bfilt, (size_t)M))) return rc;
+        HIPCHK(h, hipMemcpyAsync(pl.chirp, chirp.data(), N * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(pl.bfilt, bf.data(), M * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
     pl.ok = true;
     return MSL_OK;
 }
@@ -233,7 +286,8 @@ int launch_lines(msl_handle* h, const FftPlan& pl, const LineArgs& a, int kind) 
     job.store_mode = a.store_mode; job.shift_n = a.shift_n; job.shift_r = a.shift_r;
     job.n_stages = pl.n_stages; for (int i = 0; i < pl.n_stages; ++i) job.radix[i] = pl.radix[i];
     job.scale = a.scale; job.sigma = a.sigma;
-    const int N = pl.N;
+    const int N = pl.M;         // sizing follows the transform length (M > N for Bluestein lines)
+    job.M = pl.M; job.chirp = pl.chirp; job.bfilt = pl.bfilt;
     const int max_elems = MSL_GEN_E * 1024;
     int C;
     if (a.contiguous_lines) C = 16; else C = std::max(1, std::min(16, 8192 / N));
@@ -242,7 +296,7 @@ int launch_lines(msl_handle* h, const FftPlan& pl, const LineArgs& a, int kind) 
     auto lds_need = [&](int c, bool tw) { return (size_t)c * job.npad * 8 + (tw ? (size_t)N * 8 : 0); };
     while (C > 1 && ((long long)C * N > max_elems || lds_need(C, false) > (size_t)h->lds_limit)) C >>= 1;
     if ((long long)C * N > max_elems || lds_need(C, false) > (size_t)h->lds_limit)
-        return fail(h, MSL_ERR_UNSUPPORTED, "line length %d too long for the LDS kernel", N);
+        return fail(h, MSL_ERR_UNSUPPORTED, "line length %d too long for the LDS kernel", pl.N);
     job.C = C;
     job.tw_in_lds = lds_need(C, true) <= (size_t)h->lds_limit ? 1 : 0;
     size_t lds = lds_need(C, job.tw_in_lds != 0);
@@ -564,7 +618,8 @@ int msl_destroy(msl_handle* h) {
     for (auto& s : h->ring) for (auto e : s.ev) (void)hipEventDestroy(e);
     void* bufs[] = {h->psi0, h->psi, h->trans, h->V, h->wf, h->intensity, h->pxt, h->pyt, h->d_abcd, h->d_lo, h->d_hi,
                     h->d_pos, h->d_Z, h->d_key, h->d_order, h->d_u1, h->d_u2, h->d_ex, h->d_ey, h->d_counts, h->d_start,
-                    h->d_z2s, h->d_species, h->d_ff, h->d_xy, h->plan_x.tw, h->plan_y.tw, h->plan_t.tw, h->tw4_x, h->tw4_y};
+                    h->d_z2s, h->d_species, h->d_ff, h->d_xy, h->plan_x.tw, h->plan_y.tw, h->plan_t.tw, h->tw4_x, h->tw4_y,
+                    h->plan_x.chirp, h->plan_x.bfilt, h->plan_y.chirp, h->plan_y.bfilt, h->plan_t.chirp, h->plan_t.bfilt};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -746,22 +801,45 @@ int msl_build_potential(msl_handle* h, const double* pos, const int32_t* Z, int6
                                h->d_order, n_sorted, c.nx);
             hipLaunchKernelGGL(phase_table_kernel, dim3((unsigned)((ty + 255) / 256)), dim3(256), 0, h->stream, h->d_ey, h->d_u2,
                                h->d_order, n_sorted, c.ny);
-            const int tiles_x = (c.nx + SF_TILE - 1) / SF_TILE, tiles_y = (c.ny + SF_TILE - 1) / SF_TILE;
+            const int tiles_y = (c.ny + SF_TILE - 1) / SF_TILE;
+            const bool hermitian = (c.nx % (2 * SF_TILE) == 0) && (c.ny % 2 == 0) && !getenv("MSL_NO_HERMITIAN");
+            const int tiles_x = hermitian ? c.nx / 2 / SF_TILE : (c.nx + SF_TILE - 1) / SF_TILE;
             hipLaunchKernelGGL(structure_factor_kernel, dim3(tiles_x * tiles_y, c.nz), dim3(256), 0, h->stream, h->trans, h->d_ex,
                                h->d_ey, h->d_ff, h->d_start, nsp, c.nx, c.ny, tiles_y);
+            if (hermitian) {
+                const int nb = c.ny + c.nx / 2 - 1;
+                hipLaunchKernelGGL(structure_factor_nyquist_kernel, dim3((nb + 127) / 128, c.nz), dim3(128), 0, h->stream, h->trans,
+                                   h->d_ex, h->d_ey, h->d_ff, h->d_start, nsp, c.nx, c.ny);
+                hipLaunchKernelGGL(structure_factor_mirror_kernel, dim3((c.ny + 255) / 256, c.nx / 2 - 1, c.nz), dim3(256), 0,
+                                   h->stream, h->trans, c.nx, c.ny);
+            }
             HIPCHK(h, hipGetLastError());
         }
     }
     h->n_species = nsp;
     // V_s = Re ifft2(R_s) / (dx^2 dy^2);  t_s = exp(i sigma V_s)  -- in place over the (nz,nx,ny) buffer
-    LineArgs r = row_args(h, h->trans, h->trans, c.nz, c.ny);
-    r.fft1 = -1;
-    if ((rc = launch_lines(h, h->plan_y, r, K_OTHER))) return rc;
-    LineArgs k = col_args(h, h->trans, h->trans, c.nz, c.ny, c.ny);
-    k.fft1 = -1;
-    k.scale = (float)(1.0 / ((double)c.nx * c.ny) / (c.dx * c.dx * c.dy * c.dy));
-    k.store_mode = STORE_POTENTIAL; k.out_real = h->V; k.sigma = (float)c.sigma;
-    if ((rc = launch_lines(h, h->plan_x, k, K_OTHER))) return rc;
+    const float vscale = (float)(1.0 / ((double)c.nx * c.ny) / (c.dx * c.dx * c.dy * c.dy));
+    h->cur = nullptr;
+    if (h->Ry) {
+        RowJob r = row_job(h, h->trans, c.nz, c.ny);
+        r.do_ifft = 1;
+        if ((rc = launch_row_fast(h, r, K_OTHER))) return rc;
+    } else {
+        LineArgs r = row_args(h, h->trans, h->trans, c.nz, c.ny);
+        r.fft1 = -1;
+        if ((rc = launch_lines(h, h->plan_y, r, K_OTHER))) return rc;
+    }
+    if (h->Rx) {
+        ColJob k = col_job(h, h->trans, h->trans, c.nz, c.ny, c.ny);
+        k.flags = COL_INV | COL_POTENTIAL; k.scale = vscale; k.sigma = (float)c.sigma; k.out_real = h->V;
+        if ((rc = launch_col_fast(h, k, K_OTHER))) return rc;
+    } else {
+        LineArgs k = col_args(h, h->trans, h->trans, c.nz, c.ny, c.ny);
+        k.fft1 = -1;
+        k.scale = vscale;
+        k.store_mode = STORE_POTENTIAL; k.out_real = h->V; k.sigma = (float)c.sigma;
+        if ((rc = launch_lines(h, h->plan_x, k, K_OTHER))) return rc;
+    }
     HIPCHK(h, hipEventRecord(e1, h->stream));
     HIPCHK(h, hipEventSynchronize(e1));
     float ms = 0.f;

@@ -188,6 +188,45 @@ __global__ void __launch_bounds__(256) structure_factor_kernel(float2* __restric
     }
 }
 
+// Hermitian shortcut for even nx, ny: R_s[-k] = conj(R_s[k]) for every bin that has a mirror partner.  The tile
+// kernel then only computes rows mx < nx/2; this kernel adds the bins without a partner -- the Nyquist row
+// mx = nx/2 (all my) and the Nyquist column my = ny/2 of the rows mx > nx/2 -- by direct summation.
+__global__ void structure_factor_nyquist_kernel(float2* __restrict__ recip, const float2* __restrict__ ex,
+                                                const float2* __restrict__ ey, const float* __restrict__ ff,
+                                                const int* __restrict__ start, int n_species, int nx, int ny) {
+    const int s = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;      // 0..ny-1: row bins, ny..ny+nx/2-2: column bins
+    int mx, my;
+    if (i < ny) { mx = nx / 2; my = i; }
+    else if (i < ny + nx / 2 - 1) { mx = nx / 2 + 1 + (i - ny); my = ny / 2; }
+    else return;
+    float2 total = make_float2(0.f, 0.f);
+    for (int sp = 0; sp < n_species; ++sp) {
+        const int a0 = start[s * n_species + sp], a1 = start[s * n_species + sp + 1];
+        float2 acc = make_float2(0.f, 0.f);
+        for (int a = a0; a < a1; ++a) {
+            const float2 vx = ex[(size_t)a * nx + mx], vy = ey[(size_t)a * ny + my];
+            acc.x = fmaf(vx.x, vy.x, fmaf(-vx.y, vy.y, acc.x));
+            acc.y = fmaf(vx.x, vy.y, fmaf(vx.y, vy.x, acc.y));
+        }
+        const float w = ff[(size_t)sp * nx * ny + (size_t)mx * ny + my];
+        total.x = fmaf(w, acc.x, total.x);
+        total.y = fmaf(w, acc.y, total.y);
+    }
+    recip[(size_t)s * nx * ny + (size_t)mx * ny + my] = total;
+}
+
+// rows mx > nx/2 (except the Nyquist column): R[mx][my] = conj(R[nx-mx][(ny-my)%ny])
+__global__ void structure_factor_mirror_kernel(float2* __restrict__ recip, int nx, int ny) {
+    const int s = blockIdx.z;
+    const int mx = nx / 2 + 1 + blockIdx.y;
+    const int my = blockIdx.x * blockDim.x + threadIdx.x;
+    if (mx >= nx || my >= ny || my == ny / 2) return;
+    float2* img = recip + (size_t)s * nx * ny;
+    const float2 v = img[(size_t)(nx - mx) * ny + (my ? ny - my : 0)];
+    img[(size_t)mx * ny + my] = make_float2(v.x, -v.y);
+}
+
 // Reciprocal-space probes: psik[p][mx][my] = mask * exp(2 pi i (fx (hx/nx + px/Lx) + fy (hy/ny + py/Ly)))
 // so that ifft2(psik)[p] == create_batched_probes(Probe(...))[p]  (multislice.py:116-124, 216-227).
 // Plane wave (mrad == 0): psik = nx*ny at DC only (ones after the normalised inverse FFT).

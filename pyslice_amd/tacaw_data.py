@@ -43,6 +43,12 @@ class TACAWData(WFData):
 
         eng = self.__dict__.get("_engine")
         resident = eng is not None and self.__dict__.get("_resident", False) and len(self.layer) == 1
+        shard = self.__dict__.get("_frame_shard")
+        if shard is not None and eng is not None and len(self.layer) == 1:
+            # multi-process run with frame-sharded exit waves still on the devices (gather="none"):
+            # all-to-all to probe shards, local time FFT, gather of the intensities on rank 0
+            self.intensity = self._tacaw_sharded(eng, shard)
+            return
         if resident:
             eng.tacaw()
             if self.__dict__.get("_output") == "device":
@@ -69,6 +75,28 @@ class TACAWData(WFData):
         finally:
             helper.close()
         self.intensity = dst.to(torch.float64).cpu()
+
+    def _tacaw_sharded(self, eng, shard):
+        """Frame-sharded (P, T_r, nx, ny) on every rank -> intensity (P, T, nx, ny) on rank 0 (None elsewhere).
+
+        One RCCL all-to-all re-shards frames -> probes, msl_tacaw runs on the rank's
+        complete time series, one gather assembles the result."""
+        from . import distributed as D
+        n_frames, t_local = shard
+        P, nx, ny = eng.n_probes, eng.nx, eng.ny
+        ptr = eng.device_ptr(_native.BUF_WAVEFUNCTION)
+        dev = torch.device("cuda", eng.device)
+        local = torch.as_tensor(_native.DeviceArray(ptr, (P, eng.n_frames, nx, ny), "<c8", owner=eng), device=dev)[:, :t_local]
+        mine = D.frames_to_probes(local.reshape(P, t_local, nx * ny), n_frames)         # (P_r, T, npix)
+        out = torch.empty(mine.shape, dtype=torch.float32, device=dev)
+        if mine.shape[0] > 0:
+            torch.cuda.synchronize(dev)
+            eng.tacaw(mine.data_ptr(), out.data_ptr(), mine.shape[0], n_frames, nx * ny)
+        full = D.gather_probes(out, P, dst=0)
+        if full is None:
+            return None
+        full = full.reshape(P, n_frames, nx, ny)
+        return full if self.__dict__.get("_output") == "device" else full.to(torch.float64).cpu()
 
     # ---- reductions over intensity(P, F, kx, ky) ----------------------------------------------
     def _inten(self):

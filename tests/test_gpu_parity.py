@@ -37,10 +37,22 @@ def orc():
     return multislice_oracle
 
 
+def _prime_factors(n):
+    out, p = [], 2
+    while p * p <= n:
+        while n % p == 0:
+            out.append(p); n //= p
+        p += 1
+    if n > 1:
+        out.append(n)
+    return out or [1]
+
+
 # ------------------------------------------------------------------ FFT kernels alone
 @pytest.mark.parametrize("shape,batch", [((64, 64), 3), ((96, 80), 2), ((45, 63), 2), ((256, 256), 2), ((128, 512), 1),
                                          ((1024, 1024), 2), ((2048, 2048), 1), ((330, 200), 1), ((2, 2), 1),
-                                         ((1024, 256), 3), ((256, 1024), 3), ((1024, 64), 2), ((40, 256), 2)])
+                                         ((1024, 256), 3), ((256, 1024), 3), ((1024, 64), 2), ((40, 256), 2),
+                                         ((501, 491), 2), ((167, 64), 2), ((1024, 997), 1), ((4093, 34), 1)])
 def test_fft2_matches_numpy(ps, shape, batch):
     from pyslice_amd import _native
     rng = np.random.default_rng(5)
@@ -48,9 +60,10 @@ def test_fft2_matches_numpy(ps, shape, batch):
     eng = _native.Engine(shape[0], shape[1], 1, 0.1, 0.1, 0.5, 0.037, 1e-3, n_probes=1)
     f = eng.fft2(a, +1)
     want = np.fft.fft2(a.astype(np.complex128), axes=(1, 2))
-    assert rel_l2(f, want) < 3e-6
+    tol = 3e-6 if all(max(_prime_factors(n)) <= 13 for n in shape) else 1e-5      # Bluestein lines: two FFTs of >= 2N
+    assert rel_l2(f, want) < tol
     b = eng.fft2(f, -1)
-    assert rel_l2(b, a) < 3e-6
+    assert rel_l2(b, a) < tol
     eng.close()
 
 
@@ -84,7 +97,7 @@ def test_fourstep_kernels_match_generic_kernels(ps, n, nz, P):
 def test_unsupported_length_fails_loudly(ps):
     from pyslice_amd import _native
     with pytest.raises(NotImplementedError):
-        _native.Engine(491, 64, 1, 0.1, 0.1, 0.5, 0.037, 1e-3)       # 491 is prime (reference 00_probe.py grid)
+        _native.Engine(4099, 64, 1, 0.1, 0.1, 0.5, 0.037, 1e-3)      # prime > 4096: beyond the LDS-resident Bluestein path
 
 
 # ------------------------------------------------------------------ goldens
@@ -199,6 +212,13 @@ def test_g8_tacaw(ps, golden):
     assert inten[:, T // 2].max() == 0.0                    # K5: DC bin of the mean-subtracted series
     with pytest.raises(ValueError):
         ps.TACAWData(wf, layer_index=2)
+    # the multi-process path (all-to-all of frame shards, msl_tacaw on torch memory) degenerates to identity
+    # exchanges at world size 1: exercises the zero-copy views and the external-pointer entry
+    wf3 = ps.WFData(probe_positions=wf.probe_positions, time=wf.time, kxs=wf.kxs, kys=wf.kys, layer=wf.layer,
+                    wavefunction_data=None, probe=wf.probe)
+    wf3._engine, wf3._resident, wf3._output, wf3._frame_shard = calc._engine, False, "host", (T, T)
+    tac3 = ps.TACAWData(wf3)
+    assert rel_l2(npy(tac3.intensity), g["intensity"]) < TACAW_TOL
     # the staged path (WFData not resident on the device) gives the same numbers
     wf2 = ps.WFData(probe_positions=wf.probe_positions, time=wf.time, kxs=wf.kxs, kys=wf.kys, layer=wf.layer,
                     wavefunction_data=g["wavefunction_data"], probe=wf.probe)
@@ -242,6 +262,26 @@ def _oracle_case(ps, orc, n, nz, P, mrad, density, seed):
 def test_oracle_parity_midsize(ps, orc, n, nz, P, mrad):
     V, Vg, ex, gex = _oracle_case(ps, orc, n, nz, P, mrad, density=0.102, seed=3)
     assert np.abs(V - Vg).max() / np.abs(V).max() < POT_TOL
+    assert rel_l2(gex, ex) < WAVE_TOL
+    assert ref_residual(gex, ex) < RESID_TOL
+
+
+def test_oracle_parity_prime_grid(ps, orc):
+    """Grid lengths with large prime factors (101 x 97, like the reference's 501 x 491 probe test grid) take the
+    Bluestein path; potential, probes and slice loop must still match the oracle."""
+    from pyslice_amd.synthetic import synthetic_trajectory
+    tr = synthetic_trajectory(101, 8, 1, ny=97, density=0.15, seed=6)
+    xs, ys, zs, lx, ly, lz = ps.gridFromTrajectory(tr)
+    assert (len(xs), len(ys), len(zs)) == (101, 97, 8)
+    pp = [(lx / 2, ly / 2), (1.3, 7.7)]
+    V = orc.potential(xs, ys, zs, tr.positions[0], tr.atom_types)
+    pr = orc.batched_probes(orc.probe_array(xs, ys, 30.0, 100e3), xs, ys, pp)
+    ex = orc.propagate(pr, V, xs, ys, zs, 100e3)
+    pot = ps.Potential(xs, ys, zs, tr.positions[0], list(tr.atom_types))
+    assert np.abs(V - npy(pot.array)).max() / np.abs(V).max() < POT_TOL
+    probes = ps.create_batched_probes(ps.Probe(xs, ys, 30.0, 100e3), pp)
+    assert rel_l2(npy(probes.array), pr) < 1e-5
+    gex = npy(ps.Propagate(probes, pot))
     assert rel_l2(gex, ex) < WAVE_TOL
     assert ref_residual(gex, ex) < RESID_TOL
 
