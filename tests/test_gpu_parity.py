@@ -116,7 +116,7 @@ def test_g3_form_factor(ps, golden):
     eng.close()
 
 
-@pytest.mark.parametrize("name", ["g4_potential_64", "g4_potential_96x80"])
+@pytest.mark.parametrize("name", ["g4_potential_64", "g4_potential_96x80", "g4_potential_axis0"])
 def test_g4_potential(ps, golden, orc, name):
     g = golden(name)
     xs, ys, zs, *_ = orc.grid_from_box(g["box"], 0.1, 0.5)
@@ -126,7 +126,7 @@ def test_g4_potential(ps, golden, orc, name):
     assert np.abs(V - g["V"]).max() / np.abs(g["V"]).max() < POT_TOL
     # element-name input takes the same path
     names = ["B" if z == 5 else "N" for z in g["Z"]]
-    V2 = npy(ps.Potential(xs, ys, zs, g["positions"], names).array)
+    V2 = npy(ps.Potential(xs, ys, zs, g["positions"], names, slice_axis=int(g["slice_axis"])).array)
     assert np.array_equal(V, V2)
 
 
@@ -348,3 +348,64 @@ def test_errors_match_reference_types(ps):
         ps.Trajectory(np.array([5, 7]), np.zeros((1, 2, 2)), np.zeros((1, 2, 3)), np.eye(3), 0.005)
     with pytest.raises(NotImplementedError):
         ps.MultisliceCalculator(force_cpu=True)
+
+
+# ------------------------------------------------------------------ edge cases (empty / ragged / out-of-range inputs)
+def test_edge_atoms_outside_every_slice_give_vacuum(ps, orc):
+    xs = np.linspace(0, 6.4, 64, endpoint=False); zs = np.linspace(0, 2.0, 4, endpoint=False)
+    pos = np.array([[1.0, 1.0, -0.2], [2.0, 2.0, 9.0]])           # z<0 and z beyond the last slice: dropped (Q7)
+    pot = ps.Potential(xs, xs, zs, pos, [5, 7])
+    assert np.abs(npy(pot.array)).max() == 0.0
+    want = orc.propagate(orc.probe_array(xs, xs, 30.0, 100e3)[None], np.zeros((64, 64, 4)), xs, xs, zs, 100e3)[0]
+    got = npy(ps.Propagate(ps.Probe(xs, xs, 30.0, 100e3), pot))
+    assert rel_l2(got, want) < 1e-5
+
+
+def test_edge_single_atom_and_out_of_box_probe_positions(ps, orc):
+    xs = np.linspace(0, 6.4, 64, endpoint=False); ys = np.linspace(0, 4.8, 48, endpoint=False)
+    zs = np.linspace(0, 1.5, 3, endpoint=False)
+    pos = np.array([[6.39, 0.01, 0.74]])
+    V = orc.potential(xs, ys, zs, pos, np.array([79]))
+    pot = ps.Potential(xs, ys, zs, pos, ["Au"])
+    assert np.abs(V - npy(pot.array)).max() / np.abs(V).max() < POT_TOL
+    pp = [(-3.0, 100.0), (6.4, 4.8), (0.0, -0.05)]                # outside the box: the ramp simply wraps
+    pr = orc.batched_probes(orc.probe_array(xs, ys, 30.0, 200e3), xs, ys, pp)
+    ex = orc.propagate(pr, V, xs, ys, zs, 200e3)
+    got = npy(ps.Propagate(ps.create_batched_probes(ps.Probe(xs, ys, 30.0, 200e3), pp), pot))
+    assert rel_l2(got, ex) < WAVE_TOL
+
+
+def test_edge_many_probes_small_grid_and_two_frames(ps, orc):
+    """900 probes on a 32^2 grid (the notebook's 30x30 STEM raster shape), T = 2 (the TACAW minimum)."""
+    from pyslice_amd.synthetic import synthetic_trajectory
+    tr = synthetic_trajectory(32, 3, 2, density=0.3, seed=8)
+    pp = ps.probe_grid([0.3, 2.9], [0.2, 3.0], 30, 30)
+    calc = ps.MultisliceCalculator(progress=False)
+    calc.setup(tr, aperture=30.0, voltage_eV=100e3, probe_positions=[tuple(p) for p in pp])
+    wf = calc.run()
+    data = npy(wf.wavefunction_data)
+    assert data.shape == (900, 2, 32, 32, 1)
+    sel = [0, 17, 449, 899]
+    want = orc.run_frames(tr.box_matrix, tr.positions, tr.atom_types, 30.0, 100e3, [tuple(pp[i]) for i in sel])["wavefunction_data"]
+    assert rel_l2(data[sel], want) < WAVE_TOL
+    tac = ps.TACAWData(wf)
+    f, inten = orc.tacaw(want, wf.time)
+    assert np.allclose(tac.frequencies, f)
+    assert rel_l2(npy(tac.intensity)[sel], inten) < TACAW_TOL
+
+
+def test_edge_bad_arguments_raise_value_errors(ps):
+    from pyslice_amd import _native
+    eng = _native.Engine(64, 64, 2, 0.1, 0.1, 0.5, 0.037, 1e-3, n_probes=2, n_frames=1)
+    with pytest.raises(ValueError):
+        eng.set_probes(30.0, [(1.0, 1.0)])                       # wrong probe count
+    with pytest.raises(ValueError):
+        eng.build_potential(np.zeros((3, 2)), np.array([5, 5, 5]))
+    eng.set_kirkland(ps.loadKirkland()); eng.set_slices(np.array([0.0, 0.25]), np.array([0.25, 1.0]))
+    with pytest.raises(ValueError):
+        eng.build_potential(np.zeros((1, 3)), np.array([0]))      # Z out of 1..103
+    with pytest.raises(RuntimeError):
+        eng.propagate()                                           # no probes / potential yet
+    with pytest.raises(ValueError):
+        eng.propagate_frame(5)
+    eng.close()

@@ -36,7 +36,7 @@ def test_g3_form_factor(golden):
         assert rel_l2(orc.form_factor(g["qsq"], int(Z)), f) < TOL
 
 
-@pytest.mark.parametrize("name", ["g4_potential_64", "g4_potential_96x80"])
+@pytest.mark.parametrize("name", ["g4_potential_64", "g4_potential_96x80", "g4_potential_axis0"])
 def test_g4_potential(golden, name):
     g = golden(name)
     xs, ys, zs, *_ = orc.grid_from_box(g["box"], 0.1, 0.5)

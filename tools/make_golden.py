@@ -127,6 +127,8 @@ def pot_case(name, box, n_atoms, seed, slice_axis=2):
 
 c64 = pot_case("g4_potential_64", np.diag([6.35, 6.35, 2.75]), 12, 11)
 c96 = pot_case("g4_potential_96x80", np.diag([9.55, 7.95, 2.25]), 16, 12)
+# slice axis 0 (quirk Q17: the two in-plane axes are painted onto the kx(xs)/ky(ys) grids)
+cax = pot_case("g4_potential_axis0", np.diag([3.15, 3.15, 2.75]), 10, 13, slice_axis=0)
 # element names instead of ints take the string branch (potentials.py:287-291): same numbers
 xs, ys, zs, pos, types, V = c64
 names = ["B" if z == 5 else "N" for z in types]
