@@ -236,9 +236,12 @@ struct ColJob {
     float scale;            // applied at the store (1/(nx ny) of a stand-alone inverse transform)
     float sigma;            // COL_POTENTIAL: t = exp(i sigma V)
     float* out_real;        // COL_POTENTIAL: optional V (same pitch / image stride as `out`)
+    int tparity;            // COL_TPOT: images whose index parity differs from this are stored transposed ...
+    float2* out_t;          // ... into this separate (n_images, ny, nx) buffer (in-place transposition would race)
 };
 // COL_POTENTIAL: epilogue of the potential build, V = Re(x)*scale, out = exp(i sigma V)  (potentials.py:336-342, multislice.py:282)
-enum { COL_FWD = 1, COL_MULPX = 2, COL_INV = 4, COL_SHIFT = 8, COL_POTENTIAL = 16 };
+// COL_TPOT (with COL_POTENTIAL): every second slice's t is stored transposed, (ny, nx), for the one-pass slice loop
+enum { COL_FWD = 1, COL_MULPX = 2, COL_INV = 4, COL_SHIFT = 8, COL_POTENTIAL = 16, COL_TPOT = 32 };
 
 // Column pass.  Workgroup = 16*R threads owns a tile of 16 neighbouring columns (128-byte row
 // segments in HBM) x N rows: staged into LDS column-major, one R-lane group per column, results
@@ -291,6 +294,7 @@ __global__ void __launch_bounds__(16 * R) col_pass_kernel(ColJob job) {
                 stage[i] = *reinterpret_cast<const float4*>(src + (long long)(r0 + ROWS_PER_IT * i) * job.in_pitch);
         }
         // ---- transform my column
+        bool tstore = false;
         {
             float2 v[R];
 #pragma unroll
@@ -302,12 +306,26 @@ __global__ void __launch_bounds__(16 * R) col_pass_kernel(ColJob job) {
             }
             if (job.flags & COL_INV) fourstep_c64<R, true>(v, mycol, tw, ln);
             wave_lds_fence();
+            const long long pimg = tile / tiles_per_image;
+            tstore = (job.flags & COL_TPOT) && (((int)pimg & 1) != job.tparity);
+            if (tstore) {
+                // transposed transmission slice: column (fixed y) is a contiguous line of the (ny, nx) image
+                const int y = (int)(tile % tiles_per_image) * 16 + grp;
+                float2* trow = job.out_t + pimg * job.out_image_stride + (long long)y * N;
 #pragma unroll
-            for (int j = 0; j < R; ++j) mycol[j * R + ln] = v[j];
+                for (int j = 0; j < R; ++j) {
+                    float sn, cs;
+                    sincosf(job.sigma * (v[j].x * job.scale), &sn, &cs);
+                    trow[j * R + ln] = make_float2(cs, sn);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < R; ++j) mycol[j * R + ln] = v[j];
+            }
         }
         lds_barrier();
         // ---- LDS -> registers -> HBM (128-byte segments)
-        {
+        if (!tstore) {
             const long long p = tile / tiles_per_image;
             const int c0 = (int)(tile % tiles_per_image) * 16;
             int cshift = c0, xshift = 0;
@@ -333,9 +351,331 @@ __global__ void __launch_bounds__(16 * R) col_pass_kernel(ColJob job) {
                         make_float4(a.x * job.scale, a.y * job.scale, b.x * job.scale, b.y * job.scale);
                 }
             }
-            lds_barrier();                      // LDS is free for the next tile's staging from here on
         }
+        lds_barrier();                          // LDS is free for the next tile's staging from here on
     }
+}
+
+// =================================================================================================
+// One-pass-per-slice kernels.  The Fresnel propagator is separable, P = Px(kx) Py(ky)
+// (multislice.py:273-275), so propagation factors into two commuting 1-D operators
+//     A_y = ifft_y Py fft_y   (row-local)        A_x = ifft_x Px fft_x   (column-local)
+// and the slice recursion psi <- A_x A_y (t_z psi) can be regrouped into passes that alternate direction,
+//     row:  A_y . t_k . A_y        column:  A_x . t_{k+1} . A_x        row:  A_y . t_{k+2} . A_y   ...
+// each pass finishing the propagation of the previous slice along its axis, applying the next
+// transmission function (pointwise, so local to any tile) and starting the next propagation.  One HBM
+// read + write of psi per slice instead of two: 16 B/pixel/slice-step.  Same arithmetic as the
+// reference up to fp32 rounding order.
+// =================================================================================================
+enum { P2_PRE_A = 1, P2_POST_A = 2, P2_POST_F = 4 };
+
+struct Row2Job {
+    float2* psi;
+    const float2* trans;    // t_k (nx, ny)
+    const float2* py;       // (ny), 1/ny folded in
+    const float2* tw;
+    long long image_stride;
+    int pitch, nx, n_images, flags, pchunk;
+};
+
+template <int R>
+__global__ void __launch_bounds__(256, 2) row_pass2_kernel(Row2Job job) {
+    constexpr int N = R * R;
+    constexpr int G = 256 / R;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float2* tw = reinterpret_cast<float2*>(smem_raw);
+    float2* pyl = tw + N;
+    float* scratch_all = reinterpret_cast<float*>(pyl + N);
+    const int tid = threadIdx.x;
+    for (int i = tid; i < N; i += 256) { tw[i] = job.tw[i]; pyl[i] = job.py[i]; }
+    __syncthreads();
+    const int grp = tid / R, ln = tid % R;
+    float* scratch = scratch_all + grp * (R * (R + 1));
+    const int xgroups = job.nx / G;
+    const int PC = job.pchunk;
+    const int pchunks = (job.n_images + PC - 1) / PC;
+    const long long n_items = (long long)xgroups * pchunks;
+    long long item = blockIdx.x;
+    int k = 0;
+    auto chunk_len = [&](long long it) { const int pc = (int)(it % pchunks); return min(PC, job.n_images - pc * PC); };
+    auto row_of = [&](long long it, int kk) {
+        const int xg = (int)(it / pchunks), pc = (int)(it % pchunks);
+        const int x = xg * G + grp;
+        return job.psi + (long long)(pc * PC + kk) * job.image_stride + (long long)x * job.pitch;
+    };
+    float2 vn[R];
+    if (item < n_items) {
+        const float2* r = row_of(item, 0);
+#pragma unroll
+        for (int j = 0; j < R; ++j) vn[j] = r[j * R + ln];
+    }
+    float2 tv[R];
+    while (item < n_items) {
+        float2 v[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) v[j] = vn[j];
+        float2* cur_row = row_of(item, k);
+        if (k == 0) {
+            const int x = (int)(item / pchunks) * G + grp;
+            const float2* trow = job.trans + (long long)x * N;
+#pragma unroll
+            for (int j = 0; j < R; ++j) tv[j] = trow[j * R + ln];
+        }
+        long long nitem = item;
+        int nk = k + 1;
+        if (nk >= chunk_len(item)) { nitem = item + gridDim.x; nk = 0; }
+        if (nitem < n_items) {
+            const float2* r = row_of(nitem, nk);
+#pragma unroll
+            for (int j = 0; j < R; ++j) vn[j] = r[j * R + ln];
+        }
+        if (job.flags & P2_PRE_A) {
+            fourstep_split<R, false>(v, scratch, tw, ln);
+            mul_table<R, 0, false>(v, pyl, ln);
+            fourstep_split<R, true>(v, scratch, tw, ln);
+        }
+#pragma unroll
+        for (int j = 0; j < R; ++j) v[j] = cmulf(v[j], tv[j]);
+        if (job.flags & P2_POST_A) {
+            fourstep_split<R, false>(v, scratch, tw, ln);
+            mul_table<R, 0, false>(v, pyl, ln);
+            fourstep_split<R, true>(v, scratch, tw, ln);
+        }
+        if (job.flags & P2_POST_F) fourstep_split<R, false>(v, scratch, tw, ln);
+#pragma unroll
+        for (int j = 0; j < R; ++j) cur_row[j * R + ln] = v[j];
+        item = nitem; k = nk;
+    }
+}
+
+struct Col2Job {
+    float2* psi;            // (P, nx, pitch), in place
+    const float2* trans;    // t_k (nx, ny), unpadded
+    const float2* px;       // (nx), 1/nx folded in
+    const float2* tw;
+    long long image_stride;
+    int pitch, ny, n_images, flags, pchunk;
+};
+
+// Column pass A_x . t . A_x.  Work item = (16-column tile, chunk of probes): the t tile is staged once per
+// item through LDS into registers (tv) and reused for every probe of the chunk.
+template <int R>
+__global__ void __launch_bounds__(16 * R) col_pass2_kernel(Col2Job job) {
+    constexpr int N = R * R;
+    constexpr int NT = 16 * R;
+    constexpr int CS = R * (R + 1) + 1;
+    constexpr int ROWS_PER_IT = NT / 8;
+    constexpr int NIT = N / ROWS_PER_IT;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float2* tw = reinterpret_cast<float2*>(smem_raw);
+    float2* px = tw + N;
+    float2* cols = px + N;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < N; i += NT) { tw[i] = job.tw[i]; px[i] = job.px[i]; }
+    const int grp = tid / R, ln = tid % R;
+    const int q = tid & 7, r0 = tid >> 3;
+    float2* mycol = cols + grp * CS;
+    const int ctiles = job.ny / 16;
+    const int PC = job.pchunk;
+    const int pchunks = (job.n_images + PC - 1) / PC;
+    const long long n_items = (long long)ctiles * pchunks;
+    auto chunk_len = [&](long long it) { const int pc = (int)(it % pchunks); return min(PC, job.n_images - pc * PC); };
+    auto tile_ptr = [&](long long it, int kk) {
+        const int ct = (int)(it / pchunks), pc = (int)(it % pchunks);
+        return job.psi + (long long)(pc * PC + kk) * job.image_stride + ct * 16 + 2 * q;
+    };
+    long long item = blockIdx.x;
+    int k = 0;
+    float4 stage[NIT];
+    if (item < n_items) {
+        const float2* src = tile_ptr(item, 0);
+#pragma unroll
+        for (int i = 0; i < NIT; ++i)
+            stage[i] = *reinterpret_cast<const float4*>(src + (long long)(r0 + ROWS_PER_IT * i) * job.pitch);
+    }
+    __syncthreads();
+    float2 tv[R];
+    while (item < n_items) {
+        if (k == 0) {
+            // transmission tile of this column block: HBM/L2 -> LDS (column-major) -> registers, once per item
+            const float2* tsrc = job.trans + (long long)(item / pchunks) * 16 + 2 * q;
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) {
+                const int x = r0 + ROWS_PER_IT * i;
+                const float4 t4 = *reinterpret_cast<const float4*>(tsrc + (long long)x * job.ny);
+                cols[(2 * q) * CS + x] = make_float2(t4.x, t4.y);
+                cols[(2 * q + 1) * CS + x] = make_float2(t4.z, t4.w);
+            }
+            lds_barrier();
+#pragma unroll
+            for (int j = 0; j < R; ++j) tv[j] = mycol[j * R + ln];
+            lds_barrier();
+        }
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int x = r0 + ROWS_PER_IT * i;
+            cols[(2 * q) * CS + x] = make_float2(stage[i].x, stage[i].y);
+            cols[(2 * q + 1) * CS + x] = make_float2(stage[i].z, stage[i].w);
+        }
+        lds_barrier();
+        float2* dst = const_cast<float2*>(tile_ptr(item, k));
+        long long nitem = item;
+        int nk = k + 1;
+        if (nk >= chunk_len(item)) { nitem = item + gridDim.x; nk = 0; }
+        if (nitem < n_items) {
+            const float2* src = tile_ptr(nitem, nk);
+#pragma unroll
+            for (int i = 0; i < NIT; ++i)
+                stage[i] = *reinterpret_cast<const float4*>(src + (long long)(r0 + ROWS_PER_IT * i) * job.pitch);
+        }
+        {
+            float2 v[R];
+#pragma unroll
+            for (int j = 0; j < R; ++j) v[j] = mycol[j * R + ln];
+            wave_lds_fence();
+            if (job.flags & P2_PRE_A) {
+                fourstep_c64<R, false>(v, mycol, tw, ln);
+                mul_table<R, 0, false>(v, px, ln);
+                fourstep_c64<R, true>(v, mycol, tw, ln);
+            }
+#pragma unroll
+            for (int j = 0; j < R; ++j) v[j] = cmulf(v[j], tv[j]);
+            if (job.flags & P2_POST_A) {
+                fourstep_c64<R, false>(v, mycol, tw, ln);
+                mul_table<R, 0, false>(v, px, ln);
+                fourstep_c64<R, true>(v, mycol, tw, ln);
+            }
+            wave_lds_fence();
+#pragma unroll
+            for (int j = 0; j < R; ++j) mycol[j * R + ln] = v[j];
+        }
+        lds_barrier();
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int x = r0 + ROWS_PER_IT * i;
+            float2 a = cols[(2 * q) * CS + x], b = cols[(2 * q + 1) * CS + x];
+            *reinterpret_cast<float4*>(dst + (long long)x * job.pitch) = make_float4(a.x, a.y, b.x, b.y);
+        }
+        lds_barrier();
+        item = nitem; k = nk;
+    }
+}
+
+// Transposing pass: lines of the input are contiguous (row-style, coalesced, prefetched in registers);
+// the result is written TRANSPOSED (out[pos][line]) through an LDS tile of 16 lines so that HBM sees
+// 128-byte segments.  The next pass then again reads contiguous lines -- of the other axis.  With this
+// kernel every slice is one pass  A_d . t_k . A_d  with t_k reused from registers across a chunk of probes.
+struct RowTJob {
+    const float2* in;       // (P, n_lines, in_pitch): lines along the transform axis
+    float2* out;            // (P, N, out_pitch): transposed
+    const float2* trans;    // t_k in the input orientation, (n_lines, N) unpadded
+    const float2* pl;       // (N) Fresnel factor along the line axis, 1/N folded in
+    const float2* tw;
+    long long in_image_stride, out_image_stride;
+    int in_pitch, out_pitch, n_lines, n_images, flags, pchunk;
+};
+
+template <int R>
+__global__ void __launch_bounds__(16 * R) rowT_pass_kernel(RowTJob job) {
+    constexpr int N = R * R;
+    constexpr int NT = 16 * R;
+    constexpr int CS = R * (R + 1) + 1;
+    constexpr int POS_PER_IT = NT / 8;               // 8 threads (16 B = 2 lines each) per 128-byte output segment
+    constexpr int NIT = N / POS_PER_IT;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float2* tw = reinterpret_cast<float2*>(smem_raw);
+    float2* pl = tw + N;
+    float2* tile = pl + N;                            // 16 * CS
+    const int tid = threadIdx.x;
+    for (int i = tid; i < N; i += NT) { tw[i] = job.tw[i]; pl[i] = job.pl[i]; }
+    __syncthreads();
+    const int grp = tid / R, ln = tid % R;
+    const int q = tid & 7, r0 = tid >> 3;
+    float2* myrow = tile + grp * CS;
+    const int lblocks = job.n_lines / 16;
+    const int PC = job.pchunk;
+    const int pchunks = (job.n_images + PC - 1) / PC;
+    const long long n_items = (long long)lblocks * pchunks;
+    auto chunk_len = [&](long long it) { const int pc = (int)(it % pchunks); return min(PC, job.n_images - pc * PC); };
+    auto line_ptr = [&](long long it, int kk) {
+        const int lb = (int)(it / pchunks), pc = (int)(it % pchunks);
+        return job.in + (long long)(pc * PC + kk) * job.in_image_stride + (long long)(lb * 16 + grp) * job.in_pitch;
+    };
+    long long item = blockIdx.x;
+    int k = 0;
+    float2 vn[R];
+    if (item < n_items) {
+        const float2* r = line_ptr(item, 0);
+#pragma unroll
+        for (int j = 0; j < R; ++j) vn[j] = r[j * R + ln];
+    }
+    float2 tv[R];
+    while (item < n_items) {
+        float2 v[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) v[j] = vn[j];
+        const int lb = (int)(item / pchunks);
+        const int p = (int)(item % pchunks) * PC + k;
+        if (k == 0) {
+            const float2* trow = job.trans + (long long)(lb * 16 + grp) * N;
+#pragma unroll
+            for (int j = 0; j < R; ++j) tv[j] = trow[j * R + ln];
+        }
+        long long nitem = item;
+        int nk = k + 1;
+        if (nk >= chunk_len(item)) { nitem = item + gridDim.x; nk = 0; }
+        if (nitem < n_items) {
+            const float2* r = line_ptr(nitem, nk);
+#pragma unroll
+            for (int j = 0; j < R; ++j) vn[j] = r[j * R + ln];
+        }
+        if (job.flags & P2_PRE_A) {
+            fourstep_split<R, false>(v, reinterpret_cast<float*>(myrow), tw, ln);
+            mul_table<R, 0, false>(v, pl, ln);
+            fourstep_split<R, true>(v, reinterpret_cast<float*>(myrow), tw, ln);
+        }
+#pragma unroll
+        for (int j = 0; j < R; ++j) v[j] = cmulf(v[j], tv[j]);
+        if (job.flags & P2_POST_A) {
+            fourstep_split<R, false>(v, reinterpret_cast<float*>(myrow), tw, ln);
+            mul_table<R, 0, false>(v, pl, ln);
+            fourstep_split<R, true>(v, reinterpret_cast<float*>(myrow), tw, ln);
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int j = 0; j < R; ++j) myrow[j * R + ln] = v[j];
+        lds_barrier();
+        // uniform 64-bit base + per-thread 32-bit element offset, re-derived every iteration (the asm keeps the
+        // compiler from hoisting 16 loop-invariant 64-bit addresses into registers for the whole kernel)
+        float2* dst = job.out + (long long)p * job.out_image_stride + lb * 16;
+        int off0 = 2 * q + r0 * job.out_pitch;
+        asm volatile("" : "+v"(off0));
+        const int ostep = POS_PER_IT * job.out_pitch;
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int pos = r0 + POS_PER_IT * i;
+            const float2 a = tile[(2 * q) * CS + pos], b = tile[(2 * q + 1) * CS + pos];
+            *reinterpret_cast<float4*>(dst + (off0 + i * ostep)) = make_float4(a.x, a.y, b.x, b.y);
+        }
+        lds_barrier();
+        item = nitem; k = nk;
+    }
+}
+
+// out[img][c][r] = in[img][r][c]  (rows x cols -> cols x rows), 32x32 tiles through LDS
+__global__ void __launch_bounds__(256) transpose_kernel(const float2* __restrict__ in, float2* __restrict__ out, int rows,
+                                                        int cols, int in_pitch, int out_pitch, long long in_is,
+                                                        long long out_is) {
+    __shared__ float2 t[32][33];
+    const float2* src = in + (long long)blockIdx.z * in_is;
+    float2* dst = out + (long long)blockIdx.z * out_is;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8)
+        if (r0 + i < rows && c0 + tx < cols) t[i][tx] = src[(long long)(r0 + i) * in_pitch + c0 + tx];
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8)
+        if (c0 + i < cols && r0 + tx < rows) dst[(long long)(c0 + i) * out_pitch + r0 + tx] = t[tx][i];
 }
 
 }  // namespace msl

@@ -55,6 +55,13 @@ struct msl_handle {
     float2* tw4_x = nullptr;
     float2* tw4_y = nullptr;
     int n_cus = 256;
+    // one-pass-per-slice path (transposing passes): second work buffer in (P, ny, nx+pad) layout, transposed
+    // probes and the transposed transmission slices
+    bool onepass = false;
+    float2* psiT = nullptr;
+    float2* psi0T = nullptr;
+    float2* transT = nullptr;
+    int pitchT = 0;
     int row_pchunk = 0;         // 0 = auto (MSL_ROW_PCHUNK)
     int row_variant = 1;        // 0: plain row kernel, 1: software-pipelined (MSL_ROW_VARIANT)
     int pitch = 0;              // row pitch (elements) of psi0/psi; > ny de-aliases the column pass's 128-byte segments
@@ -436,6 +443,123 @@ int fft2_inplace(msl_handle* h, float2* buf, int images, int dir, float scale, i
     return launch_lines(h, h->plan_x, c, K_OTHER);
 }
 
+// ---- one-pass-per-slice path ------------------------------------------------------------------------
+// psi0 (P, nx, pitch) -> psi0T (P, ny, pitchT): needed when the first pass of the slice loop runs along x
+int transpose_probes(msl_handle* h) {
+    if (!h->onepass) return MSL_OK;
+    const msl_config& c = h->cfg;
+    dim3 grid((c.ny + 31) / 32, (c.nx + 31) / 32, c.n_probes);
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, h->stream, h->psi0, h->psi0T, c.nx, c.ny, h->pitch, h->pitchT,
+                       (long long)c.nx * h->pitch, (long long)c.ny * h->pitchT);
+    HIPCHK(h, hipGetLastError());
+    return MSL_OK;
+}
+
+// slice s is used by a pass along x (needs t transposed) iff its distance to the last slice is odd
+inline bool slice_is_transposed(const msl_handle* h, int s) { return h->onepass && (((h->cfg.nz - 1 - s) & 1) != 0); }
+
+// natural t (nz,nx,ny) -> transposed copies of the odd-distance slices in transT (upload / set_beam paths)
+int transpose_odd_slices(msl_handle* h) {
+    if (!h->onepass) return MSL_OK;
+    const msl_config& c = h->cfg;
+    const size_t npix = (size_t)c.nx * c.ny;
+    for (int s = 0; s < c.nz; ++s) {
+        if (!slice_is_transposed(h, s)) continue;
+        dim3 grid((c.ny + 31) / 32, (c.nx + 31) / 32, 1);
+        hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, h->stream, h->trans + s * npix, h->transT + s * npix, c.nx, c.ny,
+                           c.ny, c.nx, (long long)npix, (long long)npix);
+    }
+    HIPCHK(h, hipGetLastError());
+    return MSL_OK;
+}
+
+template <int R>
+int launch_rowT_r(msl_handle* h, RowTJob job, int kind) {
+    constexpr int N = R * R, CS = R * (R + 1) + 1;
+    const size_t lds = ((size_t)2 * N + (size_t)16 * CS) * 8;
+    const int per_cu = std::max(1, std::min(2, (int)((size_t)h->lds_limit / lds)));
+    const long long slots = (long long)h->n_cus * per_cu;
+    const long long lb = job.n_lines / 16;
+    int pc = job.n_images;
+    while (pc > 1 && lb * ((job.n_images + pc - 1) / pc) < slots) pc = (pc + 1) / 2;
+    if (h->row_pchunk > 0) pc = std::min(h->row_pchunk, job.n_images);
+    job.pchunk = pc;
+    const long long items = lb * ((job.n_images + pc - 1) / pc);
+    const int grid = (int)std::min<long long>(items, slots);
+    hipLaunchKernelGGL(rowT_pass_kernel<R>, dim3(grid), dim3(16 * R), lds, h->stream, job);
+    HIPCHK(h, hipGetLastError());
+    return mark_launch(h, kind);
+}
+
+template <int R>
+int launch_row2_r(msl_handle* h, Row2Job job, int kind) {
+    constexpr int N = R * R, G = 256 / R;
+    const size_t lds = (size_t)N * 16 + (size_t)G * R * (R + 1) * 4;
+    const int per_cu = std::max(1, std::min(2, (int)((size_t)h->lds_limit / lds)));
+    const long long slots = (long long)h->n_cus * per_cu;
+    const long long xg = job.nx / G;
+    int pc = job.n_images;
+    while (pc > 1 && xg * ((job.n_images + pc - 1) / pc) < slots) pc = (pc + 1) / 2;
+    if (h->row_pchunk > 0) pc = std::min(h->row_pchunk, job.n_images);
+    job.pchunk = pc;
+    const long long items = xg * ((job.n_images + pc - 1) / pc);
+    const int grid = (int)std::min<long long>(items, slots);
+    hipLaunchKernelGGL(row_pass2_kernel<R>, dim3(grid), dim3(256), lds, h->stream, job);
+    HIPCHK(h, hipGetLastError());
+    return mark_launch(h, kind);
+}
+
+// Slice loop with one HBM pass per slice (see fft_pow2.h).  Pass k runs along y when its distance to the last
+// slice is even, else along x; all passes but the last write transposed, the last one is in place on layout A.
+int slice_loop_onepass(msl_handle* h, int fused_slot) {
+    const msl_config& c = h->cfg;
+    const int P = c.n_probes, nz = c.nz;
+    const size_t npix = (size_t)c.nx * c.ny;
+    const long long isA = (long long)c.nx * h->pitch, isB = (long long)c.ny * h->pitchT;
+    const bool fused = fused_slot >= 0;
+    int rc;
+    if (nz == 1)
+        HIPCHK(h, hipMemcpyAsync(h->psi, h->psi0, (size_t)P * isA * sizeof(float2), hipMemcpyDeviceToDevice, h->stream));
+    if ((rc = begin_timed(h, nz + 2))) return rc;
+    for (int k = 0; k < nz; ++k) {
+        const bool last = (k == nz - 1);
+        const int flags = (k > 0 ? P2_PRE_A : 0) | (!last ? P2_POST_A : 0) | ((last && fused) ? P2_POST_F : 0);
+        if (last) {
+            Row2Job j{};
+            j.psi = h->psi; j.trans = h->trans + (size_t)k * npix; j.py = h->pyt; j.tw = h->tw4_y;
+            j.image_stride = isA; j.pitch = h->pitch; j.nx = c.nx; j.n_images = P; j.flags = flags;
+            rc = h->Ry == 32 ? launch_row2_r<32>(h, j, K_ROW) : launch_row2_r<16>(h, j, K_ROW);
+            if (rc) return rc;
+            break;
+        }
+        const bool along_y = !slice_is_transposed(h, k);
+        RowTJob j{};
+        j.flags = flags; j.n_images = P;
+        if (along_y) {
+            j.in = (k == 0) ? h->psi0 : h->psi; j.out = h->psiT;
+            j.trans = h->trans + (size_t)k * npix; j.pl = h->pyt; j.tw = h->tw4_y;
+            j.in_image_stride = isA; j.out_image_stride = isB; j.in_pitch = h->pitch; j.out_pitch = h->pitchT; j.n_lines = c.nx;
+            rc = h->Ry == 32 ? launch_rowT_r<32>(h, j, K_ROW) : launch_rowT_r<16>(h, j, K_ROW);
+        } else {
+            j.in = (k == 0) ? h->psi0T : h->psiT; j.out = h->psi;
+            j.trans = h->transT + (size_t)k * npix; j.pl = h->pxt; j.tw = h->tw4_x;
+            j.in_image_stride = isB; j.out_image_stride = isA; j.in_pitch = h->pitchT; j.out_pitch = h->pitch; j.n_lines = c.ny;
+            rc = h->Rx == 32 ? launch_rowT_r<32>(h, j, K_COL) : launch_rowT_r<16>(h, j, K_COL);
+        }
+        if (rc) return rc;
+    }
+    if (fused) {
+        ColJob k = col_job(h, h->psi, h->wf + (size_t)fused_slot * npix, P, h->pitch, c.ny);
+        k.flags = COL_FWD | COL_SHIFT; k.out_image_stride = (long long)c.n_frames * npix;
+        if ((rc = launch_col_fast(h, k, K_OTHER))) return rc;
+    }
+    h->cur = nullptr;
+    h->ctr.slice_steps += (uint64_t)P * nz;
+    h->ctr.frames += 1;
+    h->ctr.algorithmic_bytes += (uint64_t)P * nz * 16ull * npix + (uint64_t)nz * 8ull * npix + (fused ? (uint64_t)P * 16ull * npix : 0ull);
+    return MSL_OK;
+}
+
 int ensure_atoms(msl_handle* h, size_t n) {
     if (n <= h->atom_cap) return MSL_OK;
     size_t cap = std::max<size_t>(n, h->atom_cap * 3 / 2 + 1024);
@@ -454,6 +578,7 @@ int ensure_atoms(msl_handle* h, size_t n) {
 
 // The slice loop (generic kernels).  fused_slot < 0: leave real-space exit waves in psi.
 int slice_loop(msl_handle* h, int fused_slot) {
+    if (h->onepass) return slice_loop_onepass(h, fused_slot);
     const msl_config& c = h->cfg;
     const int P = c.n_probes, nz = c.nz;
     const size_t npix = (size_t)c.nx * c.ny;
@@ -591,6 +716,21 @@ int msl_create(const msl_config* cfg, msl_handle** out) {
     }
     if ((rc = dalloc(h, &h->psi0, (size_t)cfg->nx * h->pitch * cfg->n_probes))) return bail(rc);
     if ((rc = dalloc(h, &h->psi, (size_t)cfg->nx * h->pitch * cfg->n_probes))) return bail(rc);
+    {
+        const char* e = getenv("MSL_SLICE_PATH");           // 2 = force the two-pass four-step loop
+        const bool want = cfg->fft_path == 0 && !(e && atoi(e) == 2);
+        h->onepass = want && h->Rx && h->Ry && cfg->nx % 16 == 0 && cfg->ny % 16 == 0 && !cfg->keep_potential;
+        if (h->onepass) {
+            h->pitchT = cfg->nx + (h->pitch - cfg->ny);
+            if ((rc = dalloc(h, &h->psiT, (size_t)cfg->ny * h->pitchT * cfg->n_probes))) return bail(rc);
+            if ((rc = dalloc(h, &h->psi0T, (size_t)cfg->ny * h->pitchT * cfg->n_probes))) return bail(rc);
+            if ((rc = dalloc(h, &h->transT, npix * cfg->nz))) return bail(rc);
+            (void)hipFuncSetAttribute((const void*)rowT_pass_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
+            (void)hipFuncSetAttribute((const void*)rowT_pass_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
+            (void)hipFuncSetAttribute((const void*)row_pass2_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
+            (void)hipFuncSetAttribute((const void*)row_pass2_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
+        }
+    }
     if ((rc = dalloc(h, &h->trans, npix * cfg->nz))) return bail(rc);
     if (cfg->keep_potential && (rc = dalloc(h, &h->V, npix * cfg->nz))) return bail(rc);
     if (cfg->n_frames > 0) {
@@ -619,7 +759,7 @@ int msl_destroy(msl_handle* h) {
     void* bufs[] = {h->psi0, h->psi, h->trans, h->V, h->wf, h->intensity, h->pxt, h->pyt, h->d_abcd, h->d_lo, h->d_hi,
                     h->d_pos, h->d_Z, h->d_key, h->d_order, h->d_u1, h->d_u2, h->d_ex, h->d_ey, h->d_counts, h->d_start,
                     h->d_z2s, h->d_species, h->d_ff, h->d_xy, h->plan_x.tw, h->plan_y.tw, h->plan_t.tw, h->tw4_x, h->tw4_y,
-                    h->plan_x.chirp, h->plan_x.bfilt, h->plan_y.chirp, h->plan_y.bfilt, h->plan_t.chirp, h->plan_t.bfilt};
+                    h->psiT, h->psi0T, h->transT, h->plan_x.chirp, h->plan_x.bfilt, h->plan_y.chirp, h->plan_y.bfilt, h->plan_t.chirp, h->plan_t.bfilt};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -678,6 +818,10 @@ int msl_resize_probes(msl_handle* h, int32_t n_probes) {
     int rc;
     if ((rc = dalloc(h, &h->psi0, (size_t)h->cfg.nx * h->pitch * n_probes))) return rc;
     if ((rc = dalloc(h, &h->psi, (size_t)h->cfg.nx * h->pitch * n_probes))) return rc;
+    if (h->onepass) {
+        if ((rc = dalloc(h, &h->psiT, (size_t)h->cfg.ny * h->pitchT * n_probes))) return rc;
+        if ((rc = dalloc(h, &h->psi0T, (size_t)h->cfg.ny * h->pitchT * n_probes))) return rc;
+    }
     if ((rc = dalloc(h, &h->d_xy, (size_t)2 * n_probes))) return rc;
     h->cfg.n_probes = n_probes;
     h->have_probes = false; h->have_exit = false;
@@ -704,6 +848,7 @@ int msl_shift_probes(msl_handle* h, const float* base, const double* xy, int32_t
         if (hipGetLastError() != hipSuccess) rc = fail(h, MSL_ERR_HIP, "probe_ramp_kernel launch failed");
     }
     if (rc == MSL_OK) rc = fft2_inplace(h, h->psi0, n_probes, -1, 1.0f / ((float)c.nx * (float)c.ny), h->pitch);
+    if (rc == MSL_OK) rc = transpose_probes(h);
     hipError_t e = hipStreamSynchronize(h->stream);
     (void)hipFree(bk);
     if (rc) return rc;
@@ -727,6 +872,7 @@ int msl_set_probes(msl_handle* h, double mrad, const double* xy, int32_t n_probe
     HIPCHK(h, hipGetLastError());
     int rc = fft2_inplace(h, h->psi0, n_probes, -1, 1.0f / ((float)c.nx * (float)c.ny), h->pitch);
     if (rc) return rc;
+    if ((rc = transpose_probes(h))) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->have_probes = true;
     return MSL_OK;
@@ -738,6 +884,7 @@ int msl_upload_probes(msl_handle* h, const float* c64, int32_t n_probes) {
     HIPCHK(h, hipSetDevice(h->cfg.device));
     HIPCHK(h, hipMemcpy2DAsync(h->psi0, (size_t)h->pitch * sizeof(float2), c64, (size_t)h->cfg.ny * sizeof(float2),
                                (size_t)h->cfg.ny * sizeof(float2), (size_t)n_probes * h->cfg.nx, hipMemcpyHostToDevice, h->stream));
+    { int rc = transpose_probes(h); if (rc) return rc; }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->have_probes = true;
     return MSL_OK;
@@ -832,6 +979,7 @@ int msl_build_potential(msl_handle* h, const double* pos, const int32_t* Z, int6
     if (h->Rx) {
         ColJob k = col_job(h, h->trans, h->trans, c.nz, c.ny, c.ny);
         k.flags = COL_INV | COL_POTENTIAL; k.scale = vscale; k.sigma = (float)c.sigma; k.out_real = h->V;
+        if (h->onepass) { k.flags |= COL_TPOT; k.tparity = (c.nz - 1) & 1; k.out_t = h->transT; }
         if ((rc = launch_col_fast(h, k, K_OTHER))) return rc;
     } else {
         LineArgs k = col_args(h, h->trans, h->trans, c.nz, c.ny, c.ny);
@@ -862,6 +1010,7 @@ int msl_upload_potential(msl_handle* h, const float* V) {
     hipLaunchKernelGGL(transmission_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->trans, dst, (long long)n,
                        (float)c.sigma);
     HIPCHK(h, hipGetLastError());
+    { int rc = transpose_odd_slices(h); if (rc) return rc; }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (tmp) (void)hipFree(tmp);
     h->have_potential = true;
@@ -979,6 +1128,17 @@ int msl_download(msl_handle* h, msl_buffer what, void* dst, size_t bytes, int64_
     size_t total = msl_buffer_bytes(h, what);
     if (!src || total == 0) return fail(h, MSL_ERR_STATE, "msl_download: buffer %d not available", (int)what);
     if (what == MSL_BUF_EXIT && !h->have_exit) return fail(h, MSL_ERR_STATE, "msl_download: no exit waves (call msl_propagate)");
+    if (what == MSL_BUF_TRANSMISSION && h->onepass && h->have_potential) {
+        // the one-pass loop keeps every second slice transposed in its own buffer: restore the natural copies
+        const size_t npix = (size_t)h->cfg.nx * h->cfg.ny;
+        for (int s = 0; s < h->cfg.nz; ++s) {
+            if (!slice_is_transposed(h, s)) continue;
+            dim3 grid((h->cfg.nx + 31) / 32, (h->cfg.ny + 31) / 32, 1);
+            hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, h->stream, h->transT + s * npix, h->trans + s * npix,
+                               h->cfg.ny, h->cfg.nx, h->cfg.nx, h->cfg.ny, (long long)npix, (long long)npix);
+        }
+        HIPCHK(h, hipGetLastError());
+    }
     size_t off = 0, len = total;
     if (count > 0) {
         if (what != MSL_BUF_WAVEFUNCTION && what != MSL_BUF_INTENSITY)

@@ -266,6 +266,29 @@ def test_oracle_parity_midsize(ps, orc, n, nz, P, mrad):
     assert ref_residual(gex, ex) < RESID_TOL
 
 
+@pytest.mark.parametrize("n,nz,P", [(256, 7, 3), (256, 8, 2), (256, 1, 2), (256, 2, 1)])
+def test_calculator_oracle_parity_onepass(ps, orc, n, nz, P):
+    """MultisliceCalculator on a four-step grid takes the one-pass-per-slice loop (alternating transposing passes);
+    odd and even slice counts start along different axes, nz = 1 and 2 are the degenerate cases."""
+    from pyslice_amd.synthetic import synthetic_trajectory
+    from pyslice_amd import _native
+    tr = synthetic_trajectory(n, nz, 2, density=0.05, seed=21 + nz)
+    lx, ly = tr.box_matrix[0, 0], tr.box_matrix[1, 1]
+    pp = [tuple(v) for v in np.random.default_rng(3).random((P, 2)) * [lx, ly]]
+    calc = ps.MultisliceCalculator(progress=False)
+    calc.setup(tr, aperture=30.0, voltage_eV=100e3, probe_positions=pp)
+    wf = calc.run()
+    want = orc.run_frames(tr.box_matrix, tr.positions, tr.atom_types, 30.0, 100e3, pp)["wavefunction_data"]
+    got = npy(wf.wavefunction_data)
+    assert rel_l2(got, want) < WAVE_TOL
+    assert ref_residual(got, want) < RESID_TOL
+    # the transmission functions come back in natural orientation whatever the internal layout
+    t = calc._engine.download(_native.BUF_TRANSMISSION, np.complex64, (calc.nz, n, n))
+    xs, ys, zs, *_ = orc.grid_from_box(tr.box_matrix)
+    V = orc.potential(xs, ys, zs, tr.positions[-1], tr.atom_types)
+    assert rel_l2(t, np.exp(1j * orc.interaction_sigma(100e3) * np.moveaxis(V, 2, 0))) < 1e-4
+
+
 def test_oracle_parity_prime_grid(ps, orc):
     """Grid lengths with large prime factors (101 x 97, like the reference's 501 x 491 probe test grid) take the
     Bluestein path; potential, probes and slice loop must still match the oracle."""
