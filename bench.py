@@ -142,23 +142,34 @@ def main():
         npix = n * n
         steps_total = world * a.steps * P * nz
         value = steps_total / dt
-        # dominant slice-loop kernel (row pass or column pass): each launch streams P wave functions once,
-        # 8 B read + 8 B write per pixel = 16 B x nx x ny x P algorithmic bytes (32 B/slice-step = 2 passes)
+        # Slice-loop kernels.  Every launch streams the P wave functions of the frame once: 8 B read + 8 B write per
+        # pixel = 16 B x nx x ny x P algorithmic bytes per launch.  The default one-pass loop needs ONE
+        # such launch per slice (16 B/pixel/slice-step: the separable Fresnel propagator lets a pass finish one
+        # propagation and start the next); the two-pass loop (MSL_SLICE_PATH=2) needs two (SURVEY 8d's 32 B).
         rows, cols = (ctr["row_launches"], ctr["ms_row"]), (ctr["col_launches"], ctr["ms_col"])
-        name, (cnt, ms) = max((("row_pass", rows), ("col_pass", cols)), key=lambda kv: kv[1][1])
+        name, (cnt, ms) = max((("pass_along_y", rows), ("pass_along_x", cols)), key=lambda kv: kv[1][1])
         bytes_per_launch = 16.0 * npix * P
+        passes_per_slice = (rows[0] + cols[0]) / float(a.steps * nz) if nz else 0.0
         roof = None
         if cnt:
             avg_s = ms * 1e-3 / cnt
             ach = bytes_per_launch / avg_s / 1e9
+            traffic = None
+            tpath = os.path.join(REPO, "profiles", "pmc_traffic_current.json")
+            if os.path.exists(tpath):
+                tj = json.load(open(tpath))
+                if tj.get("grid") == n and tj.get("probes") == P and round(passes_per_slice) == tj.get("passes_per_slice"):
+                    traffic = tj.get("hbm_bytes_per_launch")
             roof = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "avg_launch_us": round(avg_s * 1e6, 2), "launches": int(cnt),
-                    "row_pass_GBps": round(bytes_per_launch * rows[0] / (rows[1] * 1e-3) / 1e9, 1) if rows[1] else None,
-                    "col_pass_GBps": round(bytes_per_launch * cols[0] / (cols[1] * 1e-3) / 1e9, 1) if cols[1] else None,
                     "algorithmic_bytes_per_launch": bytes_per_launch,
-                    "slice_loop_GBps_both_passes": round(32.0 * npix * P * nz * a.steps / (ctr["ms_slice_kernels"] * 1e-3) / 1e9, 1)
-                    if ctr["ms_slice_kernels"] else None}
+                    "passes_per_slice": round(passes_per_slice, 3),
+                    "pass_along_y_GBps": round(bytes_per_launch * rows[0] / (rows[1] * 1e-3) / 1e9, 1) if rows[1] else None,
+                    "pass_along_x_GBps": round(bytes_per_launch * cols[0] / (cols[1] * 1e-3) / 1e9, 1) if cols[1] else None,
+                    "slice_loop_GBps_on_32B_per_slice_step_basis":
+                        round(32.0 * npix * P * nz * a.steps / (ctr["ms_slice_kernels"] * 1e-3) / 1e9, 1)
+                        if ctr["ms_slice_kernels"] else None}
         out = {
             "metric": "slice-steps/sec (probes x frames x slices / s), potential + slice loop + exit FFT",
             "value": round(value, 1), "unit": "slice-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,

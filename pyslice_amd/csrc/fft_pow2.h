@@ -575,31 +575,34 @@ struct RowTJob {
     int in_pitch, out_pitch, n_lines, n_images, flags, pchunk;
 };
 
-template <int R>
-__global__ void __launch_bounds__(16 * R) rowT_pass_kernel(RowTJob job) {
+template <int R, int LINES, bool C64>
+__global__ void __launch_bounds__(LINES * R) rowT_pass_kernel(RowTJob job) {
     constexpr int N = R * R;
-    constexpr int NT = 16 * R;
+    constexpr int NT = LINES * R;
     constexpr int CS = R * (R + 1) + 1;
-    constexpr int POS_PER_IT = NT / 8;               // 8 threads (16 B = 2 lines each) per 128-byte output segment
+    constexpr int TPS = LINES / 2;                    // threads (16 B = 2 lines each) per output segment of LINES*8 bytes
+    constexpr int POS_PER_IT = NT / TPS;
     constexpr int NIT = N / POS_PER_IT;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr bool PL_LDS = (LINES == 16);            // 8-line tiles: Fresnel table from L1/L2 so two workgroups fit a CU
     float2* tw = reinterpret_cast<float2*>(smem_raw);
-    float2* pl = tw + N;
-    float2* tile = pl + N;                            // 16 * CS
+    float2* pl_lds = tw + N;
+    float2* tile = PL_LDS ? pl_lds + N : pl_lds;      // LINES * CS
     const int tid = threadIdx.x;
-    for (int i = tid; i < N; i += NT) { tw[i] = job.tw[i]; pl[i] = job.pl[i]; }
+    for (int i = tid; i < N; i += NT) { tw[i] = job.tw[i]; if (PL_LDS) pl_lds[i] = job.pl[i]; }
+    const float2* pl = PL_LDS ? pl_lds : job.pl;
     __syncthreads();
     const int grp = tid / R, ln = tid % R;
-    const int q = tid & 7, r0 = tid >> 3;
+    const int q = tid % TPS, r0 = tid / TPS;
     float2* myrow = tile + grp * CS;
-    const int lblocks = job.n_lines / 16;
+    const int lblocks = job.n_lines / LINES;
     const int PC = job.pchunk;
     const int pchunks = (job.n_images + PC - 1) / PC;
     const long long n_items = (long long)lblocks * pchunks;
     auto chunk_len = [&](long long it) { const int pc = (int)(it % pchunks); return min(PC, job.n_images - pc * PC); };
     auto line_ptr = [&](long long it, int kk) {
         const int lb = (int)(it / pchunks), pc = (int)(it % pchunks);
-        return job.in + (long long)(pc * PC + kk) * job.in_image_stride + (long long)(lb * 16 + grp) * job.in_pitch;
+        return job.in + (long long)(pc * PC + kk) * job.in_image_stride + (long long)(lb * LINES + grp) * job.in_pitch;
     };
     long long item = blockIdx.x;
     int k = 0;
@@ -617,7 +620,7 @@ __global__ void __launch_bounds__(16 * R) rowT_pass_kernel(RowTJob job) {
         const int lb = (int)(item / pchunks);
         const int p = (int)(item % pchunks) * PC + k;
         if (k == 0) {
-            const float2* trow = job.trans + (long long)(lb * 16 + grp) * N;
+            const float2* trow = job.trans + (long long)(lb * LINES + grp) * N;
 #pragma unroll
             for (int j = 0; j < R; ++j) tv[j] = trow[j * R + ln];
         }
@@ -630,16 +633,16 @@ __global__ void __launch_bounds__(16 * R) rowT_pass_kernel(RowTJob job) {
             for (int j = 0; j < R; ++j) vn[j] = r[j * R + ln];
         }
         if (job.flags & P2_PRE_A) {
-            fourstep_split<R, false>(v, reinterpret_cast<float*>(myrow), tw, ln);
+            if constexpr (C64) fourstep_c64<R, false>(v, myrow, tw, ln); else fourstep_split<R, false>(v, reinterpret_cast<float*>(myrow), tw, ln);
             mul_table<R, 0, false>(v, pl, ln);
-            fourstep_split<R, true>(v, reinterpret_cast<float*>(myrow), tw, ln);
+            if constexpr (C64) fourstep_c64<R, true>(v, myrow, tw, ln); else fourstep_split<R, true>(v, reinterpret_cast<float*>(myrow), tw, ln);
         }
 #pragma unroll
         for (int j = 0; j < R; ++j) v[j] = cmulf(v[j], tv[j]);
         if (job.flags & P2_POST_A) {
-            fourstep_split<R, false>(v, reinterpret_cast<float*>(myrow), tw, ln);
+            if constexpr (C64) fourstep_c64<R, false>(v, myrow, tw, ln); else fourstep_split<R, false>(v, reinterpret_cast<float*>(myrow), tw, ln);
             mul_table<R, 0, false>(v, pl, ln);
-            fourstep_split<R, true>(v, reinterpret_cast<float*>(myrow), tw, ln);
+            if constexpr (C64) fourstep_c64<R, true>(v, myrow, tw, ln); else fourstep_split<R, true>(v, reinterpret_cast<float*>(myrow), tw, ln);
         }
         wave_lds_fence();
 #pragma unroll
@@ -647,7 +650,7 @@ __global__ void __launch_bounds__(16 * R) rowT_pass_kernel(RowTJob job) {
         lds_barrier();
         // uniform 64-bit base + per-thread 32-bit element offset, re-derived every iteration (the asm keeps the
         // compiler from hoisting 16 loop-invariant 64-bit addresses into registers for the whole kernel)
-        float2* dst = job.out + (long long)p * job.out_image_stride + lb * 16;
+        float2* dst = job.out + (long long)p * job.out_image_stride + lb * LINES;
         int off0 = 2 * q + r0 * job.out_pitch;
         asm volatile("" : "+v"(off0));
         const int ostep = POS_PER_IT * job.out_pitch;

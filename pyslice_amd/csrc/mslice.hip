@@ -62,6 +62,8 @@ struct msl_handle {
     float2* psi0T = nullptr;
     float2* transT = nullptr;
     int pitchT = 0;
+    int rowT_variant = 0;
+    int debug_flags_mask = -1;
     int row_pchunk = 0;         // 0 = auto (MSL_ROW_PCHUNK)
     int row_variant = 1;        // 0: plain row kernel, 1: software-pipelined (MSL_ROW_VARIANT)
     int pitch = 0;              // row pitch (elements) of psi0/psi; > ny de-aliases the column pass's 128-byte segments
@@ -473,22 +475,35 @@ int transpose_odd_slices(msl_handle* h) {
     return MSL_OK;
 }
 
-template <int R>
-int launch_rowT_r(msl_handle* h, RowTJob job, int kind) {
+template <int R, int LINES, bool C64>
+int launch_rowT_v(msl_handle* h, RowTJob job, int kind) {
     constexpr int N = R * R, CS = R * (R + 1) + 1;
-    const size_t lds = ((size_t)2 * N + (size_t)16 * CS) * 8;
+    const size_t lds = ((size_t)(LINES == 16 ? 2 : 1) * N + (size_t)LINES * CS) * 8;
     const int per_cu = std::max(1, std::min(2, (int)((size_t)h->lds_limit / lds)));
     const long long slots = (long long)h->n_cus * per_cu;
-    const long long lb = job.n_lines / 16;
+    const long long lb = job.n_lines / LINES;
     int pc = job.n_images;
     while (pc > 1 && lb * ((job.n_images + pc - 1) / pc) < slots) pc = (pc + 1) / 2;
     if (h->row_pchunk > 0) pc = std::min(h->row_pchunk, job.n_images);
     job.pchunk = pc;
     const long long items = lb * ((job.n_images + pc - 1) / pc);
     const int grid = (int)std::min<long long>(items, slots);
-    hipLaunchKernelGGL(rowT_pass_kernel<R>, dim3(grid), dim3(16 * R), lds, h->stream, job);
+    (void)hipFuncSetAttribute((const void*)rowT_pass_kernel<R, LINES, C64>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
+    hipLaunchKernelGGL((rowT_pass_kernel<R, LINES, C64>), dim3(grid), dim3(LINES * R), lds, h->stream, job);
     HIPCHK(h, hipGetLastError());
     return mark_launch(h, kind);
+}
+
+// variant selection (MSL_ROWT_VARIANT): 0 = 16 lines / split transposes, 1 = 16 lines / complex transposes,
+// 2 = 8 lines / split, 3 = 8 lines / complex
+template <int R>
+int launch_rowT_r(msl_handle* h, RowTJob job, int kind) {
+    switch (h->rowT_variant) {
+        case 1: return launch_rowT_v<R, 16, true>(h, job, kind);
+        case 2: return launch_rowT_v<R, 8, false>(h, job, kind);
+        case 3: return launch_rowT_v<R, 8, true>(h, job, kind);
+        default: return launch_rowT_v<R, 16, false>(h, job, kind);
+    }
 }
 
 template <int R>
@@ -523,7 +538,8 @@ int slice_loop_onepass(msl_handle* h, int fused_slot) {
     if ((rc = begin_timed(h, nz + 2))) return rc;
     for (int k = 0; k < nz; ++k) {
         const bool last = (k == nz - 1);
-        const int flags = (k > 0 ? P2_PRE_A : 0) | (!last ? P2_POST_A : 0) | ((last && fused) ? P2_POST_F : 0);
+        int flags = (k > 0 ? P2_PRE_A : 0) | (!last ? P2_POST_A : 0) | ((last && fused) ? P2_POST_F : 0);
+        if (h->debug_flags_mask >= 0) flags &= h->debug_flags_mask;     // timing experiments only (MSL_DEBUG_FLAGS_MASK)
         if (last) {
             Row2Job j{};
             j.psi = h->psi; j.trans = h->trans + (size_t)k * npix; j.py = h->pyt; j.tw = h->tw4_y;
@@ -725,8 +741,8 @@ int msl_create(const msl_config* cfg, msl_handle** out) {
             if ((rc = dalloc(h, &h->psiT, (size_t)cfg->ny * h->pitchT * cfg->n_probes))) return bail(rc);
             if ((rc = dalloc(h, &h->psi0T, (size_t)cfg->ny * h->pitchT * cfg->n_probes))) return bail(rc);
             if ((rc = dalloc(h, &h->transT, npix * cfg->nz))) return bail(rc);
-            (void)hipFuncSetAttribute((const void*)rowT_pass_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
-            (void)hipFuncSetAttribute((const void*)rowT_pass_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
+            { const char* ev = getenv("MSL_ROWT_VARIANT"); if (ev) h->rowT_variant = atoi(ev); }
+            { const char* ev = getenv("MSL_DEBUG_FLAGS_MASK"); if (ev) h->debug_flags_mask = atoi(ev); }
             (void)hipFuncSetAttribute((const void*)row_pass2_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
             (void)hipFuncSetAttribute((const void*)row_pass2_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
         }

@@ -289,6 +289,22 @@ def test_calculator_oracle_parity_onepass(ps, orc, n, nz, P):
     assert rel_l2(t, np.exp(1j * orc.interaction_sigma(100e3) * np.moveaxis(V, 2, 0))) < 1e-4
 
 
+def test_calculator_oracle_parity_onepass_nonsquare(ps, orc):
+    """256 x 1024 grid: the transposing passes alternate between the R=16 (x lines) and R=32 (y lines) kernels."""
+    from pyslice_amd.synthetic import synthetic_trajectory
+    tr = synthetic_trajectory(256, 6, 1, ny=1024, density=0.03, seed=31)
+    xs, ys, zs, lx, ly, lz = ps.gridFromTrajectory(tr)
+    assert (len(xs), len(ys), len(zs)) == (256, 1024, 6)
+    pp = [(lx / 2, ly / 2), (3.3, 70.1), (20.0, 5.0)]
+    calc = ps.MultisliceCalculator(progress=False)
+    calc.setup(tr, aperture=30.0, voltage_eV=100e3, probe_positions=pp)
+    assert calc._engine is not None
+    got = npy(calc.run().wavefunction_data)
+    want = orc.run_frames(tr.box_matrix, tr.positions, tr.atom_types, 30.0, 100e3, pp)["wavefunction_data"]
+    assert rel_l2(got, want) < WAVE_TOL
+    assert ref_residual(got, want) < RESID_TOL
+
+
 def test_oracle_parity_prime_grid(ps, orc):
     """Grid lengths with large prime factors (101 x 97, like the reference's 501 x 491 probe test grid) take the
     Bluestein path; potential, probes and slice loop must still match the oracle."""
