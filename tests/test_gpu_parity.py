@@ -448,3 +448,41 @@ def test_edge_bad_arguments_raise_value_errors(ps):
     with pytest.raises(ValueError):
         eng.propagate_frame(5)
     eng.close()
+
+
+# ------------------------------------------------------------------ BASELINE configs / domain known answers
+def test_config_c2_shape_512_100slices_64frames(ps, orc):
+    """BASELINE configs[1]: single probe, 64 MD frames, 512^2 grid, 100 slices on one GPU.  All 64 frames run on the
+    device; the last frame is validated against the oracle at full atom density (the oracle needs ~15 s per frame)."""
+    from pyslice_amd.synthetic import synthetic_trajectory
+    tr = synthetic_trajectory(512, 100, 64, seed=2)
+    calc = ps.MultisliceCalculator(progress=False, dtype="complex64")
+    calc.setup(tr, aperture=30.0, voltage_eV=100e3)
+    assert (calc.nx, calc.ny, calc.nz, calc.n_probes, calc.n_frames) == (512, 512, 100, 1, 64)
+    wf = calc.run()
+    data = npy(wf.wavefunction_data)
+    assert data.shape == (1, 64, 512, 512, 1)
+    want = orc.run_frames(tr.box_matrix, tr.positions, tr.atom_types, 30.0, 100e3, frames=[63])["wavefunction_data"]
+    assert rel_l2(data[:, 63:64], want) < WAVE_TOL
+    assert ref_residual(data[:, 63:64], want) < RESID_TOL
+    # frames differ (the atoms move) but every frame conserves the norm (K2)
+    norms = (np.abs(data[0, :, :, :, 0].astype(np.complex128)) ** 2).sum(axis=(1, 2))
+    assert np.allclose(norms, norms[0], rtol=2e-4)
+    assert rel_l2(data[0, 0], data[0, 32]) > 1e-3
+
+
+def test_k5_tacaw_peaks_at_phonon_frequencies(ps):
+    """K5: atoms oscillating at 10/25/40 THz (pyslice_amd.synthetic) put the TACAW spectrum's weight into the
+    +-10, +-25, +-40 THz bins and nothing into the DC bin."""
+    from pyslice_amd.synthetic import synthetic_trajectory
+    tr = synthetic_trajectory(64, 4, 40, density=0.25, seed=5)         # T*dt = 0.2 ps -> 5 THz bins
+    calc = ps.MultisliceCalculator(progress=False)
+    calc.setup(tr, aperture=0.0, voltage_eV=100e3)
+    tac = ps.TACAWData(calc.run())
+    f = tac.frequencies
+    spec = tac.spectrum(0)
+    assert np.isclose(f[1] - f[0], 5.0)
+    on = np.isin(np.round(np.abs(f)).astype(int), [10, 25, 40])
+    assert spec[np.argmin(np.abs(f))] == 0.0
+    assert spec[on].sum() > 0.8 * spec.sum()          # the rest is multi-phonon (sum and difference) weight
+    assert spec[on].min() > 20 * np.median(spec[~on])
