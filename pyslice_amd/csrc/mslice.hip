@@ -939,7 +939,7 @@ int msl_build_potential(msl_handle* h, const double* pos, const int32_t* Z, int6
     if ((rc = dalloc(h, &h->d_start, (size_t)nkeys + 1))) return rc;
     if ((rc = ensure_atoms(h, (size_t)n))) return rc;
     HIPCHK(h, hipMemsetAsync(h->d_counts, 0, ((size_t)nkeys + 1) * sizeof(int), h->stream));
-    HIPCHK(h, hipMemsetAsync(h->trans, 0, npix * c.nz * sizeof(float2), h->stream));
+    bool recip_written = false;     // the structure-factor kernels write every bin of R_s; zero-fill only when none runs
     if (n > 0 && nsp > 0) {
         HIPCHK(h, hipMemcpyAsync(h->d_z2s, z2s, sizeof z2s, hipMemcpyHostToDevice, h->stream));
         HIPCHK(h, hipMemcpyAsync(h->d_species, species, nsp * sizeof(int), hipMemcpyHostToDevice, h->stream));
@@ -959,6 +959,7 @@ int msl_build_potential(msl_handle* h, const double* pos, const int32_t* Z, int6
         HIPCHK(h, hipMemcpyAsync(&n_sorted, h->d_start + nkeys, sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
         if (n_sorted > 0) {
+            recip_written = true;
             long long tx = (long long)n_sorted * c.nx, ty = (long long)n_sorted * c.ny;
             hipLaunchKernelGGL(phase_table_kernel, dim3((unsigned)((tx + 255) / 256)), dim3(256), 0, h->stream, h->d_ex, h->d_u1,
                                h->d_order, n_sorted, c.nx);
@@ -967,8 +968,16 @@ int msl_build_potential(msl_handle* h, const double* pos, const int32_t* Z, int6
             const int tiles_y = (c.ny + SF_TILE - 1) / SF_TILE;
             const bool hermitian = (c.nx % (2 * SF_TILE) == 0) && (c.ny % 2 == 0) && !getenv("MSL_NO_HERMITIAN");
             const int tiles_x = hermitian ? c.nx / 2 / SF_TILE : (c.nx + SF_TILE - 1) / SF_TILE;
-            hipLaunchKernelGGL(structure_factor_kernel, dim3(tiles_x * tiles_y, c.nz), dim3(256), 0, h->stream, h->trans, h->d_ex,
-                               h->d_ey, h->d_ff, h->d_start, nsp, c.nx, c.ny, tiles_y);
+            // matrix-core variant: whole 32x32 tiles only (rows kx < nx/2 of the Hermitian path, ny % 32 == 0)
+            const bool use_mfma = hermitian && (c.ny % 32 == 0) && !getenv("MSL_NO_MFMA");
+            if (use_mfma) {
+                const int ty32 = c.ny / 32, n_tiles = (c.nx / 2 / 32) * ty32;
+                hipLaunchKernelGGL(structure_factor_mfma_kernel, dim3((n_tiles + 3) / 4, c.nz), dim3(256), 0, h->stream, h->trans,
+                                   h->d_ex, h->d_ey, h->d_ff, h->d_start, nsp, c.nx, c.ny, ty32, n_tiles);
+            } else {
+                hipLaunchKernelGGL(structure_factor_kernel, dim3(tiles_x * tiles_y, c.nz), dim3(256), 0, h->stream, h->trans, h->d_ex,
+                                   h->d_ey, h->d_ff, h->d_start, nsp, c.nx, c.ny, tiles_y);
+            }
             if (hermitian) {
                 const int nb = c.ny + c.nx / 2 - 1;
                 hipLaunchKernelGGL(structure_factor_nyquist_kernel, dim3((nb + 127) / 128, c.nz), dim3(128), 0, h->stream, h->trans,
@@ -979,6 +988,7 @@ int msl_build_potential(msl_handle* h, const double* pos, const int32_t* Z, int6
             HIPCHK(h, hipGetLastError());
         }
     }
+    if (!recip_written) HIPCHK(h, hipMemsetAsync(h->trans, 0, npix * c.nz * sizeof(float2), h->stream));
     h->n_species = nsp;
     // V_s = Re ifft2(R_s) / (dx^2 dy^2);  t_s = exp(i sigma V_s)  -- in place over the (nz,nx,ny) buffer
     const float vscale = (float)(1.0 / ((double)c.nx * c.ny) / (c.dx * c.dx * c.dy * c.dy));

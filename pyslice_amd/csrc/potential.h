@@ -188,6 +188,65 @@ __global__ void __launch_bounds__(256) structure_factor_kernel(float2* __restric
     }
 }
 
+// The same accumulation on the matrix cores.  S = sum_a ex_a (x) ey_a is a complex GEMM with a short inner
+// dimension (atoms of one species in one slice); gfx950's exact-f32 MFMA (v_mfma_f32_32x32x2_f32) runs at twice the
+// rate a scalar-f32 VALU kernel reaches (77 TFLOP/s measured, tools/valubench.hip; the VALU kernel above sits at 72).
+// One wave owns a 32 x 32 output tile: A[i][k] = ex[atom k][kx0+i], B[k][j] = ey[atom k][ky0+j], two atoms per
+// instruction (lanes 0-31 / 32-63), four real MFMAs per complex product, Re/Im accumulators 2 x 16 VGPRs.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+__global__ void __launch_bounds__(256) structure_factor_mfma_kernel(float2* __restrict__ recip,
+                                                                    const float2* __restrict__ ex,
+                                                                    const float2* __restrict__ ey,
+                                                                    const float* __restrict__ ff,
+                                                                    const int* __restrict__ start, int n_species,
+                                                                    int nx, int ny, int tiles_y, int n_tiles) {
+    const int s = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= n_tiles) return;
+    const int kx0 = (tile / tiles_y) * 32, ky0 = (tile % tiles_y) * 32;
+    const int i = lane & 31, kk = lane >> 5;
+    f32x16 tot_re = {0}, tot_im = {0};
+    for (int sp = 0; sp < n_species; ++sp) {
+        const int a0 = start[s * n_species + sp], a1 = start[s * n_species + sp + 1];
+        if (a0 == a1) continue;
+        f32x16 acc_re = {0}, acc_im = {0};
+        const float2* px = ex + (size_t)(a0 + kk) * nx + kx0 + i;
+        const float2* py = ey + (size_t)(a0 + kk) * ny + ky0 + i;
+        // 8 atoms (4 MFMA k-steps) per trip: all eight loads are issued before the sixteen MFMAs consume them
+        for (int a = a0 + kk; a < a1 + kk; a += 8) {           // same trip count for both lane halves
+            float2 x[4], y[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                x[u] = make_float2(0.f, 0.f); y[u] = make_float2(0.f, 0.f);
+                if (a + 2 * u < a1) { x[u] = px[(size_t)(2 * u) * nx]; y[u] = py[(size_t)(2 * u) * ny]; }
+            }
+            px += 8 * (size_t)nx; py += 8 * (size_t)ny;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc_re = __builtin_amdgcn_mfma_f32_32x32x2f32(x[u].x, y[u].x, acc_re, 0, 0, 0);
+                acc_im = __builtin_amdgcn_mfma_f32_32x32x2f32(x[u].x, y[u].y, acc_im, 0, 0, 0);
+                acc_re = __builtin_amdgcn_mfma_f32_32x32x2f32(-x[u].y, y[u].y, acc_re, 0, 0, 0);
+                acc_im = __builtin_amdgcn_mfma_f32_32x32x2f32(x[u].y, y[u].x, acc_im, 0, 0, 0);
+            }
+        }
+        const float* f = ff + (size_t)sp * nx * ny;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;      // C/D layout of the 32x32 MFMA
+            const float w = f[(size_t)(kx0 + row) * ny + ky0 + i];
+            tot_re[r] = fmaf(w, acc_re[r], tot_re[r]);
+            tot_im[r] = fmaf(w, acc_im[r], tot_im[r]);
+        }
+    }
+    float2* out = recip + (size_t)s * nx * ny;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
+        out[(size_t)(kx0 + row) * ny + ky0 + i] = make_float2(tot_re[r], tot_im[r]);
+    }
+}
+
 // Hermitian shortcut for even nx, ny: R_s[-k] = conj(R_s[k]) for every bin that has a mirror partner.  The tile
 // kernel then only computes rows mx < nx/2; this kernel adds the bins without a partner -- the Nyquist row
 // mx = nx/2 (all my) and the Nyquist column my = ny/2 of the rows mx > nx/2 -- by direct summation.
