@@ -82,9 +82,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     import torch.distributed as dist
+    backend = os.environ.get("MSL_BENCH_BACKEND", "nccl")      # "gloo": rehearsal of the N>1 path on fewer GPUs than ranks
+    n_dev = max(1, torch.cuda.device_count())
+    if backend == "gloo":
+        local_rank = local_rank % n_dev
     if world > 1:
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     if world != a.gpus and rank == 0:
         print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
@@ -128,7 +135,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ctr = eng.counters()

@@ -44,12 +44,21 @@ def shard_frames(n_frames: int, world: int, rank: int) -> List[int]:
 
 
 def _as_real(t):
-    """Collectives move real views (gloo has no complex support; RCCL moves bytes either way)."""
-    return (torch.view_as_real(t), True) if t.is_complex() else (t, False)
+    """Collectives move real views (gloo has no complex support; RCCL moves bytes either way).  Under gloo (CPU
+    rehearsal of the multi-process path, possibly with device-resident data) tensors are staged through the host."""
+    t = torch.view_as_real(t) if t.is_complex() else t
+    if dist.get_backend() == "gloo" and t.is_cuda:
+        return t.cpu(), True, t.device
+    return t, True, None
 
 
-def _restore(t, was_complex):
-    return torch.view_as_complex(t.contiguous()) if (was_complex and t is not None) else t
+def _restore(t, meta):
+    if t is None:
+        return None
+    was_complex, dev = meta
+    if dev is not None:
+        t = t.to(dev)
+    return torch.view_as_complex(t.contiguous()) if was_complex else t
 
 
 def gather_frames(local, n_frames: int, dst: Optional[int] = 0):
@@ -57,8 +66,9 @@ def gather_frames(local, n_frames: int, dst: Optional[int] = 0):
     rank, world = rank_world()
     if world == 1:
         return local
-    local, cplx = _as_real(local)
-    return _restore(_gather_frames_real(local, n_frames, dst, rank, world), cplx)
+    cplx = local.is_complex()
+    local, _, dev = _as_real(local)
+    return _restore(_gather_frames_real(local, n_frames, dst, rank, world), (cplx, dev))
 
 
 def _gather_frames_real(local, n_frames, dst, rank, world):
@@ -86,8 +96,9 @@ def frames_to_probes(local, n_frames: int):
     rank, world = rank_world()
     if world == 1:
         return local
-    local, cplx = _as_real(local)
-    return _restore(_frames_to_probes_real(local, n_frames, rank, world), cplx)
+    cplx = local.is_complex()
+    local, _, dev = _as_real(local)
+    return _restore(_frames_to_probes_real(local, n_frames, rank, world), (cplx, dev))
 
 
 def _frames_to_probes_real(local, n_frames, rank, world):
@@ -122,8 +133,9 @@ def gather_probes(local, n_probes: int, dst: Optional[int] = 0):
     rank, world = rank_world()
     if world == 1:
         return local
-    local, cplx = _as_real(local)
-    return _restore(_gather_probes_real(local, n_probes, dst, rank, world), cplx)
+    cplx = local.is_complex()
+    local, _, dev = _as_real(local)
+    return _restore(_gather_probes_real(local, n_probes, dst, rank, world), (cplx, dev))
 
 
 def _gather_probes_real(local, n_probes, dst, rank, world):

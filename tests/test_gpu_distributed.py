@@ -1,0 +1,77 @@
+"""Two ranks on one MI355X (gloo rehearsal of the one-process-per-GPU path): frames are sharded over the ranks, each
+rank propagates its shard on the device, WFData is gathered on rank 0, and TACAWData re-shards frames -> probes with
+the all-to-all, runs the device time FFT per rank and gathers the intensities.  RCCL itself needs >= 2 GPUs and is
+exercised by `bench.py --gpus N`; the exchange logic, shard arithmetic and device plumbing are the same code."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import pyslice_amd as ps
+        from pyslice_amd.synthetic import synthetic_trajectory
+        tr = synthetic_trajectory(256, 5, 5, density=0.05, seed=41)          # 5 frames -> shards of 3 and 2
+        pp = [(12.0, 12.0), (3.0, 20.0), (17.5, 6.25)]
+        out = {}
+        calc = ps.MultisliceCalculator(device=0, progress=False, gather="rank0")
+        calc.setup(tr, aperture=30.0, voltage_eV=100e3, probe_positions=pp)
+        wf = calc.run()
+        if rank == 0:
+            out["wf"] = wf.wavefunction_data.cpu().numpy()
+        else:
+            assert wf.wavefunction_data is None
+        calc2 = ps.MultisliceCalculator(device=0, progress=False, gather="none")
+        calc2.setup(tr, aperture=30.0, voltage_eV=100e3, probe_positions=pp)
+        tac = ps.TACAWData(calc2.run())
+        if rank == 0:
+            out["intensity"] = tac.intensity.cpu().numpy()
+            out["frequencies"] = tac.frequencies
+        else:
+            assert tac.intensity is None
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_frame_sharding_gather_and_tacaw():
+    import torch.multiprocessing as mp
+    from conftest import rel_l2
+    from oracle import multislice_oracle as orc
+    from pyslice_amd.synthetic import synthetic_trajectory
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    assert all(p.exitcode == 0 for p in procs)
+    tr = synthetic_trajectory(256, 5, 5, density=0.05, seed=41)
+    pp = [(12.0, 12.0), (3.0, 20.0), (17.5, 6.25)]
+    want = orc.run_frames(tr.box_matrix, tr.positions, tr.atom_types, 30.0, 100e3, pp)["wavefunction_data"]
+    got = res[0]["wf"]
+    assert got.shape == want.shape
+    assert rel_l2(got, want) < 1e-4
+    f, inten = orc.tacaw(want, np.arange(5) * tr.timestep)
+    assert np.allclose(res[0]["frequencies"], f)
+    assert rel_l2(res[0]["intensity"], inten) < 2e-4
