@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmslice.so")
+LIB_PATH = os.environ.get("MSL_LIB") or os.path.join(_HERE, "libmslice.so")
 
 MSL_OK, MSL_ERR_INVALID, MSL_ERR_HIP, MSL_ERR_UNSUPPORTED, MSL_ERR_STATE, MSL_ERR_NOMEM = 0, -1, -2, -3, -4, -5
 (BUF_PROBES, BUF_EXIT, BUF_POTENTIAL, BUF_TRANSMISSION, BUF_WAVEFUNCTION, BUF_INTENSITY, BUF_FORMFACTOR) = range(7)

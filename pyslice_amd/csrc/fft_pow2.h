@@ -17,10 +17,12 @@
 
 namespace msl {
 
-__device__ __forceinline__ cf cmulf(cf a, cf b) { return cmulp(a, b); }
-__device__ __forceinline__ cf cmulf_conj(cf a, cf b) { return cmulp_conj(a, b); }
-__device__ __forceinline__ const cf* as_cf(const float2* p) { return reinterpret_cast<const cf*>(p); }
-__device__ __forceinline__ cf* as_cf(float2* p) { return reinterpret_cast<cf*>(p); }
+__device__ __forceinline__ float2 cmulf(float2 a, float2 b) {
+    return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x));
+}
+__device__ __forceinline__ float2 cmulf_conj(float2 a, float2 b) {      // a * conj(b)
+    return make_float2(fmaf(a.x, b.x, a.y * b.y), fmaf(a.y, b.x, -a.x * b.y));
+}
 
 // LDS ordering inside one wave: DS instructions of a wave execute in order, so only the compiler
 // must be kept from reordering the accesses of the transpose.
@@ -38,11 +40,11 @@ __device__ __forceinline__ void lds_barrier() {
 // Multiply v[j] (j = J0..R-1) by tab[j*R + ln] (conjugated when CONJ) in chunks of 8 with a scheduling
 // barrier between chunks, so the compiler cannot hoist all R table loads at once (register pressure).
 template <int R, int J0, bool CONJ, typename TabPtr>
-__device__ __forceinline__ void mul_table(cf (&v)[R], TabPtr tab, int ln) {
+__device__ __forceinline__ void mul_table(float2 (&v)[R], TabPtr tab, int ln) {
     constexpr int CH = 8;
 #pragma unroll
     for (int c = 0; c < R; c += CH) {
-        cf w[CH];
+        float2 w[CH];
 #pragma unroll
         for (int j = 0; j < CH; ++j) if (c + j >= J0) w[j] = tab[(c + j) * R + ln];
 #pragma unroll
@@ -56,7 +58,7 @@ __device__ __forceinline__ void mul_table(cf (&v)[R], TabPtr tab, int ln) {
 // Transpose through a float scratch of R*(R+1) words, real and imaginary parts one after the other
 // (row pass: halves the LDS footprint so more waves fit a CU).
 template <int R, bool INV>
-__device__ __forceinline__ void fourstep_split(cf (&v)[R], float* scratch, const cf* tw, int ln) {
+__device__ __forceinline__ void fourstep_split(float2 (&v)[R], float* scratch, const float2* tw, int ln) {
     fft_regs<R, INV>(v);
     mul_table<R, 1, INV>(v, tw, ln);
 #pragma unroll
@@ -74,9 +76,9 @@ __device__ __forceinline__ void fourstep_split(cf (&v)[R], float* scratch, const
     fft_regs<R, INV>(v);
 }
 
-// same with a complex scratch of R*(R+1) cf (column pass: the tile is in LDS anyway)
+// same with a complex scratch of R*(R+1) float2 (column pass: the tile is in LDS anyway)
 template <int R, bool INV>
-__device__ __forceinline__ void fourstep_c64(cf (&v)[R], cf* scratch, const cf* tw, int ln) {
+__device__ __forceinline__ void fourstep_c64(float2 (&v)[R], float2* scratch, const float2* tw, int ln) {
     fft_regs<R, INV>(v);
     mul_table<R, 1, INV>(v, tw, ln);
 #pragma unroll
@@ -89,10 +91,10 @@ __device__ __forceinline__ void fourstep_c64(cf (&v)[R], cf* scratch, const cf* 
 }
 
 struct RowJob {
-    cf* psi;            // (P, nx, pitch) working waves, rows contiguous
-    const cf* trans;    // t_z (nx, ny) of this slice, or null
-    const cf* py;       // (ny) Fresnel factor along y with 1/ny folded in, or null
-    const cf* tw;       // (N) four-step twiddles T[k1*R + n2]
+    float2* psi;            // (P, nx, pitch) working waves, rows contiguous
+    const float2* trans;    // t_z (nx, ny) of this slice, or null
+    const float2* py;       // (ny) Fresnel factor along y with 1/ny folded in, or null
+    const float2* tw;       // (N) four-step twiddles T[k1*R + n2]
     long long image_stride; // elements between probes
     int pitch;              // elements between rows
     int nx;                 // rows per image
@@ -109,7 +111,7 @@ __global__ void __launch_bounds__(256, R == 32 ? 3 : 4) row_pass_kernel(RowJob j
     constexpr int N = R * R;
     constexpr int G = 256 / R;                       // lines per workgroup iteration
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    cf* tw = reinterpret_cast<cf*>(smem_raw);                 // N cf
+    float2* tw = reinterpret_cast<float2*>(smem_raw);                 // N float2
     float* scratch_all = reinterpret_cast<float*>(tw + N);            // G * R*(R+1) floats
     const int tid = threadIdx.x;
     for (int i = tid; i < N; i += 256) tw[i] = job.tw[i];
@@ -128,13 +130,13 @@ __global__ void __launch_bounds__(256, R == 32 ? 3 : 4) row_pass_kernel(RowJob j
         const int p = (int)(g % job.n_images);
         if (xcd_map) xg = xg * 8 + (int)(blockIdx.x % 8);
         const int x = xg * G + grp;
-        cf* row = job.psi + (long long)p * job.image_stride + (long long)x * job.pitch;
-        cf v[R];
+        float2* row = job.psi + (long long)p * job.image_stride + (long long)x * job.pitch;
+        float2 v[R];
 #pragma unroll
         for (int j = 0; j < R; ++j) v[j] = row[j * R + ln];
         if (job.do_ifft) fourstep_split<R, true>(v, scratch, tw, ln);
         if (job.trans) {
-            const cf* trow = job.trans + (long long)x * N;
+            const float2* trow = job.trans + (long long)x * N;
             mul_table<R, 0, false>(v, trow, ln);
         }
         if (job.do_fft) {
@@ -158,11 +160,11 @@ __global__ void __launch_bounds__(256, 2) row_pass_pf_kernel(RowJob job) {
     constexpr int N = R * R;
     constexpr int G = 256 / R;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    cf* tw = reinterpret_cast<cf*>(smem_raw);                 // N
-    cf* pyl = tw + N;                                             // N
+    float2* tw = reinterpret_cast<float2*>(smem_raw);                 // N
+    float2* pyl = tw + N;                                             // N
     float* scratch_all = reinterpret_cast<float*>(pyl + N);           // G * R*(R+1) floats
     const int tid = threadIdx.x;
-    for (int i = tid; i < N; i += 256) { tw[i] = job.tw[i]; pyl[i] = job.py ? job.py[i] : mk(1.f, 0.f); }
+    for (int i = tid; i < N; i += 256) { tw[i] = job.tw[i]; pyl[i] = job.py ? job.py[i] : make_float2(1.f, 0.f); }
     __syncthreads();
     const int grp = tid / R, ln = tid % R;
     float* scratch = scratch_all + grp * (R * (R + 1));
@@ -179,21 +181,21 @@ __global__ void __launch_bounds__(256, 2) row_pass_pf_kernel(RowJob job) {
         const int x = xg * G + grp;
         return job.psi + (long long)(pc * PC + kk) * job.image_stride + (long long)x * job.pitch;
     };
-    cf vn[R];
+    float2 vn[R];
     if (item < n_items) {
-        const cf* r = row_of(item, 0);
+        const float2* r = row_of(item, 0);
 #pragma unroll
         for (int j = 0; j < R; ++j) vn[j] = r[j * R + ln];
     }
-    cf tv[R];
+    float2 tv[R];
     while (item < n_items) {
-        cf v[R];
+        float2 v[R];
 #pragma unroll
         for (int j = 0; j < R; ++j) v[j] = vn[j];
-        cf* cur_row = row_of(item, k);
+        float2* cur_row = row_of(item, k);
         if (k == 0 && job.trans) {          // new x-group: its transmission rows first (L2), before the next HBM loads
             const int x = (int)(item / pchunks) * G + grp;
-            const cf* trow = job.trans + (long long)x * N;
+            const float2* trow = job.trans + (long long)x * N;
 #pragma unroll
             for (int j = 0; j < R; ++j) tv[j] = trow[j * R + ln];
         }
@@ -202,7 +204,7 @@ __global__ void __launch_bounds__(256, 2) row_pass_pf_kernel(RowJob job) {
         int nk = k + 1;
         if (nk >= chunk_len(item)) { nitem = item + gridDim.x; nk = 0; }
         if (nitem < n_items) {
-            const cf* r = row_of(nitem, nk);
+            const float2* r = row_of(nitem, nk);
 #pragma unroll
             for (int j = 0; j < R; ++j) vn[j] = r[j * R + ln];
         }
@@ -222,10 +224,10 @@ __global__ void __launch_bounds__(256, 2) row_pass_pf_kernel(RowJob job) {
 }
 
 struct ColJob {
-    const cf* in;       // (P, nx, pitch)
-    cf* out;            // same buffer for the slice loop; the (P,T,nx,ny) result for the epilogue
-    const cf* px;       // (nx) Fresnel factor along x with 1/nx folded in (mode 0)
-    const cf* tw;       // (N) four-step twiddles
+    const float2* in;       // (P, nx, pitch)
+    float2* out;            // same buffer for the slice loop; the (P,T,nx,ny) result for the epilogue
+    const float2* px;       // (nx) Fresnel factor along x with 1/nx folded in (mode 0)
+    const float2* tw;       // (N) four-step twiddles
     long long in_image_stride, out_image_stride;
     int in_pitch, out_pitch;
     int ny;                 // columns per image
@@ -235,7 +237,7 @@ struct ColJob {
     float sigma;            // COL_POTENTIAL: t = exp(i sigma V)
     float* out_real;        // COL_POTENTIAL: optional V (same pitch / image stride as `out`)
     int tparity;            // COL_TPOT: images whose index parity differs from this are stored transposed ...
-    cf* out_t;          // ... into this separate (n_images, ny, nx) buffer (in-place transposition would race)
+    float2* out_t;          // ... into this separate (n_images, ny, nx) buffer (in-place transposition would race)
 };
 // COL_POTENTIAL: epilogue of the potential build, V = Re(x)*scale, out = exp(i sigma V)  (potentials.py:336-342, multislice.py:282)
 // COL_TPOT (with COL_POTENTIAL): every second slice's t is stored transposed, (ny, nx), for the one-pass slice loop
@@ -249,25 +251,25 @@ template <int R>
 __global__ void __launch_bounds__(16 * R) col_pass_kernel(ColJob job) {
     constexpr int N = R * R;
     constexpr int NT = 16 * R;                        // threads
-    constexpr int CS = R * (R + 1) + 1;               // LDS column stride in cf (odd*8 B: conflict-free staging)
+    constexpr int CS = R * (R + 1) + 1;               // LDS column stride in float2 (odd*8 B: conflict-free staging)
     constexpr int ROWS_PER_IT = NT / 8;               // 8 threads (16 B each) per 128-byte row segment
     constexpr int NIT = N / ROWS_PER_IT;              // float4 per thread per tile
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    cf* tw = reinterpret_cast<cf*>(smem_raw);                 // N
-    cf* px = tw + N;                                              // N
-    cf* cols = px + N;                                            // 16 * CS
+    float2* tw = reinterpret_cast<float2*>(smem_raw);                 // N
+    float2* px = tw + N;                                              // N
+    float2* cols = px + N;                                            // 16 * CS
     const int tid = threadIdx.x;
-    for (int i = tid; i < N; i += NT) { tw[i] = job.tw[i]; px[i] = job.px ? job.px[i] : mk(1.f, 0.f); }
+    for (int i = tid; i < N; i += NT) { tw[i] = job.tw[i]; px[i] = job.px ? job.px[i] : make_float2(1.f, 0.f); }
     const int grp = tid / R, ln = tid % R;            // column handled in the transform phase
     const int q = tid & 7, r0 = tid >> 3;             // staging role: column pair q, row r0 + ROWS_PER_IT*i
-    cf* mycol = cols + grp * CS;
+    float2* mycol = cols + grp * CS;
     const int tiles_per_image = job.ny / 16;
     const long long n_tiles = (long long)tiles_per_image * job.n_images;
     float4 stage[NIT];
     long long tile = blockIdx.x;
     if (tile < n_tiles) {
         const long long p = tile / tiles_per_image, c0 = (tile % tiles_per_image) * 16;
-        const cf* src = job.in + p * job.in_image_stride + c0 + 2 * q;
+        const float2* src = job.in + p * job.in_image_stride + c0 + 2 * q;
 #pragma unroll
         for (int i = 0; i < NIT; ++i)
             stage[i] = *reinterpret_cast<const float4*>(src + (long long)(r0 + ROWS_PER_IT * i) * job.in_pitch);
@@ -278,15 +280,15 @@ __global__ void __launch_bounds__(16 * R) col_pass_kernel(ColJob job) {
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
             const int x = r0 + ROWS_PER_IT * i;
-            cols[(2 * q) * CS + x] = mk(stage[i].x, stage[i].y);
-            cols[(2 * q + 1) * CS + x] = mk(stage[i].z, stage[i].w);
+            cols[(2 * q) * CS + x] = make_float2(stage[i].x, stage[i].y);
+            cols[(2 * q + 1) * CS + x] = make_float2(stage[i].z, stage[i].w);
         }
         lds_barrier();
         // ---- next tile's loads go out now and fly during the transform
         const long long nxt = tile + gridDim.x;
         if (nxt < n_tiles) {
             const long long p = nxt / tiles_per_image, c0 = (nxt % tiles_per_image) * 16;
-            const cf* src = job.in + p * job.in_image_stride + c0 + 2 * q;
+            const float2* src = job.in + p * job.in_image_stride + c0 + 2 * q;
 #pragma unroll
             for (int i = 0; i < NIT; ++i)
                 stage[i] = *reinterpret_cast<const float4*>(src + (long long)(r0 + ROWS_PER_IT * i) * job.in_pitch);
@@ -294,7 +296,7 @@ __global__ void __launch_bounds__(16 * R) col_pass_kernel(ColJob job) {
         // ---- transform my column
         bool tstore = false;
         {
-            cf v[R];
+            float2 v[R];
 #pragma unroll
             for (int j = 0; j < R; ++j) v[j] = mycol[j * R + ln];
             wave_lds_fence();
@@ -309,12 +311,12 @@ __global__ void __launch_bounds__(16 * R) col_pass_kernel(ColJob job) {
             if (tstore) {
                 // transposed transmission slice: column (fixed y) is a contiguous line of the (ny, nx) image
                 const int y = (int)(tile % tiles_per_image) * 16 + grp;
-                cf* trow = job.out_t + pimg * job.out_image_stride + (long long)y * N;
+                float2* trow = job.out_t + pimg * job.out_image_stride + (long long)y * N;
 #pragma unroll
                 for (int j = 0; j < R; ++j) {
                     float sn, cs;
                     sincosf(job.sigma * (v[j].x * job.scale), &sn, &cs);
-                    trow[j * R + ln] = mk(cs, sn);
+                    trow[j * R + ln] = make_float2(cs, sn);
                 }
             } else {
 #pragma unroll
@@ -328,18 +330,18 @@ __global__ void __launch_bounds__(16 * R) col_pass_kernel(ColJob job) {
             const int c0 = (int)(tile % tiles_per_image) * 16;
             int cshift = c0, xshift = 0;
             if (job.flags & COL_SHIFT) { cshift = (c0 + job.ny / 2) % job.ny; xshift = N / 2; }
-            cf* dst = job.out + p * job.out_image_stride + cshift + 2 * q;
+            float2* dst = job.out + p * job.out_image_stride + cshift + 2 * q;
 #pragma unroll
             for (int i = 0; i < NIT; ++i) {
                 const int x = r0 + ROWS_PER_IT * i;
-                cf a = cols[(2 * q) * CS + x], b = cols[(2 * q + 1) * CS + x];
+                float2 a = cols[(2 * q) * CS + x], b = cols[(2 * q + 1) * CS + x];
                 int xo = x + xshift;
                 if (xo >= N) xo -= N;
                 if (job.flags & COL_POTENTIAL) {
                     const float va = a.x * job.scale, vb = b.x * job.scale;
                     if (job.out_real)
-                        *reinterpret_cast<cf*>(job.out_real + p * job.out_image_stride + cshift + 2 * q +
-                                                   (long long)xo * job.out_pitch) = mk(va, vb);
+                        *reinterpret_cast<float2*>(job.out_real + p * job.out_image_stride + cshift + 2 * q +
+                                                   (long long)xo * job.out_pitch) = make_float2(va, vb);
                     float sa, ca, sb, cb;
                     sincosf(job.sigma * va, &sa, &ca);
                     sincosf(job.sigma * vb, &sb, &cb);
@@ -368,10 +370,10 @@ __global__ void __launch_bounds__(16 * R) col_pass_kernel(ColJob job) {
 enum { P2_PRE_A = 1, P2_POST_A = 2, P2_POST_F = 4 };
 
 struct Row2Job {
-    cf* psi;
-    const cf* trans;    // t_k (nx, ny)
-    const cf* py;       // (ny), 1/ny folded in
-    const cf* tw;
+    float2* psi;
+    const float2* trans;    // t_k (nx, ny)
+    const float2* py;       // (ny), 1/ny folded in
+    const float2* tw;
     long long image_stride;
     int pitch, nx, n_images, flags, pchunk;
 };
@@ -381,8 +383,8 @@ __global__ void __launch_bounds__(256, 2) row_pass2_kernel(Row2Job job) {
     constexpr int N = R * R;
     constexpr int G = 256 / R;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    cf* tw = reinterpret_cast<cf*>(smem_raw);
-    cf* pyl = tw + N;
+    float2* tw = reinterpret_cast<float2*>(smem_raw);
+    float2* pyl = tw + N;
     float* scratch_all = reinterpret_cast<float*>(pyl + N);
     const int tid = threadIdx.x;
     for (int i = tid; i < N; i += 256) { tw[i] = job.tw[i]; pyl[i] = job.py[i]; }
@@ -401,21 +403,21 @@ __global__ void __launch_bounds__(256, 2) row_pass2_kernel(Row2Job job) {
         const int x = xg * G + grp;
         return job.psi + (long long)(pc * PC + kk) * job.image_stride + (long long)x * job.pitch;
     };
-    cf vn[R];
+    float2 vn[R];
     if (item < n_items) {
-        const cf* r = row_of(item, 0);
+        const float2* r = row_of(item, 0);
 #pragma unroll
         for (int j = 0; j < R; ++j) vn[j] = r[j * R + ln];
     }
-    cf tv[R];
+    float2 tv[R];
     while (item < n_items) {
-        cf v[R];
+        float2 v[R];
 #pragma unroll
         for (int j = 0; j < R; ++j) v[j] = vn[j];
-        cf* cur_row = row_of(item, k);
+        float2* cur_row = row_of(item, k);
         if (k == 0) {
             const int x = (int)(item / pchunks) * G + grp;
-            const cf* trow = job.trans + (long long)x * N;
+            const float2* trow = job.trans + (long long)x * N;
 #pragma unroll
             for (int j = 0; j < R; ++j) tv[j] = trow[j * R + ln];
         }
@@ -423,7 +425,7 @@ __global__ void __launch_bounds__(256, 2) row_pass2_kernel(Row2Job job) {
         int nk = k + 1;
         if (nk >= chunk_len(item)) { nitem = item + gridDim.x; nk = 0; }
         if (nitem < n_items) {
-            const cf* r = row_of(nitem, nk);
+            const float2* r = row_of(nitem, nk);
 #pragma unroll
             for (int j = 0; j < R; ++j) vn[j] = r[j * R + ln];
         }
@@ -446,129 +448,16 @@ __global__ void __launch_bounds__(256, 2) row_pass2_kernel(Row2Job job) {
     }
 }
 
-struct Col2Job {
-    cf* psi;            // (P, nx, pitch), in place
-    const cf* trans;    // t_k (nx, ny), unpadded
-    const cf* px;       // (nx), 1/nx folded in
-    const cf* tw;
-    long long image_stride;
-    int pitch, ny, n_images, flags, pchunk;
-};
-
-// Column pass A_x . t . A_x.  Work item = (16-column tile, chunk of probes): the t tile is staged once per
-// item through LDS into registers (tv) and reused for every probe of the chunk.
-template <int R>
-__global__ void __launch_bounds__(16 * R) col_pass2_kernel(Col2Job job) {
-    constexpr int N = R * R;
-    constexpr int NT = 16 * R;
-    constexpr int CS = R * (R + 1) + 1;
-    constexpr int ROWS_PER_IT = NT / 8;
-    constexpr int NIT = N / ROWS_PER_IT;
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    cf* tw = reinterpret_cast<cf*>(smem_raw);
-    cf* px = tw + N;
-    cf* cols = px + N;
-    const int tid = threadIdx.x;
-    for (int i = tid; i < N; i += NT) { tw[i] = job.tw[i]; px[i] = job.px[i]; }
-    const int grp = tid / R, ln = tid % R;
-    const int q = tid & 7, r0 = tid >> 3;
-    cf* mycol = cols + grp * CS;
-    const int ctiles = job.ny / 16;
-    const int PC = job.pchunk;
-    const int pchunks = (job.n_images + PC - 1) / PC;
-    const long long n_items = (long long)ctiles * pchunks;
-    auto chunk_len = [&](long long it) { const int pc = (int)(it % pchunks); return min(PC, job.n_images - pc * PC); };
-    auto tile_ptr = [&](long long it, int kk) {
-        const int ct = (int)(it / pchunks), pc = (int)(it % pchunks);
-        return job.psi + (long long)(pc * PC + kk) * job.image_stride + ct * 16 + 2 * q;
-    };
-    long long item = blockIdx.x;
-    int k = 0;
-    float4 stage[NIT];
-    if (item < n_items) {
-        const cf* src = tile_ptr(item, 0);
-#pragma unroll
-        for (int i = 0; i < NIT; ++i)
-            stage[i] = *reinterpret_cast<const float4*>(src + (long long)(r0 + ROWS_PER_IT * i) * job.pitch);
-    }
-    __syncthreads();
-    cf tv[R];
-    while (item < n_items) {
-        if (k == 0) {
-            // transmission tile of this column block: HBM/L2 -> LDS (column-major) -> registers, once per item
-            const cf* tsrc = job.trans + (long long)(item / pchunks) * 16 + 2 * q;
-#pragma unroll
-            for (int i = 0; i < NIT; ++i) {
-                const int x = r0 + ROWS_PER_IT * i;
-                const float4 t4 = *reinterpret_cast<const float4*>(tsrc + (long long)x * job.ny);
-                cols[(2 * q) * CS + x] = mk(t4.x, t4.y);
-                cols[(2 * q + 1) * CS + x] = mk(t4.z, t4.w);
-            }
-            lds_barrier();
-#pragma unroll
-            for (int j = 0; j < R; ++j) tv[j] = mycol[j * R + ln];
-            lds_barrier();
-        }
-#pragma unroll
-        for (int i = 0; i < NIT; ++i) {
-            const int x = r0 + ROWS_PER_IT * i;
-            cols[(2 * q) * CS + x] = mk(stage[i].x, stage[i].y);
-            cols[(2 * q + 1) * CS + x] = mk(stage[i].z, stage[i].w);
-        }
-        lds_barrier();
-        cf* dst = const_cast<cf*>(tile_ptr(item, k));
-        long long nitem = item;
-        int nk = k + 1;
-        if (nk >= chunk_len(item)) { nitem = item + gridDim.x; nk = 0; }
-        if (nitem < n_items) {
-            const cf* src = tile_ptr(nitem, nk);
-#pragma unroll
-            for (int i = 0; i < NIT; ++i)
-                stage[i] = *reinterpret_cast<const float4*>(src + (long long)(r0 + ROWS_PER_IT * i) * job.pitch);
-        }
-        {
-            cf v[R];
-#pragma unroll
-            for (int j = 0; j < R; ++j) v[j] = mycol[j * R + ln];
-            wave_lds_fence();
-            if (job.flags & P2_PRE_A) {
-                fourstep_c64<R, false>(v, mycol, tw, ln);
-                mul_table<R, 0, false>(v, px, ln);
-                fourstep_c64<R, true>(v, mycol, tw, ln);
-            }
-#pragma unroll
-            for (int j = 0; j < R; ++j) v[j] = cmulf(v[j], tv[j]);
-            if (job.flags & P2_POST_A) {
-                fourstep_c64<R, false>(v, mycol, tw, ln);
-                mul_table<R, 0, false>(v, px, ln);
-                fourstep_c64<R, true>(v, mycol, tw, ln);
-            }
-            wave_lds_fence();
-#pragma unroll
-            for (int j = 0; j < R; ++j) mycol[j * R + ln] = v[j];
-        }
-        lds_barrier();
-#pragma unroll
-        for (int i = 0; i < NIT; ++i) {
-            const int x = r0 + ROWS_PER_IT * i;
-            cf a = cols[(2 * q) * CS + x], b = cols[(2 * q + 1) * CS + x];
-            *reinterpret_cast<float4*>(dst + (long long)x * job.pitch) = make_float4(a.x, a.y, b.x, b.y);
-        }
-        lds_barrier();
-        item = nitem; k = nk;
-    }
-}
-
 // Transposing pass: lines of the input are contiguous (row-style, coalesced, prefetched in registers);
 // the result is written TRANSPOSED (out[pos][line]) through an LDS tile of 16 lines so that HBM sees
 // 128-byte segments.  The next pass then again reads contiguous lines -- of the other axis.  With this
 // kernel every slice is one pass  A_d . t_k . A_d  with t_k reused from registers across a chunk of probes.
 struct RowTJob {
-    const cf* in;       // (P, n_lines, in_pitch): lines along the transform axis
-    cf* out;            // (P, N, out_pitch): transposed
-    const cf* trans;    // t_k in the input orientation, (n_lines, N) unpadded
-    const cf* pl;       // (N) Fresnel factor along the line axis, 1/N folded in
-    const cf* tw;
+    const float2* in;       // (P, n_lines, in_pitch): lines along the transform axis
+    float2* out;            // (P, N, out_pitch): transposed
+    const float2* trans;    // t_k in the input orientation, (n_lines, N) unpadded
+    const float2* pl;       // (N) Fresnel factor along the line axis, 1/N folded in
+    const float2* tw;
     long long in_image_stride, out_image_stride;
     int in_pitch, out_pitch, n_lines, n_images, flags, pchunk;
 };
@@ -582,17 +471,16 @@ __global__ void __launch_bounds__(LINES * R) rowT_pass_kernel(RowTJob job) {
     constexpr int POS_PER_IT = NT / TPS;
     constexpr int NIT = N / POS_PER_IT;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    constexpr bool PL_LDS = (LINES == 16);            // 8-line tiles: Fresnel table from L1/L2 so two workgroups fit a CU
-    cf* tw = reinterpret_cast<cf*>(smem_raw);
-    cf* pl_lds = tw + N;
-    cf* tile = PL_LDS ? pl_lds + N : pl_lds;      // LINES * CS
+    static_assert(LINES == 16, "16 lines = 128-byte transposed segments (8 lines / 64 bytes measured 1.6x slower)");
+    float2* tw = reinterpret_cast<float2*>(smem_raw);
+    float2* pl = tw + N;
+    float2* tile = pl + N;                            // LINES * CS
     const int tid = threadIdx.x;
-    for (int i = tid; i < N; i += NT) { tw[i] = job.tw[i]; if (PL_LDS) pl_lds[i] = job.pl[i]; }
-    const cf* pl = PL_LDS ? pl_lds : job.pl;
+    for (int i = tid; i < N; i += NT) { tw[i] = job.tw[i]; pl[i] = job.pl[i]; }
     __syncthreads();
     const int grp = tid / R, ln = tid % R;
     const int q = tid % TPS, r0 = tid / TPS;
-    cf* myrow = tile + grp * CS;
+    float2* myrow = tile + grp * CS;
     const int lblocks = job.n_lines / LINES;
     const int PC = job.pchunk;
     const int pchunks = (job.n_images + PC - 1) / PC;
@@ -604,21 +492,21 @@ __global__ void __launch_bounds__(LINES * R) rowT_pass_kernel(RowTJob job) {
     };
     long long item = blockIdx.x;
     int k = 0;
-    cf vn[R];
+    float2 vn[R];
     if (item < n_items) {
-        const cf* r = line_ptr(item, 0);
+        const float2* r = line_ptr(item, 0);
 #pragma unroll
         for (int j = 0; j < R; ++j) vn[j] = r[j * R + ln];
     }
-    cf tv[R];
+    float2 tv[R];
     while (item < n_items) {
-        cf v[R];
+        float2 v[R];
 #pragma unroll
         for (int j = 0; j < R; ++j) v[j] = vn[j];
         const int lb = (int)(item / pchunks);
         const int p = (int)(item % pchunks) * PC + k;
         if (k == 0) {
-            const cf* trow = job.trans + (long long)(lb * LINES + grp) * N;
+            const float2* trow = job.trans + (long long)(lb * LINES + grp) * N;
 #pragma unroll
             for (int j = 0; j < R; ++j) tv[j] = trow[j * R + ln];
         }
@@ -626,7 +514,7 @@ __global__ void __launch_bounds__(LINES * R) rowT_pass_kernel(RowTJob job) {
         int nk = k + 1;
         if (nk >= chunk_len(item)) { nitem = item + gridDim.x; nk = 0; }
         if (nitem < n_items) {
-            const cf* r = line_ptr(nitem, nk);
+            const float2* r = line_ptr(nitem, nk);
 #pragma unroll
             for (int j = 0; j < R; ++j) vn[j] = r[j * R + ln];
         }
@@ -648,14 +536,14 @@ __global__ void __launch_bounds__(LINES * R) rowT_pass_kernel(RowTJob job) {
         lds_barrier();
         // uniform 64-bit base + per-thread 32-bit element offset, re-derived every iteration (the asm keeps the
         // compiler from hoisting 16 loop-invariant 64-bit addresses into registers for the whole kernel)
-        cf* dst = job.out + (long long)p * job.out_image_stride + lb * LINES;
+        float2* dst = job.out + (long long)p * job.out_image_stride + lb * LINES;
         int off0 = 2 * q + r0 * job.out_pitch;
         asm volatile("" : "+v"(off0));
         const int ostep = POS_PER_IT * job.out_pitch;
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
             const int pos = r0 + POS_PER_IT * i;
-            const cf a = tile[(2 * q) * CS + pos], b = tile[(2 * q + 1) * CS + pos];
+            const float2 a = tile[(2 * q) * CS + pos], b = tile[(2 * q + 1) * CS + pos];
             *reinterpret_cast<float4*>(dst + (off0 + i * ostep)) = make_float4(a.x, a.y, b.x, b.y);
         }
         lds_barrier();

@@ -12,46 +12,15 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define MSL_HD __host__ __device__ __forceinline__
+namespace msl { using cf = float2; }
 #else
 #define MSL_HD inline
+namespace msl { struct cf { float x, y; }; }
 #endif
+
 namespace msl {
 
-// A complex number is a 2-lane clang vector: complex add/sub compile to one v_pk_add_f32, a complex multiply to
-// v_pk_mul_f32 + v_pk_fma_f32.  Measured on MI355X (tools/valubench.hip, valubench2.hip): a wave64 VALU instruction
-// issues every ~4 cycles per SIMD whether scalar or packed (v_fma_f32 77 TFLOP/s, v_pk_fma_f32 142 TFLOP/s), so
-// packed math nearly halves the VALU time of these issue-bound kernels -- provided no v_mov / v_xor glue is needed:
-// the swap and the sign of a complex product must ride on the VOP3P op_sel / neg modifiers, which hipcc does not
-// emit for runtime operands, hence the two-instruction inline asm below.
-typedef float cf __attribute__((ext_vector_type(2)));
-MSL_HD cf mk(float x, float y) { return cf{x, y}; }
-
-// a * b  and  a * conj(b)
-MSL_HD cf cmulp(cf a, cf b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    cf t, d;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(b));                        // (a.x b.x, a.y b.x)
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"               // (-a.y b.y + t.x, a.x b.y + t.y)
-        : "=v"(d) : "v"(a), "v"(b), "v"(t));
-    return d;
-#else
-    return cf{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
-#endif
-}
-MSL_HD cf cmulp_conj(cf a, cf b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    cf t, d;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(b));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]"               // (a.y b.y + t.x, -a.x b.y + t.y)
-        : "=v"(d) : "v"(a), "v"(b), "v"(t));
-    return d;
-#else
-    return cf{a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y};
-#endif
-}
-// a * (-i)  and  a * (+i): one packed multiply with swapped halves
-MSL_HD cf rot_mi(cf a) { return cf{a.y, a.x} * cf{1.f, -1.f}; }
-MSL_HD cf rot_pi(cf a) { return cf{a.y, a.x} * cf{-1.f, 1.f}; }
+MSL_HD cf mk(float x, float y) { cf r; r.x = x; r.y = y; return r; }
 
 // constexpr cos/sin of 2*pi*k/n in double (Taylor on a reduced argument); exact to double rounding
 constexpr double cx_pi = 3.14159265358979323846264338327950288;
@@ -92,13 +61,21 @@ constexpr int bitrev(int i, int n) {
 // (a - b) * W_N^k with W = exp(-+ 2 pi i / N); INV selects the conjugate (inverse transform)
 template <int N, int K, bool INV>
 MSL_HD cf twiddle_mul(cf t) {
-    if constexpr (K == 0) { return t; }
-    else if constexpr (4 * K == N) { return INV ? rot_pi(t) : rot_mi(t); }
-    else {
+    if constexpr (K == 0) {
+        return t;
+    } else if constexpr (4 * K == N) {            // -i (forward) / +i (inverse)
+        return INV ? mk(-t.y, t.x) : mk(t.y, -t.x);
+    } else if constexpr (8 * K == N) {            // (1 -+ i)/sqrt2
+        constexpr float h = 0.70710678118654752440f;
+        return INV ? mk((t.x - t.y) * h, (t.x + t.y) * h) : mk((t.x + t.y) * h, (t.y - t.x) * h);
+    } else if constexpr (8 * K == 3 * N) {        // (-1 -+ i)/sqrt2
+        constexpr float h = 0.70710678118654752440f;
+        return INV ? mk((-t.x - t.y) * h, (t.x - t.y) * h) : mk((t.y - t.x) * h, (-t.x - t.y) * h);
+    } else {
         constexpr float c = (float)cx_cos2pi(K, N);
-        constexpr float s = (float)cx_sin2pi(K, N);
-        if constexpr (INV) return t * cf{c, c} + cf{t.y, t.x} * cf{-s, s};
-        else return t * cf{c, c} + cf{t.y, t.x} * cf{s, -s};
+        constexpr float s = (float)cx_sin2pi(K, N);       // W = c - i s (forward), c + i s (inverse)
+        if constexpr (INV) return mk(t.x * c - t.y * s, t.y * c + t.x * s);
+        else return mk(t.x * c + t.y * s, t.y * c - t.x * s);
     }
 }
 
@@ -106,8 +83,8 @@ template <int N, int S, bool INV, int K>
 MSL_HD void dif_level(cf* v) {
     if constexpr (K < N / 2) {
         cf a = v[K * S], b = v[(K + N / 2) * S];
-        v[K * S] = a + b;
-        v[(K + N / 2) * S] = twiddle_mul<N, K, INV>(a - b);
+        v[K * S] = mk(a.x + b.x, a.y + b.y);
+        v[(K + N / 2) * S] = twiddle_mul<N, K, INV>(mk(a.x - b.x, a.y - b.y));
         dif_level<N, S, INV, K + 1>(v);
     }
 }

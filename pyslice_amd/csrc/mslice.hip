@@ -18,11 +18,6 @@
 
 using namespace msl;
 
-// job structs of the four-step kernels carry packed-complex pointers (same layout as float2)
-static inline cf* cfp(float2* p) { return reinterpret_cast<cf*>(p); }
-static inline const cf* cfp(const float2* p) { return reinterpret_cast<const cf*>(p); }
-static inline cf* cfp(std::nullptr_t) { return nullptr; }
-
 namespace {
 
 thread_local std::string g_create_error;
@@ -67,7 +62,7 @@ struct msl_handle {
     float2* psi0T = nullptr;
     float2* transT = nullptr;
     int pitchT = 0;
-    int rowT_variant = 1;          // complex (b64) LDS transposes: with packed math the split form needs half-register moves
+    int rowT_variant = 0;
     int debug_flags_mask = -1;
     int row_pchunk = 0;         // 0 = auto (MSL_ROW_PCHUNK)
     int row_variant = 1;        // 0: plain row kernel, 1: software-pipelined (MSL_ROW_VARIANT)
@@ -417,13 +412,13 @@ int launch_col_fast(msl_handle* h, const ColJob& job, int kind) {
 
 RowJob row_job(const msl_handle* h, float2* buf, int images, int pitch) {
     RowJob j{};
-    j.psi = cfp(buf); j.trans = cfp(nullptr); j.py = cfp(nullptr); j.tw = cfp(h->tw4_y);
+    j.psi = buf; j.trans = nullptr; j.py = nullptr; j.tw = h->tw4_y;
     j.image_stride = (long long)h->cfg.nx * pitch; j.pitch = pitch; j.nx = h->cfg.nx; j.n_images = images;
     return j;
 }
 ColJob col_job(const msl_handle* h, const float2* in, float2* out, int images, int in_pitch, int out_pitch) {
     ColJob j{};
-    j.in = cfp(in); j.out = cfp(out); j.px = cfp(nullptr); j.tw = cfp(h->tw4_x);
+    j.in = in; j.out = out; j.px = nullptr; j.tw = h->tw4_x;
     j.in_image_stride = (long long)h->cfg.nx * in_pitch; j.out_image_stride = (long long)h->cfg.nx * out_pitch;
     j.in_pitch = in_pitch; j.out_pitch = out_pitch; j.ny = h->cfg.ny; j.n_images = images; j.flags = 0; j.scale = 1.f;
     return j;
@@ -483,7 +478,7 @@ int transpose_odd_slices(msl_handle* h) {
 template <int R, int LINES, bool C64>
 int launch_rowT_v(msl_handle* h, RowTJob job, int kind) {
     constexpr int N = R * R, CS = R * (R + 1) + 1;
-    const size_t lds = ((size_t)(LINES == 16 ? 2 : 1) * N + (size_t)LINES * CS) * 8;
+    const size_t lds = ((size_t)2 * N + (size_t)LINES * CS) * 8;
     const int per_cu = std::max(1, std::min(2, (int)((size_t)h->lds_limit / lds)));
     const long long slots = (long long)h->n_cus * per_cu;
     const long long lb = job.n_lines / LINES;
@@ -499,16 +494,10 @@ int launch_rowT_v(msl_handle* h, RowTJob job, int kind) {
     return mark_launch(h, kind);
 }
 
-// variant selection (MSL_ROWT_VARIANT): 0 = 16 lines / split transposes, 1 = 16 lines / complex transposes,
-// 2 = 8 lines / split, 3 = 8 lines / complex
+// MSL_ROWT_VARIANT: 0 (default) = real and imaginary parts transposed one after the other, 1 = complex (b64) transposes
 template <int R>
 int launch_rowT_r(msl_handle* h, RowTJob job, int kind) {
-    switch (h->rowT_variant) {
-        case 1: return launch_rowT_v<R, 16, true>(h, job, kind);
-        case 2: return launch_rowT_v<R, 8, false>(h, job, kind);
-        case 3: return launch_rowT_v<R, 8, true>(h, job, kind);
-        default: return launch_rowT_v<R, 16, false>(h, job, kind);
-    }
+    return h->rowT_variant == 1 ? launch_rowT_v<R, 16, true>(h, job, kind) : launch_rowT_v<R, 16, false>(h, job, kind);
 }
 
 template <int R>
@@ -547,7 +536,7 @@ int slice_loop_onepass(msl_handle* h, int fused_slot) {
         if (h->debug_flags_mask >= 0) flags &= h->debug_flags_mask;     // timing experiments only (MSL_DEBUG_FLAGS_MASK)
         if (last) {
             Row2Job j{};
-            j.psi = cfp(h->psi); j.trans = cfp(h->trans + (size_t)k * npix); j.py = cfp(h->pyt); j.tw = cfp(h->tw4_y);
+            j.psi = h->psi; j.trans = h->trans + (size_t)k * npix; j.py = h->pyt; j.tw = h->tw4_y;
             j.image_stride = isA; j.pitch = h->pitch; j.nx = c.nx; j.n_images = P; j.flags = flags;
             rc = h->Ry == 32 ? launch_row2_r<32>(h, j, K_ROW) : launch_row2_r<16>(h, j, K_ROW);
             if (rc) return rc;
@@ -557,13 +546,13 @@ int slice_loop_onepass(msl_handle* h, int fused_slot) {
         RowTJob j{};
         j.flags = flags; j.n_images = P;
         if (along_y) {
-            j.in = cfp((k == 0) ? h->psi0 : h->psi); j.out = cfp(h->psiT);
-            j.trans = cfp(h->trans + (size_t)k * npix); j.pl = cfp(h->pyt); j.tw = cfp(h->tw4_y);
+            j.in = (k == 0) ? h->psi0 : h->psi; j.out = h->psiT;
+            j.trans = h->trans + (size_t)k * npix; j.pl = h->pyt; j.tw = h->tw4_y;
             j.in_image_stride = isA; j.out_image_stride = isB; j.in_pitch = h->pitch; j.out_pitch = h->pitchT; j.n_lines = c.nx;
             rc = h->Ry == 32 ? launch_rowT_r<32>(h, j, K_ROW) : launch_rowT_r<16>(h, j, K_ROW);
         } else {
-            j.in = cfp((k == 0) ? h->psi0T : h->psiT); j.out = cfp(h->psi);
-            j.trans = cfp(h->transT + (size_t)k * npix); j.pl = cfp(h->pxt); j.tw = cfp(h->tw4_x);
+            j.in = (k == 0) ? h->psi0T : h->psiT; j.out = h->psi;
+            j.trans = h->transT + (size_t)k * npix; j.pl = h->pxt; j.tw = h->tw4_x;
             j.in_image_stride = isB; j.out_image_stride = isA; j.in_pitch = h->pitchT; j.out_pitch = h->pitch; j.n_lines = c.ny;
             rc = h->Rx == 32 ? launch_rowT_r<32>(h, j, K_COL) : launch_rowT_r<16>(h, j, K_COL);
         }
@@ -611,8 +600,8 @@ int slice_loop(msl_handle* h, int fused_slot) {
         const bool last = (z == nz - 1);
         if (h->Ry) {
             RowJob r = row_job(h, h->psi, P, h->pitch);
-            r.do_ifft = z > 0; r.trans = cfp(h->trans + (size_t)z * npix);
-            r.do_fft = (!last || fused); r.py = last ? nullptr : cfp(h->pyt);
+            r.do_ifft = z > 0; r.trans = h->trans + (size_t)z * npix;
+            r.do_fft = (!last || fused); r.py = last ? nullptr : h->pyt;
             if ((rc = launch_row_fast(h, r, K_ROW))) return rc;
         } else {
             LineArgs r = row_args(h, h->psi, h->psi, P, h->pitch);
@@ -625,7 +614,7 @@ int slice_loop(msl_handle* h, int fused_slot) {
         if (!last) {
             if (h->Rx) {
                 ColJob k = col_job(h, h->psi, h->psi, P, h->pitch, h->pitch);
-                k.px = cfp(h->pxt); k.flags = COL_FWD | COL_MULPX | COL_INV;
+                k.px = h->pxt; k.flags = COL_FWD | COL_MULPX | COL_INV;
                 if ((rc = launch_col_fast(h, k, K_COL))) return rc;
             } else {
                 LineArgs k = col_args(h, h->psi, h->psi, P, h->pitch, h->pitch);
@@ -1010,7 +999,7 @@ int msl_build_potential(msl_handle* h, const double* pos, const int32_t* Z, int6
     if (h->Rx) {
         ColJob k = col_job(h, h->trans, h->trans, c.nz, c.ny, c.ny);
         k.flags = COL_INV | COL_POTENTIAL; k.scale = vscale; k.sigma = (float)c.sigma; k.out_real = h->V;
-        if (h->onepass) { k.flags |= COL_TPOT; k.tparity = (c.nz - 1) & 1; k.out_t = cfp(h->transT); }
+        if (h->onepass) { k.flags |= COL_TPOT; k.tparity = (c.nz - 1) & 1; k.out_t = h->transT; }
         if ((rc = launch_col_fast(h, k, K_OTHER))) return rc;
     } else {
         LineArgs k = col_args(h, h->trans, h->trans, c.nz, c.ny, c.ny);

@@ -1,6 +1,6 @@
 // Host check of pyslice_amd/csrc/fft_regs.h: the register FFT network and the four-step
 // (32 lanes x 32 registers) index algebra used by fft_pow2.h, against a float64 DFT.
-//   /opt/rocm/lib/llvm/bin/clang++ -O2 -std=c++17 -o tools/bin/fft_regs_host tools/fft_regs_host.cpp && tools/bin/fft_regs_host
+//   g++ -O2 -std=c++17 -o tools/bin/fft_regs_host tools/fft_regs_host.cpp && tools/bin/fft_regs_host
 #include <cmath>
 #include <complex>
 #include <cstdio>
