@@ -155,6 +155,11 @@ size_t msl_buffer_bytes(const msl_handle* h, msl_buffer what);
 /* Raw device pointer of a library buffer, for zero-copy use by the caller's collective (RCCL). */
 void* msl_device_ptr(msl_handle* h, msl_buffer what);
 
+/* One frame slot of the (P,T_local,nx,ny) result, host (P,nx,ny) c64 <-> device.  Used by the opt-in frame cache
+ * (reference: psi_data/torch_<key>/frame_<i>.npy written and re-read per frame, calculators.py:173, 259-260, 311). */
+int  msl_download_frame(msl_handle* h, int32_t slot, void* dst_c64, size_t bytes);
+int  msl_upload_frame(msl_handle* h, int32_t slot, const void* src_c64, size_t bytes);
+
 int  msl_synchronize(msl_handle* h);
 int  msl_get_counters(const msl_handle* h, msl_counters* out);
 int  msl_reset_counters(msl_handle* h);

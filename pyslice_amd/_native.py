@@ -20,7 +20,8 @@ EXPORTS = [
     "msl_abi_version", "msl_last_error", "msl_create", "msl_destroy", "msl_set_kirkland", "msl_set_slices",
     "msl_set_beam", "msl_resize_probes", "msl_set_probes", "msl_upload_probes", "msl_shift_probes",
     "msl_build_potential", "msl_upload_potential", "msl_propagate", "msl_propagate_frame", "msl_tacaw",
-    "msl_download", "msl_buffer_bytes", "msl_device_ptr", "msl_synchronize", "msl_get_counters",
+    "msl_download", "msl_download_frame", "msl_upload_frame", "msl_buffer_bytes", "msl_device_ptr", "msl_synchronize",
+    "msl_get_counters",
     "msl_reset_counters", "msl_fft2_host",
 ]
 
@@ -74,6 +75,8 @@ def load():
         "msl_propagate_frame": (C.c_int, [vp, i32]),
         "msl_tacaw": (C.c_int, [vp, vp, vp, i64, i32, i64]),
         "msl_download": (C.c_int, [vp, C.c_int, vp, C.c_size_t, i64, i64]),
+        "msl_download_frame": (C.c_int, [vp, i32, vp, C.c_size_t]),
+        "msl_upload_frame": (C.c_int, [vp, i32, vp, C.c_size_t]),
         "msl_buffer_bytes": (C.c_size_t, [vp, C.c_int]),
         "msl_device_ptr": (vp, [vp, C.c_int]),
         "msl_synchronize": (C.c_int, [vp]),
@@ -236,6 +239,17 @@ class Engine:
     def wavefunction(self, first=0, count=0):
         n = count if count else self.n_probes
         return self.download(BUF_WAVEFUNCTION, np.complex64, (n, self.n_frames, self.nx, self.ny), first, count)
+
+    def frame(self, slot):
+        out = np.empty((self.n_probes, self.nx, self.ny), dtype=np.complex64)
+        self._chk(self._lib.msl_download_frame(self._h, int(slot), _ptr(out), out.nbytes))
+        return out
+
+    def upload_frame(self, slot, data):
+        a = np.ascontiguousarray(data, dtype=np.complex64)
+        if a.shape != (self.n_probes, self.nx, self.ny):
+            raise ValueError(f"frame must be ({self.n_probes},{self.nx},{self.ny}), got {a.shape}")
+        self._chk(self._lib.msl_upload_frame(self._h, int(slot), _ptr(a), a.nbytes))
 
     def intensity(self, first=0, count=0):
         n = count if count else self.n_probes

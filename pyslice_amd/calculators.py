@@ -36,7 +36,7 @@ logger = logging.getLogger(__name__)
 class MultisliceCalculator:
 
     def __init__(self, device=None, force_cpu=False, *, output="host", dtype="complex128", progress=True,
-                 gather="rank0"):
+                 gather="rank0", cache=False):
         """
         device / force_cpu: as the reference (calculators.py:41).  There is no CPU path here, so
         force_cpu=True raises.  Keyword-only extras (not in the reference):
@@ -44,6 +44,11 @@ class MultisliceCalculator:
                    "device" (zero-copy torch view of the library's (P,T,nx,ny) buffer, complex64)
           dtype    "complex128" (default, reference dtype; upcast after download) or "complex64"
           gather   multi-process runs: "rank0" (default), "all" or "none" (keep the local frame shard)
+          cache    True: per-frame cache files psi_data/torch_<key>/frame_<i>.npy, (P,nx,ny,1,1) complex128, in the
+                   reference's own naming and format (calculators.py:140, 173, 259-260, 311): frames found there are
+                   loaded instead of computed (resume), computed frames are written.  Off by default: the reference
+                   writes 16*P*nx*ny bytes per frame to the CWD unconditionally (1 GB/frame at C3) and its key ignores
+                   the atom positions (stale-hit hazard).
         """
         if force_cpu:
             raise NotImplementedError("pyslice_amd has no CPU path (force_cpu=True): use the reference for CPU runs")
@@ -55,6 +60,7 @@ class MultisliceCalculator:
             raise ValueError("gather must be 'rank0', 'all' or 'none'")
         self.device = device
         self._output, self._dtype, self._progress, self._gather = output, dtype, progress, gather
+        self._cache = bool(cache)
         self._engine = None
         # reference calculators.py:70-76 (display names for Z <= 36)
         self.element_map = {
@@ -99,7 +105,9 @@ class MultisliceCalculator:
         self.slice_axis = slice_axis
 
         cache_key = self._generate_cache_key(trajectory, aperture, voltage_eV, slice_thickness, sampling, probe_positions)
-        self.output_dir = Path("psi_data") / f"torch_{cache_key}"    # named, not created: the frame cache is opt-in
+        self.output_dir = Path("psi_data") / f"torch_{cache_key}"    # created only when the frame cache is switched on
+        if self._cache:
+            self.output_dir.mkdir(parents=True, exist_ok=True)
 
         xs, ys, zs, lx, ly, lz = gridFromTrajectory(trajectory, sampling=sampling, slice_thickness=slice_thickness)
         nx, ny, nz = len(xs), len(ys), len(zs)
@@ -152,16 +160,25 @@ class MultisliceCalculator:
                 bar = tqdm(total=len(frames), desc="Processing frames", unit="frame")
             except ImportError:
                 bar = None
+        self.frames_computed = self.frames_cached = 0
         for slot, frame_idx in enumerate(frames):
-            eng.build_potential(self.trajectory.positions[frame_idx], self._Z, self.slice_axis)
-            eng.propagate_frame(slot)
+            cache_file = self.output_dir / f"frame_{frame_idx}.npy"
+            if self._cache and cache_file.exists():
+                eng.upload_frame(slot, np.load(cache_file)[:, :, :, 0, 0])
+                self.frames_cached += 1
+            else:
+                eng.build_potential(self.trajectory.positions[frame_idx], self._Z, self.slice_axis)
+                eng.propagate_frame(slot)
+                self.frames_computed += 1
+                if self._cache:
+                    np.save(cache_file, eng.frame(slot).astype(np.complex128)[:, :, :, None, None])
             if bar is not None:
                 bar.update(1)
         eng.synchronize()
         if bar is not None:
             bar.close()
         self.elapsed = time.time() - t0
-        logger.info(f"Simulation completed in {self.elapsed:.2f}s ({len(frames)} computed, 0 cached)")
+        logger.info(f"Simulation completed in {self.elapsed:.2f}s ({self.frames_computed} computed, {self.frames_cached} cached)")
 
         # reference calculators.py:218-221 (quirk Q2: `sampling`, not dx; torch default float32)
         kxs = np.fft.fftshift(np.fft.fftfreq(self.nx, self.sampling)).astype(np.float32)

@@ -1179,6 +1179,29 @@ int msl_download(msl_handle* h, msl_buffer what, void* dst, size_t bytes, int64_
     return MSL_OK;
 }
 
+static int frame_copy(msl_handle* h, int32_t slot, void* host, size_t bytes, bool to_host) {
+    if (!h || !host) return fail(h, MSL_ERR_INVALID, "frame copy: null argument");
+    if (!h->wf) return fail(h, MSL_ERR_STATE, "frame copy: handle created with n_frames == 0");
+    const msl_config& c = h->cfg;
+    if (slot < 0 || slot >= c.n_frames) return fail(h, MSL_ERR_INVALID, "frame copy: slot %d out of range [0,%d)", slot, c.n_frames);
+    const size_t npix = (size_t)c.nx * c.ny;
+    if (bytes != npix * c.n_probes * sizeof(float2)) return fail(h, MSL_ERR_INVALID, "frame copy: buffer holds %zu bytes, a frame is %zu", bytes, npix * c.n_probes * sizeof(float2));
+    HIPCHK(h, hipSetDevice(c.device));
+    // (P, T, nx, ny) device <-> (P, nx, ny) host: P strided blocks of one image
+    float2* dev = h->wf + (size_t)slot * npix;
+    if (to_host)
+        HIPCHK(h, hipMemcpy2DAsync(host, npix * sizeof(float2), dev, (size_t)c.n_frames * npix * sizeof(float2), npix * sizeof(float2),
+                                   c.n_probes, hipMemcpyDeviceToHost, h->stream));
+    else
+        HIPCHK(h, hipMemcpy2DAsync(dev, (size_t)c.n_frames * npix * sizeof(float2), host, npix * sizeof(float2), npix * sizeof(float2),
+                                   c.n_probes, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return MSL_OK;
+}
+
+int msl_download_frame(msl_handle* h, int32_t slot, void* dst, size_t bytes) { return frame_copy(h, slot, dst, bytes, true); }
+int msl_upload_frame(msl_handle* h, int32_t slot, const void* src, size_t bytes) { return frame_copy(h, slot, const_cast<void*>(src), bytes, false); }
+
 int msl_synchronize(msl_handle* h) {
     if (!h) return fail(h, MSL_ERR_INVALID, "null handle");
     HIPCHK(h, hipSetDevice(h->cfg.device));

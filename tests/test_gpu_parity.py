@@ -486,3 +486,33 @@ def test_k5_tacaw_peaks_at_phonon_frequencies(ps):
     assert spec[np.argmin(np.abs(f))] == 0.0
     assert spec[on].sum() > 0.8 * spec.sum()          # the rest is multi-phonon (sum and difference) weight
     assert spec[on].min() > 20 * np.median(spec[~on])
+
+
+def test_frame_cache_format_and_resume(ps, golden, tmp_path, monkeypatch):
+    """Opt-in frame cache: files named and shaped like the reference's (frame_<i>.npy, (P,nx,ny,1,1) complex128,
+    calculators.py:173, 279, 311); a second run loads them instead of computing (resume)."""
+    g = golden("g7_calculator_64")
+    pos = g["positions"]
+    tr = ps.Trajectory(g["Z"], pos, np.zeros_like(pos), g["box"], 0.005)
+    pp = [tuple(p) for p in g["probe_positions"]]
+    monkeypatch.chdir(tmp_path)
+    calc = ps.MultisliceCalculator(progress=False, cache=True)
+    calc.setup(tr, aperture=float(g["aperture"]), voltage_eV=float(g["eV"]), probe_positions=pp)
+    wf1 = npy(calc.run().wavefunction_data)
+    assert (calc.frames_computed, calc.frames_cached) == (pos.shape[0], 0)
+    files = sorted(calc.output_dir.glob("frame_*.npy"))
+    assert len(files) == pos.shape[0] and str(calc.output_dir).startswith("psi_data/torch_")
+    f0 = np.load(calc.output_dir / "frame_0.npy")
+    assert f0.shape == (len(pp), 64, 64, 1, 1) and f0.dtype == np.complex128
+    assert rel_l2(f0[:, :, :, 0, 0], g["wavefunction_data"][:, 0, :, :, 0]) < WAVE_TOL
+    calc2 = ps.MultisliceCalculator(progress=False, cache=True)
+    calc2.setup(tr, aperture=float(g["aperture"]), voltage_eV=float(g["eV"]), probe_positions=pp)
+    wf2 = npy(calc2.run().wavefunction_data)
+    assert (calc2.frames_computed, calc2.frames_cached) == (0, pos.shape[0])
+    assert np.array_equal(wf1, wf2)
+    # without cache=True nothing is written
+    monkeypatch.chdir(tmp_path / "psi_data")
+    calc3 = ps.MultisliceCalculator(progress=False)
+    calc3.setup(tr, aperture=float(g["aperture"]), voltage_eV=float(g["eV"]), probe_positions=pp)
+    calc3.run()
+    assert not (tmp_path / "psi_data" / "psi_data").exists()
