@@ -241,7 +241,9 @@ struct ColJob {
 };
 // COL_POTENTIAL: epilogue of the potential build, V = Re(x)*scale, out = exp(i sigma V)  (potentials.py:336-342, multislice.py:282)
 // COL_TPOT (with COL_POTENTIAL): every second slice's t is stored transposed, (ny, nx), for the one-pass slice loop
-enum { COL_FWD = 1, COL_MULPX = 2, COL_INV = 4, COL_SHIFT = 8, COL_POTENTIAL = 16, COL_TPOT = 32 };
+// COL_INTENSITY: TACAW epilogue -- DC bin zeroed (== time-mean subtraction), |x|^2 as float into out_real with the
+//                line index fftshifted (tacaw_data.py:94-104); the "columns" are pixels, the lines run along time
+enum { COL_FWD = 1, COL_MULPX = 2, COL_INV = 4, COL_SHIFT = 8, COL_POTENTIAL = 16, COL_TPOT = 32, COL_INTENSITY = 64 };
 
 // Column pass.  Workgroup = 16*R threads owns a tile of 16 neighbouring columns (128-byte row
 // segments in HBM) x N rows: staged into LDS column-major, one R-lane group per column, results
@@ -337,7 +339,13 @@ __global__ void __launch_bounds__(16 * R) col_pass_kernel(ColJob job) {
                 float2 a = cols[(2 * q) * CS + x], b = cols[(2 * q + 1) * CS + x];
                 int xo = x + xshift;
                 if (xo >= N) xo -= N;
-                if (job.flags & COL_POTENTIAL) {
+                if (job.flags & COL_INTENSITY) {
+                    const float ia = (x == 0) ? 0.f : fmaf(a.x, a.x, a.y * a.y), ib = (x == 0) ? 0.f : fmaf(b.x, b.x, b.y * b.y);
+                    int xs = x + N / 2;
+                    if (xs >= N) xs -= N;
+                    *reinterpret_cast<float2*>(job.out_real + p * job.out_image_stride + c0 + 2 * q +
+                                               (long long)xs * job.out_pitch) = make_float2(ia, ib);
+                } else if (job.flags & COL_POTENTIAL) {
                     const float va = a.x * job.scale, vb = b.x * job.scale;
                     if (job.out_real)
                         *reinterpret_cast<float2*>(job.out_real + p * job.out_image_stride + cshift + 2 * q +

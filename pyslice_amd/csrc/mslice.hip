@@ -1090,25 +1090,47 @@ int msl_tacaw(msl_handle* h, const void* d_src, void* d_dst, int64_t batch, int3
     }
     if (T < 2) return fail(h, MSL_ERR_INVALID, "msl_tacaw: needs at least 2 frames (got %d)", T);
     if (batch < 1 || npix < 1) return fail(h, MSL_ERR_INVALID, "msl_tacaw: bad batch/npix");
-    int rc = make_plan(h, h->plan_t, T);
-    if (rc) return rc;
+    if (npix > 0x7fffffffLL) return fail(h, MSL_ERR_UNSUPPORTED, "msl_tacaw: npix too large");
+    const int Rt = (c.fft_path == 0) ? fast_radix(T) : 0;           // 256 or 1024 frames: four-step column kernel
+    const bool fast_t = Rt && (npix % 16 == 0) && npix >= 32 && !getenv("MSL_TACAW_GENERIC");
+    int rc = MSL_OK;
+    float2* tw4_t = nullptr;
+    if (fast_t) {
+        if ((rc = make_tw4(h, &tw4_t, Rt))) return rc;
+    } else if ((rc = make_plan(h, h->plan_t, T))) {
+        return rc;
+    }
     hipEvent_t e0, e1;
     HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
     HIPCHK(h, hipEventRecord(e0, h->stream));
-    LineArgs a;
-    a.in = src; a.out = nullptr; a.out_real = dst;
-    a.n_lines = (long long)batch * npix; a.lines_per_image = (int)npix;
-    if (npix > 0x7fffffffLL) return fail(h, MSL_ERR_UNSUPPORTED, "msl_tacaw: npix too large");
-    a.in_es = a.out_es = npix; a.in_ls = a.out_ls = 1; a.in_is = a.out_is = (long long)T * npix;
-    a.contiguous_lines = 1; a.fft1 = +1; a.store_mode = STORE_INTENSITY; a.shift_n = T / 2;
     h->cur = nullptr;
-    if ((rc = launch_lines(h, h->plan_t, a, K_OTHER))) return rc;
+    if (fast_t) {
+        // time lines are "columns" of a (T, npix) image per probe: 16 neighbouring pixels per tile
+        ColJob j{};
+        j.in = src; j.out = nullptr; j.px = nullptr; j.tw = tw4_t; j.out_real = dst;
+        j.in_image_stride = j.out_image_stride = (long long)T * npix;
+        j.in_pitch = j.out_pitch = (int)npix; j.ny = (int)npix; j.n_images = (int)batch;
+        j.flags = COL_FWD | COL_INTENSITY; j.scale = 1.f;
+        const int saved = h->Rx;
+        h->Rx = Rt;
+        rc = launch_col_fast(h, j, K_OTHER);
+        h->Rx = saved;
+        if (rc) { (void)hipFree(tw4_t); return rc; }
+    } else {
+        LineArgs a;
+        a.in = src; a.out = nullptr; a.out_real = dst;
+        a.n_lines = (long long)batch * npix; a.lines_per_image = (int)npix;
+        a.in_es = a.out_es = npix; a.in_ls = a.out_ls = 1; a.in_is = a.out_is = (long long)T * npix;
+        a.contiguous_lines = 1; a.fft1 = +1; a.store_mode = STORE_INTENSITY; a.shift_n = T / 2;
+        if ((rc = launch_lines(h, h->plan_t, a, K_OTHER))) return rc;
+    }
     HIPCHK(h, hipEventRecord(e1, h->stream));
     HIPCHK(h, hipEventSynchronize(e1));
     float ms = 0.f;
     HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
     h->ctr.ms_tacaw += ms;
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (tw4_t) (void)hipFree(tw4_t);
     return MSL_OK;
 }
 

@@ -6,6 +6,8 @@ SURVEY.md section 8c:
     potential                 max|dV| / max|V| <= 1e-5
     TACAW intensity           rel-L2 <= 2e-4
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -516,3 +518,29 @@ def test_frame_cache_format_and_resume(ps, golden, tmp_path, monkeypatch):
     calc3.setup(tr, aperture=float(g["aperture"]), voltage_eV=float(g["eV"]), probe_positions=pp)
     calc3.run()
     assert not (tmp_path / "psi_data" / "psi_data").exists()
+
+
+def test_tacaw_fourstep_time_axis_256_frames(ps, orc):
+    """T = 256 frames (BASELINE C3's frame count) takes the four-step time-FFT kernel (pixels as columns of a
+    (T, npix) image, DC zeroed, fftshifted |.|^2 epilogue); compare with the oracle and with the generic kernel."""
+    from pyslice_amd.synthetic import synthetic_trajectory
+    tr = synthetic_trajectory(32, 2, 256, density=0.3, seed=13)
+    pp = [(1.6, 1.6), (0.5, 2.5)]
+    calc = ps.MultisliceCalculator(progress=False)
+    calc.setup(tr, aperture=30.0, voltage_eV=100e3, probe_positions=pp)
+    wf = calc.run()
+    data = npy(wf.wavefunction_data)
+    tac = ps.TACAWData(wf)
+    f, inten = orc.tacaw(data, wf.time)
+    got = npy(tac.intensity)
+    assert got.shape == (2, 256, 32, 32)
+    assert np.allclose(tac.frequencies, f)
+    assert rel_l2(got, inten) < TACAW_TOL
+    assert got[:, 128].max() == 0.0
+    os.environ["MSL_TACAW_GENERIC"] = "1"
+    try:
+        calc._engine.tacaw()
+        gen = calc._engine.intensity()
+    finally:
+        del os.environ["MSL_TACAW_GENERIC"]
+    assert rel_l2(got, gen) < 1e-5
