@@ -213,15 +213,23 @@ __global__ void __launch_bounds__(256) structure_factor_mfma_kernel(float2* __re
         f32x16 acc_re = {0}, acc_im = {0};
         const float2* px = ex + (size_t)(a0 + kk) * nx + kx0 + i;
         const float2* py = ey + (size_t)(a0 + kk) * ny + ky0 + i;
-        // 8 atoms (4 MFMA k-steps) per trip: all eight loads are issued before the sixteen MFMAs consume them
-        for (int a = a0 + kk; a < a1 + kk; a += 8) {           // same trip count for both lane halves
-            float2 x[4], y[4];
+        // 8 atoms (4 MFMA k-steps) per trip, software-pipelined: the loads of trip i+1 are in flight while the
+        // sixteen MFMAs of trip i run (matrix pipe 49 % -> 61 % busy; a 32 x 64 block per wave was slower: occupancy)
+        auto load8 = [&](int a, float2 (&x)[4], float2 (&y)[4]) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 x[u] = make_float2(0.f, 0.f); y[u] = make_float2(0.f, 0.f);
                 if (a + 2 * u < a1) { x[u] = px[(size_t)(2 * u) * nx]; y[u] = py[(size_t)(2 * u) * ny]; }
             }
             px += 8 * (size_t)nx; py += 8 * (size_t)ny;
+        };
+        float2 xn[4], yn[4];
+        load8(a0 + kk, xn, yn);
+        for (int a = a0 + kk; a < a1 + kk; a += 8) {           // same trip count for both lane halves
+            float2 x[4], y[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { x[u] = xn[u]; y[u] = yn[u]; }
+            load8(a + 8, xn, yn);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 acc_re = __builtin_amdgcn_mfma_f32_32x32x2f32(x[u].x, y[u].x, acc_re, 0, 0, 0);
