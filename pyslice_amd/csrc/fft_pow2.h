@@ -39,14 +39,14 @@ __device__ __forceinline__ void lds_barrier() {
 
 // Multiply v[j] (j = J0..R-1) by tab[j*R + ln] (conjugated when CONJ) in chunks of 8 with a scheduling
 // barrier between chunks, so the compiler cannot hoist all R table loads at once (register pressure).
-template <int R, int J0, bool CONJ, typename TabPtr>
+template <int R, int J0, bool CONJ, int STRIDE = R, typename TabPtr>
 __device__ __forceinline__ void mul_table(float2 (&v)[R], TabPtr tab, int ln) {
     constexpr int CH = 8;
 #pragma unroll
     for (int c = 0; c < R; c += CH) {
         float2 w[CH];
 #pragma unroll
-        for (int j = 0; j < CH; ++j) if (c + j >= J0) w[j] = tab[(c + j) * R + ln];
+        for (int j = 0; j < CH; ++j) if (c + j >= J0) w[j] = tab[(c + j) * STRIDE + ln];
 #pragma unroll
         for (int j = 0; j < CH; ++j) if (c + j >= J0) v[c + j] = CONJ ? cmulf_conj(v[c + j], w[j]) : cmulf(v[c + j], w[j]);
         __builtin_amdgcn_sched_barrier(0);
@@ -464,8 +464,9 @@ struct RowTJob {
     const float2* in;       // (P, n_lines, in_pitch): lines along the transform axis
     float2* out;            // (P, N, out_pitch): transposed
     const float2* trans;    // t_k in the input orientation, (n_lines, N) unpadded
-    const float2* pl;       // (N) Fresnel factor along the line axis, 1/N folded in
+    const float2* pl;       // (N) Fresnel factor along the line axis, 1/N folded in (split order for N = 2R^2)
     const float2* tw;
+    const float2* tw2;      // N = 2R^2 only: W_N^m, m < R^2
     long long in_image_stride, out_image_stride;
     int in_pitch, out_pitch, n_lines, n_images, flags, pchunk;
 };
@@ -556,6 +557,165 @@ __global__ void __launch_bounds__(LINES * R) rowT_pass_kernel(RowTJob job) {
         }
         lds_barrier();
         item = nitem; k = nk;
+    }
+}
+
+// ---- lines of N = 2 R^2 points (512 = 2*16^2, 2048 = 2*32^2) ----------------------------------------------
+// One radix-2 step wrapped around two four-step transforms.  A group of R lanes holds two register sets; in the
+// natural domain set b, register j, lane l is element b*R^2 + j*R + l.  The forward transform is decimation in
+// frequency (a = x0 + x1, d = (x0 - x1) W_N^m, then N/2-point transforms of a and d give X[2k] and X[2k+1]); the
+// inverse is the mirror decimation in time.  The frequency domain therefore lives in "split" order -- set b, slot k
+// holds X[2k+b] -- which never leaves the kernel: the propagator table is stored in the same order.
+template <int R, bool INV>
+__device__ __forceinline__ void line2_transform(float2 (&v)[2 * R], float* scratch, const float2* tw, const float2* tw2, int ln) {
+    float2 (&lo)[R] = reinterpret_cast<float2 (&)[R]>(v[0]);
+    float2 (&hi)[R] = reinterpret_cast<float2 (&)[R]>(v[R]);
+    constexpr int CH = 8;                              // table chunks with scheduling barriers: see mul_table
+    if constexpr (!INV) {
+#pragma unroll
+        for (int c = 0; c < R; c += CH) {
+            float2 w[CH];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) w[j] = tw2[(c + j) * R + ln];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const float2 a = v[c + j], b = v[R + c + j];
+                v[c + j] = make_float2(a.x + b.x, a.y + b.y);
+                v[R + c + j] = cmulf(make_float2(a.x - b.x, a.y - b.y), w[j]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        fourstep_split<R, false>(lo, scratch, tw, ln);
+        __builtin_amdgcn_sched_barrier(0);
+        fourstep_split<R, false>(hi, scratch, tw, ln);
+    } else {
+        fourstep_split<R, true>(lo, scratch, tw, ln);
+        __builtin_amdgcn_sched_barrier(0);
+        fourstep_split<R, true>(hi, scratch, tw, ln);
+#pragma unroll
+        for (int c = 0; c < R; c += CH) {
+            float2 w[CH];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) w[j] = tw2[(c + j) * R + ln];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const float2 e = v[c + j], o = cmulf_conj(v[R + c + j], w[j]);
+                v[c + j] = make_float2(e.x + o.x, e.y + o.y);
+                v[R + c + j] = make_float2(e.x - o.x, e.y - o.y);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// Transposing pass A . t_k . A for N = 2 R^2.  R = 16 (N = 512): next line prefetched and t_k kept in registers like
+// rowT_pass_kernel, full-line tile.  R = 32 (N = 2048): a line is 64 complex per lane, so neither fits; t_k comes from
+// L2 per line and the transposed store goes through the tile in two position halves (set 0, set 1).
+template <int R>
+__global__ void __launch_bounds__(16 * R) rowT2_pass_kernel(RowTJob job) {
+    constexpr int N2 = R * R, N = 2 * N2, NT = 16 * R;
+    constexpr bool BIG = (R == 32);
+    constexpr int CPOS = BIG ? N2 : N;                 // positions per store chunk
+    constexpr int NCHUNK = N / CPOS;
+    constexpr int CS = CPOS + 1;                       // tile line pitch (odd)
+    constexpr int POS_PER_IT = NT / 8;
+    constexpr int NIT = CPOS / POS_PER_IT;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float2* tw = reinterpret_cast<float2*>(smem_raw);            // N2: four-step twiddles
+    float2* tw2 = tw + N2;                                       // N2: W_N^m of the outer radix-2 step
+    float2* pl_lds = tw2 + N2;                                   // N (small variant only): propagator, split order
+    float2* tile = BIG ? pl_lds : pl_lds + N;                    // 16 * CS, also the groups' transpose scratch
+    const int tid = threadIdx.x;
+    for (int i = tid; i < N2; i += NT) { tw[i] = job.tw[i]; tw2[i] = job.tw2[i]; }
+    if (!BIG) for (int i = tid; i < N; i += NT) pl_lds[i] = job.pl[i];
+    const float2* pl = BIG ? job.pl : pl_lds;
+    __syncthreads();
+    const int grp = tid / R, ln = tid % R;
+    const int q = tid & 7, r0 = tid >> 3;
+    float* scratch = reinterpret_cast<float*>(tile + grp * CS);
+    const int lblocks = job.n_lines / 16;
+    const int PC = BIG ? 1 : job.pchunk;
+    const int pchunks = (job.n_images + PC - 1) / PC;
+    const int n_items = lblocks * pchunks;
+    const int step_lb = (int)gridDim.x / pchunks, step_pc = (int)gridDim.x % pchunks;
+    int item = blockIdx.x;
+    int lb = item / pchunks, pc = item % pchunks, k = 0;
+    const int in_off = grp * job.in_pitch + ln;
+    const int t_off = grp * N + ln;
+    auto block_base = [&](int lbb, int pcc, int kk) {
+        return job.in + ((long long)(pcc * PC + kk) * job.in_image_stride + (long long)lbb * 16 * job.in_pitch);
+    };
+    float2 vn[BIG ? 1 : 2 * R];
+    float2 tv[BIG ? 1 : 2 * R];
+    if (!BIG && item < n_items) {
+        const float2* r = block_base(lb, pc, 0);
+#pragma unroll
+        for (int j = 0; j < 2 * R; ++j) vn[j] = r[in_off + j * R];
+    }
+    while (item < n_items) {
+        float2 v[2 * R];
+        if constexpr (BIG) {
+            const float2* r = block_base(lb, pc, k);
+#pragma unroll
+            for (int j = 0; j < 2 * R; ++j) v[j] = r[in_off + j * R];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2 * R; ++j) v[j] = vn[j];
+        }
+        const int p = pc * PC + k;
+        const int cur_lb = lb;
+        if (!BIG && k == 0) {
+            const float2* trow = job.trans + (long long)lb * 16 * N;
+#pragma unroll
+            for (int j = 0; j < 2 * R; ++j) tv[j] = trow[t_off + j * R];
+        }
+        int nitem = item, nlb = lb, npc = pc, nk = k + 1;
+        if (nk >= min(PC, job.n_images - pc * PC)) {
+            nk = 0; nitem = item + (int)gridDim.x; nlb = lb + step_lb; npc = pc + step_pc;
+            if (npc >= pchunks) { npc -= pchunks; ++nlb; }
+        }
+        if (!BIG && nitem < n_items) {
+            const float2* r = block_base(nlb, npc, nk);
+#pragma unroll
+            for (int j = 0; j < 2 * R; ++j) vn[j] = r[in_off + j * R];
+        }
+        if (job.flags & P2_PRE_A) {
+            line2_transform<R, false>(v, scratch, tw, tw2, ln);
+            mul_table<2 * R, 0, false, R>(v, pl, ln);
+            line2_transform<R, true>(v, scratch, tw, tw2, ln);
+        }
+        if constexpr (BIG) {
+            mul_table<2 * R, 0, false, R>(v, job.trans + (long long)lb * 16 * N + grp * N, ln);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2 * R; ++j) v[j] = cmulf(v[j], tv[j]);
+        }
+        if (job.flags & P2_POST_A) {
+            line2_transform<R, false>(v, scratch, tw, tw2, ln);
+            mul_table<2 * R, 0, false, R>(v, pl, ln);
+            line2_transform<R, true>(v, scratch, tw, tw2, ln);
+        }
+        float2* dst = job.out + ((long long)p * job.out_image_stride + cur_lb * 16);
+        int off0 = 2 * q + r0 * job.out_pitch;
+        asm volatile("" : "+v"(off0));
+        const int ostep = POS_PER_IT * job.out_pitch;
+#pragma unroll
+        for (int c = 0; c < NCHUNK; ++c) {
+            if (c > 0) lds_barrier();                  // the previous chunk has been read out
+            wave_lds_fence();
+            float2* myrow = tile + grp * CS;
+#pragma unroll
+            for (int j = 0; j < CPOS / R; ++j) myrow[j * R + ln] = v[c * (CPOS / R) + j];
+            lds_barrier();
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) {
+                const int pos = r0 + POS_PER_IT * i;
+                const float2 a = tile[(2 * q) * CS + pos], b = tile[(2 * q + 1) * CS + pos];
+                *reinterpret_cast<float4*>(dst + (off0 + (c * NIT + i) * ostep)) = make_float4(a.x, a.y, b.x, b.y);
+            }
+        }
+        lds_barrier();
+        item = nitem; lb = nlb; pc = npc; k = nk;
     }
 }
 

@@ -58,6 +58,9 @@ struct msl_handle {
     // one-pass-per-slice path (transposing passes): second work buffer in (P, ny, nx+pad) layout, transposed
     // probes and the transposed transmission slices
     bool onepass = false;
+    bool scheme_b = false;         // a direction of 2R^2 points: every pass transposes, first pass along y, final transpose if nz is odd
+    // one-pass capability per direction: R (0 = none), two = line length 2 R^2, tables (tw2 / ptab only for two)
+    struct OpDir { int R = 0; bool two = false; float2* tw = nullptr; float2* tw2 = nullptr; float2* ptab = nullptr; } opx, opy;
     float2* psiT = nullptr;
     float2* psi0T = nullptr;
     float2* transT = nullptr;
@@ -448,7 +451,7 @@ int fft2_inplace(msl_handle* h, float2* buf, int images, int dir, float scale, i
 // ---- one-pass-per-slice path ------------------------------------------------------------------------
 // psi0 (P, nx, pitch) -> psi0T (P, ny, pitchT): needed when the first pass of the slice loop runs along x
 int transpose_probes(msl_handle* h) {
-    if (!h->onepass) return MSL_OK;
+    if (!h->onepass || h->scheme_b) return MSL_OK;          // scheme B always starts along y, on layout A
     const msl_config& c = h->cfg;
     dim3 grid((c.ny + 31) / 32, (c.nx + 31) / 32, c.n_probes);
     hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, h->stream, h->psi0, h->psi0T, c.nx, c.ny, h->pitch, h->pitchT,
@@ -458,7 +461,10 @@ int transpose_probes(msl_handle* h) {
 }
 
 // slice s is used by a pass along x (needs t transposed) iff its distance to the last slice is odd
-inline bool slice_is_transposed(const msl_handle* h, int s) { return h->onepass && (((h->cfg.nz - 1 - s) & 1) != 0); }
+inline bool slice_is_transposed(const msl_handle* h, int s) {
+    if (!h->onepass) return false;
+    return h->scheme_b ? ((s & 1) != 0) : (((h->cfg.nz - 1 - s) & 1) != 0);
+}
 
 // natural t (nz,nx,ny) -> transposed copies of the odd-distance slices in transT (upload / set_beam paths)
 int transpose_odd_slices(msl_handle* h) {
@@ -500,6 +506,101 @@ int launch_rowT_r(msl_handle* h, RowTJob job, int kind) {
     return h->rowT_variant == 1 ? launch_rowT_v<R, 16, true>(h, job, kind) : launch_rowT_v<R, 16, false>(h, job, kind);
 }
 
+// lines of 2 R^2 points (512, 2048)
+template <int R>
+int launch_rowT2_r(msl_handle* h, RowTJob job, int kind) {
+    constexpr int N2 = R * R, N = 2 * N2;
+    constexpr bool BIG = (R == 32);
+    const size_t lds = BIG ? ((size_t)2 * N2 + (size_t)16 * (N2 + 1)) * 8 : ((size_t)2 * N2 + N + (size_t)16 * (N + 1)) * 8;
+    const int per_cu = std::max(1, std::min(2, (int)((size_t)h->lds_limit / lds)));
+    const long long slots = (long long)h->n_cus * per_cu;
+    const long long lb = job.n_lines / 16;
+    int pc = BIG ? 1 : job.n_images;
+    while (pc > 1 && lb * ((job.n_images + pc - 1) / pc) < slots) pc = (pc + 1) / 2;
+    if (!BIG && h->row_pchunk > 0) pc = std::min(h->row_pchunk, job.n_images);
+    job.pchunk = pc;
+    const long long items = lb * ((job.n_images + pc - 1) / pc);
+    const int grid = (int)std::min<long long>(items, slots);
+    (void)hipFuncSetAttribute((const void*)rowT2_pass_kernel<R>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
+    hipLaunchKernelGGL(rowT2_pass_kernel<R>, dim3(grid), dim3(16 * R), lds, h->stream, job);
+    HIPCHK(h, hipGetLastError());
+    return mark_launch(h, kind);
+}
+
+// one transposing pass along direction `o` (either line length R^2 or 2 R^2)
+int launch_rowT_dir(msl_handle* h, const msl_handle::OpDir& o, RowTJob job, int kind) {
+    job.tw = o.tw;
+    if (o.two) {
+        job.tw2 = o.tw2; job.pl = o.ptab;
+        return o.R == 32 ? launch_rowT2_r<32>(h, job, kind) : launch_rowT2_r<16>(h, job, kind);
+    }
+    return o.R == 32 ? launch_rowT_r<32>(h, job, kind) : launch_rowT_r<16>(h, job, kind);
+}
+
+// Slice loop when a grid length is 2 R^2: every pass transposes (there is no in-place kernel for those lengths).
+// Pass k runs along y for even k and along x for odd k; after an odd number of slices one transpose brings the
+// waves back to layout A, and the exit FFT is the stand-alone two-pass one.
+int slice_loop_onepass_b(msl_handle* h, int fused_slot) {
+    const msl_config& c = h->cfg;
+    const int P = c.n_probes, nz = c.nz;
+    const size_t npix = (size_t)c.nx * c.ny;
+    const long long isA = (long long)c.nx * h->pitch, isB = (long long)c.ny * h->pitchT;
+    const bool fused = fused_slot >= 0;
+    int rc;
+    if ((rc = begin_timed(h, nz + 4))) return rc;
+    for (int k = 0; k < nz; ++k) {
+        RowTJob j{};
+        j.flags = (k > 0 ? P2_PRE_A : 0) | (k < nz - 1 ? P2_POST_A : 0);
+        if (h->debug_flags_mask >= 0) j.flags &= h->debug_flags_mask;
+        j.n_images = P;
+        if (!(k & 1)) {
+            j.in = (k == 0) ? h->psi0 : h->psi; j.out = h->psiT;
+            j.trans = h->trans + (size_t)k * npix; j.pl = h->pyt;
+            j.in_image_stride = isA; j.out_image_stride = isB; j.in_pitch = h->pitch; j.out_pitch = h->pitchT; j.n_lines = c.nx;
+            rc = launch_rowT_dir(h, h->opy, j, K_ROW);
+        } else {
+            j.in = h->psiT; j.out = h->psi;
+            j.trans = h->transT + (size_t)k * npix; j.pl = h->pxt;
+            j.in_image_stride = isB; j.out_image_stride = isA; j.in_pitch = h->pitchT; j.out_pitch = h->pitch; j.n_lines = c.ny;
+            rc = launch_rowT_dir(h, h->opx, j, K_COL);
+        }
+        if (rc) return rc;
+    }
+    if (nz & 1) {
+        dim3 grid((c.nx + 31) / 32, (c.ny + 31) / 32, P);
+        hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, h->stream, h->psiT, h->psi, c.ny, c.nx, h->pitchT, h->pitch, isB, isA);
+        HIPCHK(h, hipGetLastError());
+        if ((rc = mark_launch(h, K_OTHER))) return rc;
+    }
+    if (fused) {
+        if (h->Ry) {
+            RowJob r = row_job(h, h->psi, P, h->pitch);
+            r.do_fft = true;
+            if ((rc = launch_row_fast(h, r, K_OTHER))) return rc;
+        } else {
+            LineArgs r = row_args(h, h->psi, h->psi, P, h->pitch);
+            r.fft1 = +1;
+            if ((rc = launch_lines(h, h->plan_y, r, K_OTHER))) return rc;
+        }
+        if (h->Rx) {
+            ColJob k = col_job(h, h->psi, h->wf + (size_t)fused_slot * npix, P, h->pitch, c.ny);
+            k.flags = COL_FWD | COL_SHIFT; k.out_image_stride = (long long)c.n_frames * npix;
+            if ((rc = launch_col_fast(h, k, K_OTHER))) return rc;
+        } else {
+            LineArgs k = col_args(h, h->psi, h->wf + (size_t)fused_slot * npix, P, h->pitch, c.ny);
+            k.fft1 = +1;
+            k.out_is = (long long)c.n_frames * npix;
+            k.shift_n = c.nx / 2; k.shift_r = c.ny / 2;
+            if ((rc = launch_lines(h, h->plan_x, k, K_OTHER))) return rc;
+        }
+    }
+    h->cur = nullptr;
+    h->ctr.slice_steps += (uint64_t)P * nz;
+    h->ctr.frames += 1;
+    h->ctr.algorithmic_bytes += (uint64_t)P * nz * 16ull * npix + (uint64_t)nz * 8ull * npix + (fused ? (uint64_t)P * 16ull * npix : 0ull);
+    return MSL_OK;
+}
+
 template <int R>
 int launch_row2_r(msl_handle* h, Row2Job job, int kind) {
     constexpr int N = R * R, G = 256 / R;
@@ -521,6 +622,7 @@ int launch_row2_r(msl_handle* h, Row2Job job, int kind) {
 // Slice loop with one HBM pass per slice (see fft_pow2.h).  Pass k runs along y when its distance to the last
 // slice is even, else along x; all passes but the last write transposed, the last one is in place on layout A.
 int slice_loop_onepass(msl_handle* h, int fused_slot) {
+    if (h->scheme_b) return slice_loop_onepass_b(h, fused_slot);
     const msl_config& c = h->cfg;
     const int P = c.n_probes, nz = c.nz;
     const size_t npix = (size_t)c.nx * c.ny;
@@ -662,7 +764,26 @@ int fill_propagator(msl_handle* h) {
     };
     int rc = fill(h->pxt, c.nx, c.dx);
     if (rc) return rc;
-    return fill(h->pyt, c.ny, c.dy);
+    if ((rc = fill(h->pyt, c.ny, c.dy))) return rc;
+    // split-order copies for the 2R^2 kernels: entry [b*R^2 + k] = P[2k + b]
+    auto fill_split = [&](float2* dst, int n, double d) -> int {
+        if (!dst) return MSL_OK;
+        std::vector<float2> v(n);
+        for (int b = 0; b < 2; ++b)
+            for (int k = 0; k < n / 2; ++k) {
+                const int m = 2 * k + b;
+                const int f = (m < (n + 1) / 2) ? m : m - n;
+                const double kk = f * (1.0 / (n * d));
+                const double ph = -M_PI * c.wavelength * c.dz * kk * kk;
+                v[b * (n / 2) + k] = make_float2((float)(cos(ph) / n), (float)(sin(ph) / n));
+            }
+        HIPCHK(h, hipMemcpyAsync(dst, v.data(), n * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        return MSL_OK;
+    };
+    if (h->opx.two && (rc = fill_split(h->opx.ptab, c.nx, c.dx))) return rc;
+    if (h->opy.two && (rc = fill_split(h->opy.ptab, c.ny, c.dy))) return rc;
+    return MSL_OK;
 }
 
 }  // namespace
@@ -724,12 +845,33 @@ int msl_create(const msl_config* cfg, msl_handle** out) {
         if (pad < 0 || (pad & 1)) pad = 16;
         h->pitch = cfg->ny + ((h->Rx || h->Ry) ? pad : 0);
     }
-    if ((rc = dalloc(h, &h->psi0, (size_t)cfg->nx * h->pitch * cfg->n_probes))) return bail(rc);
-    if ((rc = dalloc(h, &h->psi, (size_t)cfg->nx * h->pitch * cfg->n_probes))) return bail(rc);
     {
         const char* e = getenv("MSL_SLICE_PATH");           // 2 = force the two-pass four-step loop
         const bool want = cfg->fft_path == 0 && !(e && atoi(e) == 2);
-        h->onepass = want && h->Rx && h->Ry && cfg->nx % 16 == 0 && cfg->ny % 16 == 0 && !cfg->keep_potential;
+        auto setup_dir = [&](msl_handle::OpDir& o, int n, int Rfast, float2* tw4) -> int {
+            if (Rfast) { o.R = Rfast; o.two = false; o.tw = tw4; return MSL_OK; }
+            const int R2 = (n == 512) ? 16 : (n == 2048 ? 32 : 0);
+            if (!R2 || !want || getenv("MSL_NO_TWO")) return MSL_OK;
+            o.R = R2; o.two = true;
+            int r = make_tw4(h, &o.tw, R2);
+            if (r) return r;
+            std::vector<float2> t(R2 * R2);
+            for (int m = 0; m < R2 * R2; ++m) {
+                const double a = -2.0 * M_PI * (double)m / (double)n;
+                t[m] = make_float2((float)cos(a), (float)sin(a));
+            }
+            if ((r = dalloc(h, &o.tw2, (size_t)R2 * R2))) return r;
+            if (hipMemcpy(o.tw2, t.data(), t.size() * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess)
+                return fail(h, MSL_ERR_HIP, "twiddle upload failed");
+            return dalloc(h, &o.ptab, (size_t)n);
+        };
+        if ((rc = setup_dir(h->opx, cfg->nx, h->Rx, h->tw4_x))) return bail(rc);
+        if ((rc = setup_dir(h->opy, cfg->ny, h->Ry, h->tw4_y))) return bail(rc);
+        h->onepass = want && h->opx.R && h->opy.R && cfg->nx % 16 == 0 && cfg->ny % 16 == 0 && !cfg->keep_potential;
+        h->scheme_b = h->onepass && (h->opx.two || h->opy.two);
+        if (h->pitch == cfg->ny && h->onepass) h->pitch = cfg->ny + 16;        // pad the work buffers of 2R^2 grids too
+        if ((rc = dalloc(h, &h->psi0, (size_t)cfg->nx * h->pitch * cfg->n_probes))) return bail(rc);
+        if ((rc = dalloc(h, &h->psi, (size_t)cfg->nx * h->pitch * cfg->n_probes))) return bail(rc);
         if (h->onepass) {
             h->pitchT = cfg->nx + (h->pitch - cfg->ny);
             if ((rc = dalloc(h, &h->psiT, (size_t)cfg->ny * h->pitchT * cfg->n_probes))) return bail(rc);
@@ -769,7 +911,8 @@ int msl_destroy(msl_handle* h) {
     void* bufs[] = {h->psi0, h->psi, h->trans, h->V, h->wf, h->intensity, h->pxt, h->pyt, h->d_abcd, h->d_lo, h->d_hi,
                     h->d_pos, h->d_Z, h->d_key, h->d_order, h->d_u1, h->d_u2, h->d_ex, h->d_ey, h->d_counts, h->d_start,
                     h->d_z2s, h->d_species, h->d_ff, h->d_xy, h->plan_x.tw, h->plan_y.tw, h->plan_t.tw, h->tw4_x, h->tw4_y,
-                    h->psiT, h->psi0T, h->transT, h->plan_x.chirp, h->plan_x.bfilt, h->plan_y.chirp, h->plan_y.bfilt, h->plan_t.chirp, h->plan_t.bfilt};
+                    h->psiT, h->psi0T, h->transT, h->opx.tw2, h->opx.ptab, h->opy.tw2, h->opy.ptab,
+                    (h->opx.two ? h->opx.tw : nullptr), (h->opy.two ? h->opy.tw : nullptr), h->plan_x.chirp, h->plan_x.bfilt, h->plan_y.chirp, h->plan_y.bfilt, h->plan_t.chirp, h->plan_t.bfilt};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -999,7 +1142,7 @@ int msl_build_potential(msl_handle* h, const double* pos, const int32_t* Z, int6
     if (h->Rx) {
         ColJob k = col_job(h, h->trans, h->trans, c.nz, c.ny, c.ny);
         k.flags = COL_INV | COL_POTENTIAL; k.scale = vscale; k.sigma = (float)c.sigma; k.out_real = h->V;
-        if (h->onepass) { k.flags |= COL_TPOT; k.tparity = (c.nz - 1) & 1; k.out_t = h->transT; }
+        if (h->onepass) { k.flags |= COL_TPOT; k.tparity = h->scheme_b ? 0 : ((c.nz - 1) & 1); k.out_t = h->transT; }
         if ((rc = launch_col_fast(h, k, K_OTHER))) return rc;
     } else {
         LineArgs k = col_args(h, h->trans, h->trans, c.nz, c.ny, c.ny);
@@ -1007,6 +1150,7 @@ int msl_build_potential(msl_handle* h, const double* pos, const int32_t* Z, int6
         k.scale = vscale;
         k.store_mode = STORE_POTENTIAL; k.out_real = h->V; k.sigma = (float)c.sigma;
         if ((rc = launch_lines(h, h->plan_x, k, K_OTHER))) return rc;
+        if ((rc = transpose_odd_slices(h))) return rc;          // one-pass loop on a 2R^2 grid: x-pass slices transposed
     }
     HIPCHK(h, hipEventRecord(e1, h->stream));
     HIPCHK(h, hipEventSynchronize(e1));

@@ -307,6 +307,28 @@ def test_calculator_oracle_parity_onepass_nonsquare(ps, orc):
     assert ref_residual(got, want) < RESID_TOL
 
 
+@pytest.mark.parametrize("nx,ny,nz,P", [(512, 512, 5, 3), (512, 512, 4, 2), (512, 512, 1, 2), (1024, 512, 3, 2),
+                                         (512, 256, 6, 2), (2048, 256, 4, 2), (256, 2048, 3, 2), (2048, 2048, 3, 1)])
+def test_calculator_oracle_parity_onepass_2r2_lengths(ps, orc, nx, ny, nz, P):
+    """Grid lengths 512 = 2*16^2 and 2048 = 2*32^2: one transposing pass per slice with a radix-2 step around the
+    four-step transform; passes start along y, an odd slice count ends with one plain transpose."""
+    from pyslice_amd.synthetic import synthetic_trajectory
+    from pyslice_amd import _native
+    tr = synthetic_trajectory(nx, nz, 1, ny=ny, density=0.02 if nx * ny < 2 ** 21 else 0.004, seed=41 + nz)
+    xs, ys, zs, lx, ly, lz = ps.gridFromTrajectory(tr)
+    assert (len(xs), len(ys), len(zs)) == (nx, ny, nz)
+    pp = [(lx / 2, ly / 2), (3.3, 0.4 * ly), (0.7 * lx, 5.0)][:P]
+    calc = ps.MultisliceCalculator(progress=False)
+    calc.setup(tr, aperture=30.0, voltage_eV=100e3, probe_positions=pp)
+    got = npy(calc.run().wavefunction_data)
+    want = orc.run_frames(tr.box_matrix, tr.positions, tr.atom_types, 30.0, 100e3, pp)["wavefunction_data"]
+    assert rel_l2(got, want) < WAVE_TOL
+    assert ref_residual(got, want) < RESID_TOL
+    t = calc._engine.download(_native.BUF_TRANSMISSION, np.complex64, (nz, nx, ny))
+    V = orc.potential(xs, ys, zs, tr.positions[-1], tr.atom_types)
+    assert rel_l2(t, np.exp(1j * orc.interaction_sigma(100e3) * np.moveaxis(V, 2, 0))) < 1e-4
+
+
 def test_oracle_parity_prime_grid(ps, orc):
     """Grid lengths with large prime factors (101 x 97, like the reference's 501 x 491 probe test grid) take the
     Bluestein path; potential, probes and slice loop must still match the oracle."""
