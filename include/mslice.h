@@ -148,6 +148,29 @@ int  msl_propagate_frame(msl_handle* h, int32_t slot);
  * Replaces TACAWData.fft_from_wf_data (tacaw_data.py:89-104). */
 int  msl_tacaw(msl_handle* h, const void* d_src_c64, void* d_dst_f32, int64_t batch, int32_t T, int64_t npix);
 
+/* ---- consumers of the resident results: reductions that stream the array once on the device ----
+ * The TACAW reductions take a (B,F,K) float32 intensity array: d_src == NULL selects the handle's own intensity buffer
+ * (B=P, F=T, K=nx*ny, after msl_tacaw); otherwise a caller-held device pointer with the given shape.  Results are
+ * written to HOST memory; sums are accumulated in float64 like the reference's.
+ *
+ * msl_tacaw_spectrum: out[b*F+f] = sum_k w(k) I[b,f,k], w = 1 or mask[k] != 0 (mask: K host bytes or NULL).
+ *   Replaces the k-space sums of TACAWData.spectrum (tacaw_data.py:109-143), spectrum_image (:145-179) and
+ *   masked_spectrum (:256-300); the mean over probes / the frequency pick is a lookup in the (B,F) result. */
+int  msl_tacaw_spectrum(msl_handle* h, const void* d_src_f32, int64_t B, int64_t F, int64_t K, const uint8_t* mask, double* out);
+/* msl_tacaw_diffraction: out[k] = scale * sum_{b0<=b<b1} sum_{f0<=f<f1} I[b,f,k]   (K float64).
+ *   Replaces TACAWData.diffraction (tacaw_data.py:183-217: all f, one probe or scale=1/P over all probes) and
+ *   spectral_diffraction (:219-254: one f). */
+int  msl_tacaw_diffraction(msl_handle* h, const void* d_src_f32, int64_t B, int64_t F, int64_t K, int64_t b0, int64_t b1,
+                           int64_t f0, int64_t f1, double scale, double* out);
+/* msl_tacaw_dispersion: out[(b*F+f)*n + i] = I[b,f,idx[i]] for n flat k indices (kx*ny+ky) along a path (float32).
+ *   Replaces the gather loop of TACAWData.dispersion (tacaw_data.py:302-353). */
+int  msl_tacaw_dispersion(msl_handle* h, const void* d_src_f32, int64_t B, int64_t F, int64_t K, const int64_t* idx, int64_t n,
+                          float* out);
+/* msl_adf: out[b] = mean_t sum_k w(k) |Psi[b,t,k]| over a (B,T,K) complex64 array (NULL: the handle's wavefunction
+ *   buffer); mask = the annulus q > collection_angle*1e-3/lambda as K host bytes.
+ *   Replaces the masked |.| sum and frame mean of HAADFData.calculateADF (haadf_data.py:72-94). */
+int  msl_adf(msl_handle* h, const void* d_src_c64, int64_t B, int64_t T, int64_t K, const uint8_t* mask, double* out);
+
 /* Copy a device buffer to the host (dst must hold `bytes` = full buffer size, see msl_buffer_bytes).
  * For MSL_BUF_WAVEFUNCTION `first`/`count` select a probe range (count==0: all). */
 int  msl_download(msl_handle* h, msl_buffer what, void* dst, size_t bytes, int64_t first, int64_t count);

@@ -23,6 +23,7 @@ EXPORTS = [
     "msl_download", "msl_download_frame", "msl_upload_frame", "msl_buffer_bytes", "msl_device_ptr", "msl_synchronize",
     "msl_get_counters",
     "msl_reset_counters", "msl_fft2_host",
+    "msl_tacaw_spectrum", "msl_tacaw_diffraction", "msl_tacaw_dispersion", "msl_adf",
 ]
 
 
@@ -83,6 +84,10 @@ def load():
         "msl_get_counters": (C.c_int, [vp, C.POINTER(MslCounters)]),
         "msl_reset_counters": (C.c_int, [vp]),
         "msl_fft2_host": (C.c_int, [vp, vp, vp, i32, i32]),
+        "msl_tacaw_spectrum": (C.c_int, [vp, vp, i64, i64, i64, vp, vp]),
+        "msl_tacaw_diffraction": (C.c_int, [vp, vp, i64, i64, i64, i64, i64, i64, i64, dbl, vp]),
+        "msl_tacaw_dispersion": (C.c_int, [vp, vp, i64, i64, i64, vp, i64, vp]),
+        "msl_adf": (C.c_int, [vp, vp, i64, i64, i64, vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -211,6 +216,60 @@ class Engine:
     def tacaw(self, src_ptr=None, dst_ptr=None, batch=0, T=0, npix=0):
         self._chk(self._lib.msl_tacaw(self._h, C.c_void_p(src_ptr) if src_ptr else None,
                                       C.c_void_p(dst_ptr) if dst_ptr else None, int(batch), int(T), int(npix)))
+
+    # -- reductions over resident results; src = (device pointer, B, F, K) or None for the handle's own buffer
+    @staticmethod
+    def _src(src):
+        if src is None:
+            return None, 0, 0, 0
+        ptr, B, F, K = src
+        return C.c_void_p(int(ptr)), int(B), int(F), int(K)
+
+    def _bfk(self, src):
+        return (self.n_probes, self.n_frames, self.nx * self.ny) if src is None else tuple(int(v) for v in src[1:])
+
+    def tacaw_spectrum(self, mask=None, src=None):
+        """(B,F) float64: sum over k of the (masked) intensity."""
+        B, F, K = self._bfk(src)
+        m = None
+        if mask is not None:
+            m = np.ascontiguousarray(np.asarray(mask).reshape(-1) != 0, dtype=np.uint8)
+            if m.size != K:
+                raise ValueError(f"mask has {m.size} entries, k-space has {K}")
+        out = np.empty((B, F), dtype=np.float64)
+        p, b, f, k = self._src(src)
+        self._chk(self._lib.msl_tacaw_spectrum(self._h, p, b, f, k, _ptr(m) if m is not None else None, _ptr(out)))
+        return out
+
+    def tacaw_diffraction(self, probes=None, freqs=None, scale=1.0, src=None):
+        """(K,) float64: scale * sum of I[b,f,:] over the half-open probe and frequency ranges (None = all)."""
+        B, F, K = self._bfk(src)
+        b0, b1 = (0, B) if probes is None else probes
+        f0, f1 = (0, F) if freqs is None else freqs
+        out = np.empty(K, dtype=np.float64)
+        p, b, f, k = self._src(src)
+        self._chk(self._lib.msl_tacaw_diffraction(self._h, p, b, f, k, int(b0), int(b1), int(f0), int(f1), float(scale), _ptr(out)))
+        return out
+
+    def tacaw_dispersion(self, flat_indices, src=None):
+        """(B,F,n) float32: I[b,f,idx[i]] for flat k indices kx*ny+ky."""
+        B, F, K = self._bfk(src)
+        idx = np.ascontiguousarray(flat_indices, dtype=np.int64).reshape(-1)
+        out = np.empty((B, F, idx.size), dtype=np.float32)
+        p, b, f, k = self._src(src)
+        self._chk(self._lib.msl_tacaw_dispersion(self._h, p, b, f, k, _ptr(idx), idx.size, _ptr(out)))
+        return out
+
+    def adf(self, mask, src=None):
+        """(B,) float64: mean over frames of sum_k mask |Psi|."""
+        B, T, K = self._bfk(src)
+        m = np.ascontiguousarray(np.asarray(mask).reshape(-1) != 0, dtype=np.uint8)
+        if m.size != K:
+            raise ValueError(f"mask has {m.size} entries, k-space has {K}")
+        out = np.empty(B, dtype=np.float64)
+        p, b, t, k = self._src(src)
+        self._chk(self._lib.msl_adf(self._h, p, b, t, k, _ptr(m), _ptr(out)))
+        return out
 
     # -- results
     def buffer_bytes(self, what):

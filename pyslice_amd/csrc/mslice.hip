@@ -15,6 +15,7 @@
 #include "fft_generic.h"
 #include "fft_pow2.h"
 #include "potential.h"
+#include "reduce.h"
 
 using namespace msl;
 
@@ -57,6 +58,8 @@ struct msl_handle {
     int n_cus = 256;
     // one-pass-per-slice path (transposing passes): second work buffer in (P, ny, nx+pad) layout, transposed
     // probes and the transposed transmission slices
+    char* scratch = nullptr;       // reductions: partial sums / masks / index lists
+    size_t scratch_bytes = 0;
     bool onepass = false;
     bool scheme_b = false;         // a direction of 2R^2 points: every pass transposes, first pass along y, final transpose if nz is odd
     // one-pass capability per direction: R (0 = none), two = line length 2 R^2, tables (tw2 / ptab only for two)
@@ -911,7 +914,7 @@ int msl_destroy(msl_handle* h) {
     void* bufs[] = {h->psi0, h->psi, h->trans, h->V, h->wf, h->intensity, h->pxt, h->pyt, h->d_abcd, h->d_lo, h->d_hi,
                     h->d_pos, h->d_Z, h->d_key, h->d_order, h->d_u1, h->d_u2, h->d_ex, h->d_ey, h->d_counts, h->d_start,
                     h->d_z2s, h->d_species, h->d_ff, h->d_xy, h->plan_x.tw, h->plan_y.tw, h->plan_t.tw, h->tw4_x, h->tw4_y,
-                    h->psiT, h->psi0T, h->transT, h->opx.tw2, h->opx.ptab, h->opy.tw2, h->opy.ptab,
+                    h->scratch, h->psiT, h->psi0T, h->transT, h->opx.tw2, h->opx.ptab, h->opy.tw2, h->opy.ptab,
                     (h->opx.two ? h->opx.tw : nullptr), (h->opy.two ? h->opy.tw : nullptr), h->plan_x.chirp, h->plan_x.bfilt, h->plan_y.chirp, h->plan_y.bfilt, h->plan_t.chirp, h->plan_t.bfilt};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1305,6 +1308,134 @@ void* msl_device_ptr(msl_handle* h, msl_buffer what) {
         case MSL_BUF_FORMFACTOR: return h->d_ff;
     }
     return nullptr;
+}
+
+// ---- reductions over resident results (reduce.h) ------------------------------------------------------
+static int ensure_scratch(msl_handle* h, size_t bytes) {
+    if (bytes <= h->scratch_bytes) return MSL_OK;
+    int rc = dalloc(h, &h->scratch, bytes);
+    h->scratch_bytes = rc ? 0 : bytes;
+    return rc;
+}
+
+// resolve (src, B, F, K) for the TACAW reductions: NULL = the handle's intensity buffer
+static int intensity_source(msl_handle* h, const char* who, const void** src, int64_t* B, int64_t* F, int64_t* K) {
+    if (!h) return fail(h, MSL_ERR_INVALID, "null handle");
+    if (!*src) {
+        if (!h->intensity || h->intensity_elems == 0) return fail(h, MSL_ERR_STATE, "%s: no intensity (call msl_tacaw)", who);
+        *src = h->intensity; *B = h->cfg.n_probes; *F = h->cfg.n_frames; *K = (int64_t)h->cfg.nx * h->cfg.ny;
+    }
+    if (*B < 1 || *F < 1 || *K < 1) return fail(h, MSL_ERR_INVALID, "%s: bad shape (%lld,%lld,%lld)", who, (long long)*B, (long long)*F, (long long)*K);
+    if (*B * *F > 0x7fffffffLL) return fail(h, MSL_ERR_UNSUPPORTED, "%s: more than 2^31 rows", who);
+    return MSL_OK;
+}
+
+// sum over K of rows of a (rows, K) array with an optional host mask; float64 result per row on the host
+static int reduce_rows(msl_handle* h, const void* src, bool complex_abs, int64_t rows, int64_t K, const uint8_t* mask, double* out) {
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const int64_t quads = (K + 3) / 4;
+    int n_chunks = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(quads / 1024, 4096 / rows), 64));
+    const size_t mask_bytes = mask ? (((size_t)K + 15) & ~(size_t)15) + 16 : 0;
+    const size_t part_bytes = (size_t)rows * n_chunks * sizeof(double);
+    int rc = ensure_scratch(h, mask_bytes + part_bytes);
+    if (rc) return rc;
+    uint8_t* d_mask = mask ? (uint8_t*)h->scratch : nullptr;
+    double* d_part = (double*)(h->scratch + mask_bytes);
+    if (mask) {
+        HIPCHK(h, hipMemsetAsync(d_mask, 0, mask_bytes, h->stream));
+        HIPCHK(h, hipMemcpyAsync(d_mask, mask, (size_t)K, hipMemcpyHostToDevice, h->stream));
+    }
+    dim3 grid(n_chunks, (unsigned)rows);
+    if (complex_abs) hipLaunchKernelGGL(reduce_k_kernel<true>, grid, dim3(256), 0, h->stream, src, d_mask, (long long)K, n_chunks, d_part);
+    else hipLaunchKernelGGL(reduce_k_kernel<false>, grid, dim3(256), 0, h->stream, src, d_mask, (long long)K, n_chunks, d_part);
+    HIPCHK(h, hipGetLastError());
+    std::vector<double> part((size_t)rows * n_chunks);
+    HIPCHK(h, hipMemcpyAsync(part.data(), d_part, part_bytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int64_t r = 0; r < rows; ++r) {
+        double s = 0;
+        for (int c = 0; c < n_chunks; ++c) s += part[(size_t)r * n_chunks + c];
+        out[r] = s;
+    }
+    return MSL_OK;
+}
+
+int msl_tacaw_spectrum(msl_handle* h, const void* d_src_f32, int64_t B, int64_t F, int64_t K, const uint8_t* mask, double* out) {
+    if (!out) return fail(h, MSL_ERR_INVALID, "msl_tacaw_spectrum: null output");
+    int rc = intensity_source(h, "msl_tacaw_spectrum", &d_src_f32, &B, &F, &K);
+    if (rc) return rc;
+    if (B * F > 65535) {                       // grid.y limit: go probe by probe
+        if (F > 65535) return fail(h, MSL_ERR_UNSUPPORTED, "msl_tacaw_spectrum: more than 65535 frequencies");
+        for (int64_t b = 0; b < B; ++b)
+            if ((rc = reduce_rows(h, (const float*)d_src_f32 + b * F * K, false, F, K, mask, out + b * F))) return rc;
+        return MSL_OK;
+    }
+    return reduce_rows(h, d_src_f32, false, B * F, K, mask, out);
+}
+
+int msl_adf(msl_handle* h, const void* d_src_c64, int64_t B, int64_t T, int64_t K, const uint8_t* mask, double* out) {
+    if (!h || !out) return fail(h, MSL_ERR_INVALID, "msl_adf: null argument");
+    if (!d_src_c64) {
+        if (!h->wf) return fail(h, MSL_ERR_STATE, "msl_adf: no wavefunction buffer");
+        d_src_c64 = h->wf; B = h->cfg.n_probes; T = h->cfg.n_frames; K = (int64_t)h->cfg.nx * h->cfg.ny;
+    }
+    if (B < 1 || T < 1 || K < 1) return fail(h, MSL_ERR_INVALID, "msl_adf: bad shape");
+    if (T > 65535) return fail(h, MSL_ERR_UNSUPPORTED, "msl_adf: more than 65535 frames");
+    std::vector<double> rows((size_t)T);
+    for (int64_t b = 0; b < B; ++b) {
+        int rc = reduce_rows(h, (const float2*)d_src_c64 + b * T * K, true, T, K, mask, rows.data());
+        if (rc) return rc;
+        double s = 0;
+        for (double v : rows) s += v;
+        out[b] = s / (double)T;                // mean over frames of the annulus sum (haadf_data.py:80)
+    }
+    return MSL_OK;
+}
+
+int msl_tacaw_diffraction(msl_handle* h, const void* d_src_f32, int64_t B, int64_t F, int64_t K, int64_t b0, int64_t b1,
+                          int64_t f0, int64_t f1, double scale, double* out) {
+    if (!out) return fail(h, MSL_ERR_INVALID, "msl_tacaw_diffraction: null output");
+    int rc = intensity_source(h, "msl_tacaw_diffraction", &d_src_f32, &B, &F, &K);
+    if (rc) return rc;
+    if (b0 < 0 || b1 > B || b0 >= b1 || f0 < 0 || f1 > F || f0 >= f1)
+        return fail(h, MSL_ERR_INVALID, "msl_tacaw_diffraction: range [%lld,%lld) x [%lld,%lld) outside (%lld,%lld)", (long long)b0,
+                    (long long)b1, (long long)f0, (long long)f1, (long long)B, (long long)F);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    if ((rc = ensure_scratch(h, (size_t)K * sizeof(double)))) return rc;
+    double* d_out = (double*)h->scratch;
+    const bool vec = (K % 4 == 0);
+    const long long threads = vec ? K / 4 : K;
+    const unsigned grid = (unsigned)((threads + 255) / 256);
+    if (vec) hipLaunchKernelGGL(reduce_bf_kernel<true>, dim3(grid), dim3(256), 0, h->stream, (const float*)d_src_f32, (long long)F, (long long)K,
+                                (long long)b0, (long long)b1, (long long)f0, (long long)f1, scale, d_out);
+    else hipLaunchKernelGGL(reduce_bf_kernel<false>, dim3(grid), dim3(256), 0, h->stream, (const float*)d_src_f32, (long long)F, (long long)K,
+                            (long long)b0, (long long)b1, (long long)f0, (long long)f1, scale, d_out);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(out, d_out, (size_t)K * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return MSL_OK;
+}
+
+int msl_tacaw_dispersion(msl_handle* h, const void* d_src_f32, int64_t B, int64_t F, int64_t K, const int64_t* idx, int64_t n, float* out) {
+    if (!out || !idx) return fail(h, MSL_ERR_INVALID, "msl_tacaw_dispersion: null argument");
+    int rc = intensity_source(h, "msl_tacaw_dispersion", &d_src_f32, &B, &F, &K);
+    if (rc) return rc;
+    if (n < 1) return fail(h, MSL_ERR_INVALID, "msl_tacaw_dispersion: empty path");
+    for (int64_t i = 0; i < n; ++i)
+        if (idx[i] < 0 || idx[i] >= K) return fail(h, MSL_ERR_INVALID, "msl_tacaw_dispersion: index %lld outside [0,%lld)", (long long)idx[i], (long long)K);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const size_t idx_bytes = (size_t)n * sizeof(int64_t), out_bytes = (size_t)B * F * n * sizeof(float);
+    if ((rc = ensure_scratch(h, idx_bytes + out_bytes))) return rc;
+    long long* d_idx = (long long*)h->scratch;
+    float* d_out = (float*)(h->scratch + idx_bytes);
+    HIPCHK(h, hipMemcpyAsync(d_idx, idx, idx_bytes, hipMemcpyHostToDevice, h->stream));
+    const long long tot = (long long)B * F * n;
+    hipLaunchKernelGGL(gather_k_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, (const float*)d_src_f32,
+                       (long long)(B * F), (long long)K, d_idx, (long long)n, d_out);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return MSL_OK;
 }
 
 int msl_download(msl_handle* h, msl_buffer what, void* dst, size_t bytes, int64_t first, int64_t count) {

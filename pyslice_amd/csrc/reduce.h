@@ -1,0 +1,134 @@
+// Reductions over the resident results: TACAW intensity (B, F, K) float32 and exit waves (B, T, K) complex64.
+// They replace the consumers that follow the hot path in the reference:
+//   tacaw_data.py:109-143 spectrum, :145-179 spectrum_image, :256-300 masked_spectrum   -> sum over K (optional mask)
+//   tacaw_data.py:183-217 diffraction, :219-254 spectral_diffraction                      -> sum over a (b, f) range
+//   tacaw_data.py:302-353 dispersion                                                      -> gather of K indices
+//   haadf_data.py:72-94 calculateADF                                                      -> masked sum of |Psi| over K
+// All of them stream the array once (HBM bound); sums are accumulated in float64 like the reference's.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace msl {
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// block of 256 threads; result valid in thread 0
+__device__ __forceinline__ double block_sum_256(double v, double* lds4) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) lds4[w] = v;
+    __syncthreads();
+    return lds4[0] + lds4[1] + lds4[2] + lds4[3];
+}
+
+// partial[row * n_chunks + chunk] = sum over the chunk's share of k of w(k) * a(row, k)
+//   COMPLEX_ABS = false: a = src_f32[row*K + k]      COMPLEX_ABS = true: a = |src_c64[row*K + k]|
+//   mask (K bytes) optional: w = mask[k] != 0
+// grid (n_chunks, rows), 256 threads.  K % 4 == 0 takes 16-byte loads.
+template <bool COMPLEX_ABS>
+__global__ void __launch_bounds__(256) reduce_k_kernel(const void* __restrict__ src, const uint8_t* __restrict__ mask, long long K,
+                                                       int n_chunks, double* __restrict__ partial) {
+    __shared__ double lds4[4];
+    const long long row = blockIdx.y;
+    const int chunk = blockIdx.x;
+    // chunk boundaries on multiples of 4 elements
+    const long long quads = (K + 3) / 4;
+    const long long q0 = quads * chunk / n_chunks, q1 = quads * (chunk + 1) / n_chunks;
+    double acc = 0.0;
+    if constexpr (!COMPLEX_ABS) {
+        const float* r = reinterpret_cast<const float*>(src) + row * K;
+        if ((K & 3) == 0) {
+            const float4* r4 = reinterpret_cast<const float4*>(r);
+            if (mask) {
+                const uchar4* m4 = reinterpret_cast<const uchar4*>(mask);
+                for (long long q = q0 + threadIdx.x; q < q1; q += 256) {
+                    const float4 v = r4[q];
+                    const uchar4 m = m4[q];
+                    acc += (double)((m.x ? v.x : 0.f) + (m.y ? v.y : 0.f)) + (double)((m.z ? v.z : 0.f) + (m.w ? v.w : 0.f));
+                }
+            } else {
+                for (long long q = q0 + threadIdx.x; q < q1; q += 256) {
+                    const float4 v = r4[q];
+                    acc += (double)(v.x + v.y) + (double)(v.z + v.w);
+                }
+            }
+        } else {
+            const long long k1 = min(q1 * 4, K);
+            for (long long k = q0 * 4 + threadIdx.x; k < k1; k += 256)
+                if (!mask || mask[k]) acc += (double)r[k];
+        }
+    } else {
+        const float2* r = reinterpret_cast<const float2*>(src) + row * K;
+        if ((K & 1) == 0) {
+            const float4* r4 = reinterpret_cast<const float4*>(r);
+            const long long p0 = q0 * 2, p1 = min(q1 * 2, K / 2);
+            for (long long q = p0 + threadIdx.x; q < p1; q += 256) {
+                const float4 v = r4[q];
+                const float a = (!mask || mask[2 * q]) ? sqrtf(v.x * v.x + v.y * v.y) : 0.f;
+                const float b = (!mask || mask[2 * q + 1]) ? sqrtf(v.z * v.z + v.w * v.w) : 0.f;
+                acc += (double)a + (double)b;
+            }
+        } else {
+            const long long k1 = min(q1 * 4, K);
+            for (long long k = q0 * 4 + threadIdx.x; k < k1; k += 256)
+                if (!mask || mask[k]) { const float2 v = r[k]; acc += (double)sqrtf(v.x * v.x + v.y * v.y); }
+        }
+    }
+    const double s = block_sum_256(acc, lds4);
+    if (threadIdx.x == 0) partial[row * n_chunks + chunk] = s;
+}
+
+// out[k] = scale * sum_{b in [b0,b1)} sum_{f in [f0,f1)} src[(b*F + f)*K + k]        (float64 accumulation and output)
+// thread = 4 consecutive k when K % 4 == 0 (VEC), else one k
+template <bool VEC>
+__global__ void __launch_bounds__(256) reduce_bf_kernel(const float* __restrict__ src, long long F, long long K, long long b0,
+                                                        long long b1, long long f0, long long f1, double scale,
+                                                        double* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if constexpr (VEC) {
+        if (i * 4 >= K) return;
+        double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        for (long long b = b0; b < b1; ++b) {
+            const float4* p = reinterpret_cast<const float4*>(src + (b * F + f0) * K) + i;
+            const long long step = K / 4;
+            long long f = f0;
+            for (; f + 4 <= f1; f += 4) {
+                const float4 v0 = p[0], v1 = p[step], v2 = p[2 * step], v3 = p[3 * step];
+                a0 += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
+                a1 += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
+                a2 += ((double)v0.z + (double)v1.z) + ((double)v2.z + (double)v3.z);
+                a3 += ((double)v0.w + (double)v1.w) + ((double)v2.w + (double)v3.w);
+                p += 4 * step;
+            }
+            for (; f < f1; ++f) {
+                const float4 v = p[0];
+                a0 += v.x; a1 += v.y; a2 += v.z; a3 += v.w;
+                p += step;
+            }
+        }
+        double* o = out + i * 4;
+        o[0] = a0 * scale; o[1] = a1 * scale; o[2] = a2 * scale; o[3] = a3 * scale;
+    } else {
+        if (i >= K) return;
+        double a = 0;
+        for (long long b = b0; b < b1; ++b)
+            for (long long f = f0; f < f1; ++f) a += (double)src[(b * F + f) * K + i];
+        out[i] = a * scale;
+    }
+}
+
+// out[row * n + i] = src[row * K + idx[i]]   (rows = B * F)
+__global__ void __launch_bounds__(256) gather_k_kernel(const float* __restrict__ src, long long rows, long long K,
+                                                       const long long* __restrict__ idx, long long n, float* __restrict__ out) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= rows * n) return;
+    const long long row = t / n, i = t % n;
+    out[t] = src[row * K + idx[i]];
+}
+
+}  // namespace msl

@@ -1,14 +1,15 @@
 """HAADFData -- host mirror of src/postprocessing/haadf_data.py (a consumer of WFData).
 
 ADF image: for every probe position, mean over frames of sum_k |Psi(k)| over the annulus
-q > collection_angle*1e-3/lambda  (haadf_data.py:44-68).  The masked |.| reduction runs on the
-device through torch (plumbing) when the wave data is device resident, else on the host array
-that run() already returned.
+q > collection_angle*1e-3/lambda  (haadf_data.py:44-68).  The masked |.| reduction runs in the HIP
+library (msl_adf): on the resident (P,T,nx,ny) buffer when the WFData came from run(), else on a
+complex64 copy staged through torch device memory.
 """
 from __future__ import annotations
 
 import numpy as np
 
+from . import _native
 from .potentials import TORCH_AVAILABLE
 from .wf_data import WFData
 
@@ -32,14 +33,25 @@ class HAADFData(WFData):
         q = np.sqrt(kxs[:, None] ** 2 + kys[None, :] ** 2)
         radius = (collection_angle * 1e-3) / self.probe.wavelength
         mask = (q > radius)
-        wf = self.wavefunction_data
-        if TORCH_AVAILABLE and hasattr(wf, "dim"):
-            m = torch.as_tensor(mask, device=wf.device)
-            # (P,T,kx,ky): sum over the annulus, mean over frames
-            per_probe = (wf[:, :, :, :, -1].abs() * m[None, None]).sum(dim=(2, 3)).mean(dim=1)
-            per_probe = _np(per_probe).astype(np.float64)
+        eng = self.__dict__.get("_engine")
+        if eng is not None and self.__dict__.get("_resident", False) and len(self.layer) == 1:
+            per_probe = eng.adf(mask)                                  # resident exit waves of run()
         else:
-            per_probe = (np.abs(wf[:, :, :, :, -1]) * mask[None, None]).sum(axis=(2, 3)).mean(axis=1)
+            if not TORCH_AVAILABLE or not torch.cuda.is_available():
+                raise RuntimeError("HAADFData needs the HIP device (no CPU path in pyslice_amd)")
+            wf = self.wavefunction_data
+            wf = wf if hasattr(wf, "dim") else torch.from_numpy(np.ascontiguousarray(wf))
+            dev = wf.device if wf.is_cuda else torch.device("cuda", torch.cuda.current_device())
+            src = wf[:, :, :, :, -1].to(device=dev, dtype=torch.complex64).contiguous()
+            P, T, nx, ny = src.shape
+            torch.cuda.synchronize(dev)
+            helper = eng if (eng is not None and eng.device == dev.index) else \
+                _native.Engine(2, 2, 1, 1.0, 1.0, 1.0, 1.0, 0.0, n_probes=1, n_frames=0, device=dev.index)
+            try:
+                per_probe = helper.adf(mask, src=(src.data_ptr(), P, T, nx * ny))
+            finally:
+                if helper is not eng:
+                    helper.close()
         self.adf = np.zeros((len(self.xs), len(self.ys)))
         for i, x in enumerate(self.xs):
             for j, y in enumerate(self.ys):

@@ -5,8 +5,9 @@
     intensity[p,w,kx,ky] = | fftshift_t fft_t( Psi - <Psi>_t ) |^2          (tacaw_data.py:89-104)
 runs in the HIP library (msl_tacaw).  When the WFData came from MultisliceCalculator.run() the
 exit waves are still resident on the device and are transformed in place there; otherwise the
-array is staged through torch device memory.  The reductions below (spectrum, diffraction, ...)
-are thin index/sum operations on the final intensity array (tacaw_data.py:109-353).
+array is staged through torch device memory.  The reductions below (spectrum, diffraction, ...;
+tacaw_data.py:109-353) stream the device copy of the intensity once through the library's
+reduction kernels (msl_tacaw_spectrum / _diffraction / _dispersion) and return small host arrays.
 """
 from __future__ import annotations
 
@@ -51,6 +52,7 @@ class TACAWData(WFData):
             return
         if resident:
             eng.tacaw()
+            self._intensity_src = (eng, None)          # reductions read the library's own buffer
             if self.__dict__.get("_output") == "device":
                 ptr = eng.device_ptr(_native.BUF_INTENSITY)
                 shape = (eng.n_probes, eng.n_frames, eng.nx, eng.ny)
@@ -74,6 +76,7 @@ class TACAWData(WFData):
             helper.tacaw(src.data_ptr(), dst.data_ptr(), P, T, nx * ny)
         finally:
             helper.close()
+        self._intensity_src = (None, dst)               # device copy kept for the reductions
         self.intensity = dst.to(torch.float64).cpu()
 
     def _tacaw_sharded(self, eng, shard):
@@ -96,71 +99,112 @@ class TACAWData(WFData):
         if full is None:
             return None
         full = full.reshape(P, n_frames, nx, ny)
+        self._intensity_src = (eng, full)
         return full if self.__dict__.get("_output") == "device" else full.to(torch.float64).cpu()
 
-    # ---- reductions over intensity(P, F, kx, ky) ----------------------------------------------
-    def _inten(self):
-        return self.intensity
+    # ---- reductions over intensity(P, F, kx, ky): device kernels behind the reference's method signatures -------
+    def _source(self):
+        """(engine, src) for the reduction entry points; src = None (library buffer) or (ptr, B, F, K)."""
+        d = self.__dict__
+        eng, dev = d.get("_intensity_src", (None, None))
+        if dev is None and eng is not None:
+            return eng, None, (eng.n_probes, eng.n_frames, eng.nx * eng.ny), eng.device_ptr(_native.BUF_INTENSITY)
+        if dev is None:
+            # intensity assembled elsewhere: stage a float32 copy on the device once
+            if not TORCH_AVAILABLE or not torch.cuda.is_available():
+                raise RuntimeError("TACAWData reductions need the HIP device (no CPU path in pyslice_amd)")
+            I = self.intensity
+            I = I if hasattr(I, "dim") else torch.from_numpy(np.ascontiguousarray(I))
+            dev = I.to(device=torch.device("cuda", torch.cuda.current_device()), dtype=torch.float32).contiguous()
+        if eng is None:
+            eng = d.get("_reduce_engine")
+            if eng is None:
+                eng = _native.Engine(2, 2, 1, 1.0, 1.0, 1.0, 1.0, 0.0, n_probes=1, n_frames=0, device=dev.device.index)
+                d["_reduce_engine"] = eng
+        d["_intensity_src"] = (eng, dev)
+        torch.cuda.synchronize(dev.device)
+        B, F = int(dev.shape[0]), int(dev.shape[1])
+        K = int(np.prod(dev.shape[2:]))
+        return eng, (dev.data_ptr(), B, F, K), (B, F, K), dev.data_ptr()
+
+    def _rows(self, b, f0, f1, mask=None):
+        """sum over k of I[b, f0:f1] -> (f1-f0,) float64"""
+        eng, _, (B, F, K), ptr = self._source()
+        return eng.tacaw_spectrum(mask, src=(ptr + 4 * (b * F + f0) * K, 1, f1 - f0, K))[0]
+
+    def _check_probe(self, probe_index):
+        if probe_index >= len(self.probe_positions):
+            raise ValueError(f"Probe index {probe_index} out of range")
 
     def spectrum(self, probe_index: int = None) -> np.ndarray:
         """reference tacaw_data.py:109-143"""
-        I = self._inten()
+        eng, src, (B, F, K), _ = self._source()
         if probe_index is None:
-            return np.mean([_np(I[i].sum(axis=(1, 2))) for i in range(len(self.probe_positions))], axis=0)
-        if probe_index >= len(self.probe_positions):
-            raise ValueError(f"Probe index {probe_index} out of range")
-        return _np(I[probe_index].sum(axis=(1, 2)))
+            return eng.tacaw_spectrum(src=src)[:len(self.probe_positions)].mean(axis=0)
+        self._check_probe(probe_index)
+        return self._rows(probe_index, 0, F)
 
     def spectrum_image(self, frequency: float, probe_indices: Optional[List[int]] = None) -> np.ndarray:
         """reference tacaw_data.py:145-179"""
         fi = int(np.argmin(np.abs(self.frequencies - frequency)))
         if probe_indices is None:
             probe_indices = list(range(len(self.probe_positions)))
-        return np.array([_np(self._inten()[p, fi].sum()) for p in probe_indices])
+        return np.array([self._rows(p, fi, fi + 1)[0] for p in probe_indices])
 
     def diffraction(self, probe_index: int = None) -> np.ndarray:
         """reference tacaw_data.py:183-217"""
-        I = self._inten()
+        eng, src, (B, F, K), _ = self._source()
+        shape = (len(self.kxs), len(self.kys))
         if probe_index is None:
-            return np.mean([_np(I[i].sum(axis=0)) for i in range(len(self.probe_positions))], axis=0)
-        if probe_index >= len(self.probe_positions):
-            raise ValueError(f"Probe index {probe_index} out of range")
-        return _np(I[probe_index].sum(axis=0))
+            n = len(self.probe_positions)
+            return eng.tacaw_diffraction(probes=(0, n), scale=1.0 / n, src=src).reshape(shape)
+        self._check_probe(probe_index)
+        return eng.tacaw_diffraction(probes=(probe_index, probe_index + 1), src=src).reshape(shape)
 
     def spectral_diffraction(self, frequency: float, probe_index: int = None) -> np.ndarray:
         """reference tacaw_data.py:219-254"""
         fi = int(np.argmin(np.abs(self.frequencies - frequency)))
-        I = self._inten()
+        eng, src, (B, F, K), _ = self._source()
+        shape = (len(self.kxs), len(self.kys))
         if probe_index is None:
-            return np.mean([_np(I[i, fi]) for i in range(len(self.probe_positions))], axis=0)
-        if probe_index >= len(self.probe_positions):
-            raise ValueError(f"Probe index {probe_index} out of range")
-        return _np(I[probe_index, fi])
+            n = len(self.probe_positions)
+            return eng.tacaw_diffraction(probes=(0, n), freqs=(fi, fi + 1), scale=1.0 / n, src=src).reshape(shape)
+        self._check_probe(probe_index)
+        return eng.tacaw_diffraction(probes=(probe_index, probe_index + 1), freqs=(fi, fi + 1), src=src).reshape(shape)
 
     def masked_spectrum(self, mask: np.ndarray, probe_index: int = None) -> np.ndarray:
-        """reference tacaw_data.py:256-300 (its self.kx/self.ky lookup is broken, Q18; kxs/kys used here)"""
+        """reference tacaw_data.py:256-300 (its self.kx/self.ky lookup is broken, Q18; kxs/kys used here).
+        As in the reference the mask multiplies the intensity, so a non-boolean mask weights it: weights other than
+        0/1 are applied by one masked sum per distinct weight."""
         if mask.shape != (len(self.kxs), len(self.kys)):
             raise ValueError(f"Mask shape {mask.shape} doesn't match k-space shape ({len(self.kxs)}, {len(self.kys)})")
-        I = self._inten()
-        m = torch.as_tensor(mask, dtype=I.dtype, device=I.device) if hasattr(I, "dim") else np.asarray(mask)
+        eng, src, (B, F, K), ptr = self._source()
+        mask = np.asarray(mask)
+        weights = [w for w in np.unique(mask) if w != 0]
+        if len(weights) > 8:
+            raise NotImplementedError("masked_spectrum: more than 8 distinct mask weights")
+
+        def masked(b0, nb):
+            s = (ptr + 4 * b0 * F * K, nb, F, K)
+            return sum(float(w) * eng.tacaw_spectrum(mask == w, src=s) for w in weights) if weights else np.zeros((nb, F))
+
         if probe_index is None:
-            return np.mean([_np((I[i] * m[None]).sum(axis=(1, 2))) for i in range(len(self.probe_positions))], axis=0)
-        if probe_index >= len(self.probe_positions):
-            raise ValueError(f"Probe index {probe_index} out of range")
-        return _np((I[probe_index] * m[None]).sum(axis=(1, 2)))
+            return masked(0, len(self.probe_positions)).mean(axis=0)
+        self._check_probe(probe_index)
+        return masked(probe_index, 1)[0]
 
     def dispersion(self, kx_path: np.ndarray, ky_path: np.ndarray, probe_index: int = None) -> np.ndarray:
         """reference tacaw_data.py:302-353"""
         kxs, kys = _np(self.kxs), _np(self.kys)
-        ix = np.array([int(np.argmin(np.abs(kxs - v))) for v in kx_path])
-        iy = np.array([int(np.argmin(np.abs(kys - v))) for v in ky_path])
-        out = np.zeros((len(self.frequencies), len(ix)))
-        I = self._inten()
-        for i, (a, b) in enumerate(zip(ix, iy)):
-            if probe_index is None:
-                out[:, i] = np.mean([_np(I[p, :, a, b]) for p in range(len(self.probe_positions))], axis=0)
-            else:
-                if probe_index >= len(self.probe_positions):
-                    raise ValueError(f"Probe index {probe_index} out of range")
-                out[:, i] = _np(I[probe_index, :, a, b])
+        ix = np.array([int(np.argmin(np.abs(kxs - v))) for v in kx_path], dtype=np.int64)
+        iy = np.array([int(np.argmin(np.abs(kys - v))) for v in ky_path], dtype=np.int64)
+        n = min(len(ix), len(iy))
+        eng, src, (B, F, K), _ = self._source()
+        if probe_index is not None:
+            self._check_probe(probe_index)
+        out = np.zeros((len(self.frequencies), len(ix)))          # zip() semantics: columns past the shorter path stay 0
+        if n == 0:
+            return out
+        g = eng.tacaw_dispersion(ix[:n] * len(kys) + iy[:n], src=src).astype(np.float64)      # (B, F, n)
+        out[:, :n] = g[:len(self.probe_positions)].mean(axis=0) if probe_index is None else g[probe_index]
         return out

@@ -226,6 +226,28 @@ def test_g8_tacaw(ps, golden):
                     wavefunction_data=g["wavefunction_data"], probe=wf.probe)
     tac2 = ps.TACAWData(wf2)
     assert rel_l2(npy(tac2.intensity), g["intensity"]) < TACAW_TOL
+    # reductions (device kernels) from all three intensity sources; expectations restated on the golden intensity
+    I = g["intensity"]
+    kxs, kys = npy(wf.kxs), npy(wf.kys)
+    mask = (np.sqrt(kxs[:, None] ** 2 + kys[None, :] ** 2) < 2.0)
+    fi = int(np.argmin(np.abs(g["frequencies"] - 25.0)))
+    kxp, kyp = np.linspace(-3, 3, 7), np.linspace(0, 2.5, 7)
+    ix = [int(np.argmin(np.abs(kxs - v))) for v in kxp]
+    iy = [int(np.argmin(np.abs(kys - v))) for v in kyp]
+    for t in (tac, tac2, tac3):
+        assert rel_l2(t.spectrum(1), g["intensity"][1].sum(axis=(1, 2))) < TACAW_TOL
+        assert rel_l2(t.diffraction(None), g["diffraction_all"]) < TACAW_TOL
+        assert rel_l2(t.spectral_diffraction(25.0), I[:, fi].mean(axis=0)) < TACAW_TOL
+        assert rel_l2(t.masked_spectrum(mask, 0), (I[0] * mask[None]).sum(axis=(1, 2))) < TACAW_TOL
+        assert rel_l2(t.masked_spectrum(mask), (I * mask[None, None]).sum(axis=(2, 3)).mean(axis=0)) < TACAW_TOL
+        assert rel_l2(t.masked_spectrum(mask * 0.5, 1), 0.5 * (I[1] * mask[None]).sum(axis=(1, 2))) < TACAW_TOL
+        assert rel_l2(t.dispersion(kxp, kyp, 1), I[1][:, ix, iy]) < TACAW_TOL
+        assert rel_l2(t.dispersion(kxp, kyp), I[:, :, ix, iy].mean(axis=0)) < TACAW_TOL
+        assert t.dispersion(kxp, kyp[:3]).shape == (len(g["frequencies"]), 7)
+        with pytest.raises(ValueError):
+            t.spectrum(99)
+        with pytest.raises(ValueError):
+            t.masked_spectrum(mask[:-1])
 
 
 def test_g9_haadf(ps, golden):
@@ -239,6 +261,44 @@ def test_g9_haadf(ps, golden):
     adf = ps.HAADFData(wf).calculateADF(collection_angle=float(g["collection_angle"]))
     assert adf.shape == g["adf"].shape
     assert rel_l2(adf, g["adf"]) < 1e-4
+    # staged path: a WFData that is not resident on the device (e.g. gathered shards, arrays from disk)
+    wf2 = ps.WFData(probe_positions=wf.probe_positions, time=wf.time, kxs=wf.kxs, kys=wf.kys, layer=wf.layer,
+                    wavefunction_data=npy(wf.wavefunction_data), probe=wf.probe)
+    adf2 = ps.HAADFData(wf2).calculateADF(collection_angle=float(g["collection_angle"]))
+    assert rel_l2(adf2, g["adf"]) < 1e-4
+
+
+@pytest.mark.parametrize("B,F,shape", [(3, 5, (45, 63)), (2, 16, (256, 256)), (1, 3, (6, 7)), (70, 1000, (4, 4))])
+def test_reduction_kernels_match_numpy(ps, B, F, shape):
+    """msl_tacaw_spectrum / _diffraction / _dispersion / msl_adf on caller-held device memory: odd K (scalar loads),
+    K % 4 == 0 (16-byte loads), chunked rows, more than 65535 rows."""
+    import torch
+    from pyslice_amd import _native
+    rng = np.random.default_rng(B * 100 + F)
+    K = shape[0] * shape[1]
+    I = rng.random((B, F, K), dtype=np.float32) * rng.choice([1e-3, 1.0, 50.0], size=(B, F, 1)).astype(np.float32)
+    W = (rng.standard_normal((B, F, K)) + 1j * rng.standard_normal((B, F, K))).astype(np.complex64)
+    mask = rng.random(K) < 0.4
+    dI, dW = torch.from_numpy(I).cuda(), torch.from_numpy(W).cuda()
+    torch.cuda.synchronize()
+    eng = _native.Engine(2, 2, 1, 1.0, 1.0, 1.0, 1.0, 0.0, n_probes=1, n_frames=0, device=0)
+    src = (dI.data_ptr(), B, F, K)
+    I64 = I.astype(np.float64)
+    assert rel_l2(eng.tacaw_spectrum(src=src), I64.sum(axis=2)) < 1e-6
+    assert rel_l2(eng.tacaw_spectrum(mask, src=src), (I64 * mask).sum(axis=2)) < 1e-6
+    assert rel_l2(eng.tacaw_diffraction(src=src), I64.sum(axis=(0, 1))) < 1e-6
+    b1, f0 = max(1, B // 2), F // 3
+    assert rel_l2(eng.tacaw_diffraction(probes=(0, b1), freqs=(f0, F), scale=0.25, src=src), 0.25 * I64[:b1, f0:].sum(axis=(0, 1))) < 1e-6
+    idx = rng.integers(0, K, size=11)
+    assert np.array_equal(eng.tacaw_dispersion(idx, src=src), I[:, :, idx])
+    assert rel_l2(eng.adf(mask, src=(dW.data_ptr(), B, F, K)), (np.abs(W.astype(np.complex128)) * mask).sum(axis=2).mean(axis=1)) < 1e-6
+    with pytest.raises(ValueError):
+        eng.tacaw_dispersion([K], src=src)
+    with pytest.raises(ValueError):
+        eng.tacaw_diffraction(probes=(0, B + 1), src=src)
+    with pytest.raises(RuntimeError):
+        eng.tacaw_spectrum()                     # no resident intensity on this handle
+    eng.close()
 
 
 # ------------------------------------------------------------------ oracle on seeded inputs, larger grids
