@@ -55,7 +55,11 @@ typedef struct {
     int32_t device;            /* HIP device ordinal                                        */
     int32_t keep_potential;    /* 1: also keep V (nz,nx,ny) float32 for msl_download(MSL_BUF_POTENTIAL) */
     int32_t fft_path;          /* 0 = auto (fast kernels when the size allows), 1 = generic LDS Stockham only */
-    int32_t reserved[7];
+    int32_t window_nx, window_ny; /* k-window (not in the reference, which keeps every pixel: calculators.py:161):
+                                * keep only the central window_nx x window_ny pixels of each fftshifted exit-wave spectrum,
+                                * rows [nx/2 - window_nx/2, +window_nx), columns likewise; the result, intensity and frame
+                                * buffers then have shape (.., window_nx, window_ny).  0 = the full axis. */
+    int32_t reserved[5];
 } msl_config;
 
 typedef enum {
@@ -63,8 +67,8 @@ typedef enum {
     MSL_BUF_EXIT = 1,          /* (P,nx,ny) c64     real-space exit waves of the last msl_propagate */
     MSL_BUF_POTENTIAL = 2,     /* (nz,nx,ny) f32    V of the last msl_build_potential (slice-major!) */
     MSL_BUF_TRANSMISSION = 3,  /* (nz,nx,ny) c64    exp(i sigma V)                           */
-    MSL_BUF_WAVEFUNCTION = 4,  /* (P,T_local,nx,ny) c64  fftshift(fft2(exit)) per frame slot */
-    MSL_BUF_INTENSITY = 5,     /* (P,T,nx,ny) f32   TACAW |FFT_t|^2 of the last msl_tacaw    */
+    MSL_BUF_WAVEFUNCTION = 4,  /* (P,T_local,wx,wy) c64  fftshift(fft2(exit)) per frame slot (wx,wy = nx,ny or the k-window) */
+    MSL_BUF_INTENSITY = 5,     /* (P,T,wx,wy) f32   TACAW |FFT_t|^2 of the last msl_tacaw    */
     MSL_BUF_FORMFACTOR = 6     /* (n_species,nx,ny) f32 Kirkland f_Z(q^2) of the last potential build */
 } msl_buffer;
 

@@ -32,7 +32,8 @@ class MslConfig(C.Structure):
                 ("dx", C.c_double), ("dy", C.c_double), ("dz", C.c_double),
                 ("wavelength", C.c_double), ("sigma", C.c_double),
                 ("n_probes", C.c_int32), ("n_frames", C.c_int32), ("device", C.c_int32),
-                ("keep_potential", C.c_int32), ("fft_path", C.c_int32), ("reserved", C.c_int32 * 7)]
+                ("keep_potential", C.c_int32), ("fft_path", C.c_int32),
+                ("window_nx", C.c_int32), ("window_ny", C.c_int32), ("reserved", C.c_int32 * 5)]
 
 
 class MslCounters(C.Structure):
@@ -115,13 +116,14 @@ class Engine:
     """One libmslice handle: one HIP device, one stream, all device buffers of one grid."""
 
     def __init__(self, nx, ny, nz, dx, dy, dz, wavelength, sigma, n_probes=1, n_frames=0, device=0,
-                 keep_potential=False, fft_path=0):
+                 keep_potential=False, fft_path=0, window=None):
         self._lib = load()
         self._h = C.c_void_p()
         cfg = MslConfig(nx=int(nx), ny=int(ny), nz=int(nz), dx=float(dx), dy=float(dy), dz=float(dz),
                         wavelength=float(wavelength), sigma=float(sigma), n_probes=int(n_probes),
                         n_frames=int(n_frames), device=int(device), keep_potential=int(bool(keep_potential)),
-                        fft_path=int(fft_path))
+                        fft_path=int(fft_path), window_nx=int(window[0]) if window else 0,
+                        window_ny=int(window[1]) if window else 0)
         rc = self._lib.msl_create(C.byref(cfg), C.byref(self._h))
         if rc != MSL_OK:
             msg = (self._lib.msl_last_error(None) or b"msl_create failed").decode()
@@ -130,6 +132,9 @@ class Engine:
         self.nx, self.ny, self.nz = int(nx), int(ny), int(nz)
         self.n_probes, self.n_frames, self.device = int(n_probes), int(n_frames), int(device)
         self.keep_potential = bool(keep_potential)
+        # stored shape of one exit-wave spectrum: the k-window, or the whole grid
+        self.wx = int(window[0]) if window and window[0] else self.nx
+        self.wy = int(window[1]) if window and window[1] else self.ny
 
     # -- lifetime
     def close(self):
@@ -226,7 +231,7 @@ class Engine:
         return C.c_void_p(int(ptr)), int(B), int(F), int(K)
 
     def _bfk(self, src):
-        return (self.n_probes, self.n_frames, self.nx * self.ny) if src is None else tuple(int(v) for v in src[1:])
+        return (self.n_probes, self.n_frames, self.wx * self.wy) if src is None else tuple(int(v) for v in src[1:])
 
     def tacaw_spectrum(self, mask=None, src=None):
         """(B,F) float64: sum over k of the (masked) intensity."""
@@ -297,22 +302,22 @@ class Engine:
 
     def wavefunction(self, first=0, count=0):
         n = count if count else self.n_probes
-        return self.download(BUF_WAVEFUNCTION, np.complex64, (n, self.n_frames, self.nx, self.ny), first, count)
+        return self.download(BUF_WAVEFUNCTION, np.complex64, (n, self.n_frames, self.wx, self.wy), first, count)
 
     def frame(self, slot):
-        out = np.empty((self.n_probes, self.nx, self.ny), dtype=np.complex64)
+        out = np.empty((self.n_probes, self.wx, self.wy), dtype=np.complex64)
         self._chk(self._lib.msl_download_frame(self._h, int(slot), _ptr(out), out.nbytes))
         return out
 
     def upload_frame(self, slot, data):
         a = np.ascontiguousarray(data, dtype=np.complex64)
-        if a.shape != (self.n_probes, self.nx, self.ny):
-            raise ValueError(f"frame must be ({self.n_probes},{self.nx},{self.ny}), got {a.shape}")
+        if a.shape != (self.n_probes, self.wx, self.wy):
+            raise ValueError(f"frame must be ({self.n_probes},{self.wx},{self.wy}), got {a.shape}")
         self._chk(self._lib.msl_upload_frame(self._h, int(slot), _ptr(a), a.nbytes))
 
     def intensity(self, first=0, count=0):
         n = count if count else self.n_probes
-        return self.download(BUF_INTENSITY, np.float32, (n, self.n_frames, self.nx, self.ny), first, count)
+        return self.download(BUF_INTENSITY, np.float32, (n, self.n_frames, self.wx, self.wy), first, count)
 
     def form_factors(self, n_species):
         return self.download(BUF_FORMFACTOR, np.float32, (n_species, self.nx, self.ny))

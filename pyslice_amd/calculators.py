@@ -36,7 +36,7 @@ logger = logging.getLogger(__name__)
 class MultisliceCalculator:
 
     def __init__(self, device=None, force_cpu=False, *, output="host", dtype="complex128", progress=True,
-                 gather="rank0", cache=False):
+                 gather="rank0", cache=False, k_window=None):
         """
         device / force_cpu: as the reference (calculators.py:41).  There is no CPU path here, so
         force_cpu=True raises.  Keyword-only extras (not in the reference):
@@ -49,6 +49,10 @@ class MultisliceCalculator:
                    loaded instead of computed (resume), computed frames are written.  Off by default: the reference
                    writes 16*P*nx*ny bytes per frame to the CWD unconditionally (1 GB/frame at C3) and its key ignores
                    the atom positions (stale-hit hazard).
+          k_window (wx, wy): keep only the central wx x wy pixels of every exit-wave spectrum (the detector window
+                   around k = 0).  wavefunction_data becomes (P,T,wx,wy,1), kxs/kys are cropped to match,
+                   and TACAWData / HAADFData work on the window.  Cuts the resident result by nx*ny/(wx*wy) -- the way
+                   to hold 2048^2 x 1024-frame runs at all -- and the exit FFT only transforms the columns kept.
         """
         if force_cpu:
             raise NotImplementedError("pyslice_amd has no CPU path (force_cpu=True): use the reference for CPU runs")
@@ -61,6 +65,13 @@ class MultisliceCalculator:
         self.device = device
         self._output, self._dtype, self._progress, self._gather = output, dtype, progress, gather
         self._cache = bool(cache)
+        if k_window is not None:
+            if len(k_window) != 2 or int(k_window[0]) < 1 or int(k_window[1]) < 1:
+                raise ValueError("k_window must be two positive pixel counts (wx, wy)")
+            if cache:
+                raise ValueError("the frame cache stores full (P,nx,ny,1,1) frames: cache=True cannot be combined with k_window")
+            k_window = (int(k_window[0]), int(k_window[1]))
+        self._k_window = k_window
         self._engine = None
         # reference calculators.py:70-76 (display names for Z <= 36)
         self.element_map = {
@@ -139,7 +150,8 @@ class MultisliceCalculator:
             self._engine.close()
         self._engine = _native.Engine(nx, ny, n_slices, self.dx, self.dy, dz, wavelength(voltage_eV),
                                       interaction_sigma(voltage_eV), n_probes=self.n_probes,
-                                      n_frames=max(1, len(self._frames)), device=_device_index(dev))
+                                      n_frames=max(1, len(self._frames)), device=_device_index(dev),
+                                      window=self._k_window)
         self._engine.set_kirkland(loadKirkland())
         lo, hi = slice_edges(slice_coords)
         self._engine.set_slices(lo, hi)
@@ -183,6 +195,9 @@ class MultisliceCalculator:
         # reference calculators.py:218-221 (quirk Q2: `sampling`, not dx; torch default float32)
         kxs = np.fft.fftshift(np.fft.fftfreq(self.nx, self.sampling)).astype(np.float32)
         kys = np.fft.fftshift(np.fft.fftfreq(self.ny, self.sampling)).astype(np.float32)
+        if self._k_window is not None:          # the window is centred on the DC pixel (index n//2 after the shift)
+            x0, y0 = self.nx // 2 - eng.wx // 2, self.ny // 2 - eng.wy // 2
+            kxs, kys = kxs[x0:x0 + eng.wx], kys[y0:y0 + eng.wy]
         time_array = np.arange(self.n_frames) * self.trajectory.timestep
         layer_array = np.array([0])
 
@@ -202,7 +217,7 @@ class MultisliceCalculator:
     def _collect(self):
         """Pack the device-resident (P,T_local,nx,ny) into the reference's (P,T,nx,ny,1) array."""
         eng = self._engine
-        P, nx, ny = self.n_probes, self.nx, self.ny
+        P, nx, ny = self.n_probes, eng.wx, eng.wy          # stored spectrum shape (the k-window, or the grid)
         T_local = len(self._frames)
         if self._world == 1 or self._gather == "none":
             if self._output == "device":

@@ -37,6 +37,7 @@ struct LineJob {
     int m1_kind, m2_kind;
     int store_mode;
     int shift_n, shift_r;       // out index: ((n+shift_n)%N, (r+shift_r)%lines_per_image)
+    int win_n0, win_nn, win_r0, win_nr;   // win_nn > 0: keep only out indices [win_n0, +win_nn) x [win_r0, +win_nr), rebased to 0
     int n_stages;
     int radix[MSL_MAX_STAGES];
     int M;                      // transform length of the Stockham stages: N, or >= 2N-1 for Bluestein lines
@@ -271,6 +272,10 @@ __global__ void __launch_bounds__(1024) line_fft_kernel(LineJob job) {
         v.x *= job.scale; v.y *= job.scale;
         int no = n + job.shift_n; if (no >= N) no -= N;
         long long ro = r + job.shift_r; if (ro >= job.lines_per_image) ro -= job.lines_per_image;
+        if (job.win_nn > 0) {
+            no -= job.win_n0; ro -= job.win_r0;
+            if (no < 0 || no >= job.win_nn || ro < 0 || ro >= job.win_nr) continue;
+        }
         long long o = img * job.out_is + ro * job.out_ls + (long long)no * job.out_es;
         if (job.store_mode == STORE_C64) {
             job.out[o] = v;

@@ -238,6 +238,9 @@ struct ColJob {
     float* out_real;        // COL_POTENTIAL: optional V (same pitch / image stride as `out`)
     int tparity;            // COL_TPOT: images whose index parity differs from this are stored transposed ...
     float2* out_t;          // ... into this separate (n_images, ny, nx) buffer (in-place transposition would race)
+    // COL_SHIFT only: k-window in fftshifted coordinates.  Columns [win_c0, win_c0 + win_nc) are transformed (win_nc == 0:
+    // all ny), rows [win_x0, win_x0 + win_nx) are stored, both rebased to 0.  win_c0, win_nc and ny/2 are multiples of 16.
+    int win_c0, win_nc, win_x0, win_nx;
 };
 // COL_POTENTIAL: epilogue of the potential build, V = Re(x)*scale, out = exp(i sigma V)  (potentials.py:336-342, multislice.py:282)
 // COL_TPOT (with COL_POTENTIAL): every second slice's t is stored transposed, (ny, nx), for the one-pass slice loop
@@ -265,12 +268,19 @@ __global__ void __launch_bounds__(16 * R) col_pass_kernel(ColJob job) {
     const int grp = tid / R, ln = tid % R;            // column handled in the transform phase
     const int q = tid & 7, r0 = tid >> 3;             // staging role: column pair q, row r0 + ROWS_PER_IT*i
     float2* mycol = cols + grp * CS;
-    const int tiles_per_image = job.ny / 16;
+    const bool windowed = (job.flags & COL_SHIFT) && job.win_nc > 0;
+    const int tiles_per_image = (windowed ? job.win_nc : job.ny) / 16;
     const long long n_tiles = (long long)tiles_per_image * job.n_images;
+    // first (unshifted) column of tile t of an image
+    auto tile_col = [&](long long t) {
+        int c = (int)t * 16;
+        if (windowed) { c += job.win_c0 + job.ny / 2; if (c >= job.ny) c -= job.ny; }
+        return c;
+    };
     float4 stage[NIT];
     long long tile = blockIdx.x;
     if (tile < n_tiles) {
-        const long long p = tile / tiles_per_image, c0 = (tile % tiles_per_image) * 16;
+        const long long p = tile / tiles_per_image, c0 = tile_col(tile % tiles_per_image);
         const float2* src = job.in + p * job.in_image_stride + c0 + 2 * q;
 #pragma unroll
         for (int i = 0; i < NIT; ++i)
@@ -289,7 +299,7 @@ __global__ void __launch_bounds__(16 * R) col_pass_kernel(ColJob job) {
         // ---- next tile's loads go out now and fly during the transform
         const long long nxt = tile + gridDim.x;
         if (nxt < n_tiles) {
-            const long long p = nxt / tiles_per_image, c0 = (nxt % tiles_per_image) * 16;
+            const long long p = nxt / tiles_per_image, c0 = tile_col(nxt % tiles_per_image);
             const float2* src = job.in + p * job.in_image_stride + c0 + 2 * q;
 #pragma unroll
             for (int i = 0; i < NIT; ++i)
@@ -312,7 +322,7 @@ __global__ void __launch_bounds__(16 * R) col_pass_kernel(ColJob job) {
             tstore = (job.flags & COL_TPOT) && (((int)pimg & 1) != job.tparity);
             if (tstore) {
                 // transposed transmission slice: column (fixed y) is a contiguous line of the (ny, nx) image
-                const int y = (int)(tile % tiles_per_image) * 16 + grp;
+                const int y = tile_col(tile % tiles_per_image) + grp;
                 float2* trow = job.out_t + pimg * job.out_image_stride + (long long)y * N;
 #pragma unroll
                 for (int j = 0; j < R; ++j) {
@@ -329,9 +339,10 @@ __global__ void __launch_bounds__(16 * R) col_pass_kernel(ColJob job) {
         // ---- LDS -> registers -> HBM (128-byte segments)
         if (!tstore) {
             const long long p = tile / tiles_per_image;
-            const int c0 = (int)(tile % tiles_per_image) * 16;
+            const int c0 = tile_col(tile % tiles_per_image);
             int cshift = c0, xshift = 0;
             if (job.flags & COL_SHIFT) { cshift = (c0 + job.ny / 2) % job.ny; xshift = N / 2; }
+            if (windowed) cshift -= job.win_c0;
             float2* dst = job.out + p * job.out_image_stride + cshift + 2 * q;
 #pragma unroll
             for (int i = 0; i < NIT; ++i) {
@@ -339,6 +350,10 @@ __global__ void __launch_bounds__(16 * R) col_pass_kernel(ColJob job) {
                 float2 a = cols[(2 * q) * CS + x], b = cols[(2 * q + 1) * CS + x];
                 int xo = x + xshift;
                 if (xo >= N) xo -= N;
+                if (windowed) {
+                    xo -= job.win_x0;
+                    if (xo < 0 || xo >= job.win_nx) continue;
+                }
                 if (job.flags & COL_INTENSITY) {
                     const float ia = (x == 0) ? 0.f : fmaf(a.x, a.x, a.y * a.y), ib = (x == 0) ? 0.f : fmaf(b.x, b.x, b.y * b.y);
                     int xs = x + N / 2;

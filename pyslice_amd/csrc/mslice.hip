@@ -58,6 +58,8 @@ struct msl_handle {
     int n_cus = 256;
     // one-pass-per-slice path (transposing passes): second work buffer in (P, ny, nx+pad) layout, transposed
     // probes and the transposed transmission slices
+    int wx = 0, wy = 0, wx0 = 0, wy0 = 0;   // k-window of the stored exit-wave spectra (fftshifted coordinates)
+    size_t wpix = 0;
     char* scratch = nullptr;       // reductions: partial sums / masks / index lists
     size_t scratch_bytes = 0;
     bool onepass = false;
@@ -289,6 +291,7 @@ struct LineArgs {
     int m1_kind = MUL_NONE, m2_kind = MUL_NONE; const float2* m1 = nullptr; const float2* m2 = nullptr;
     long long m1_ls = 0, m2_ls = 0;
     int store_mode = STORE_C64; int shift_n = 0, shift_r = 0; float scale = 1.f; float sigma = 0.f;
+    int win_n0 = 0, win_nn = 0, win_r0 = 0, win_nr = 0;      // win_nn > 0: store only the window of the shifted output
 };
 
 int launch_lines(msl_handle* h, const FftPlan& pl, const LineArgs& a, int kind) {
@@ -299,6 +302,7 @@ int launch_lines(msl_handle* h, const FftPlan& pl, const LineArgs& a, int kind) 
     job.N = pl.N; job.lines_per_image = a.lines_per_image; job.contiguous_lines = a.contiguous_lines;
     job.fft1 = a.fft1; job.fft2 = a.fft2; job.m1_kind = a.m1_kind; job.m2_kind = a.m2_kind;
     job.store_mode = a.store_mode; job.shift_n = a.shift_n; job.shift_r = a.shift_r;
+    job.win_n0 = a.win_n0; job.win_nn = a.win_nn; job.win_r0 = a.win_r0; job.win_nr = a.win_nr;
     job.n_stages = pl.n_stages; for (int i = 0; i < pl.n_stages; ++i) job.radix[i] = pl.radix[i];
     job.scale = a.scale; job.sigma = a.sigma;
     const int N = pl.M;         // sizing follows the transform length (M > N for Bluestein lines)
@@ -451,6 +455,30 @@ int fft2_inplace(msl_handle* h, float2* buf, int images, int dir, float scale, i
     return launch_lines(h, h->plan_x, c, K_OTHER);
 }
 
+// Exit-wave epilogue, second half: FFT along x of the y-transformed exit waves in psi, fftshift of both axes and
+// scatter into slot `slot` of the (P, T_local, wx, wy) result (calculators.py:284-290).  With a k-window only the
+// columns inside it are transformed and only the rows inside it are stored.
+int epilogue_x_pass(msl_handle* h, int slot) {
+    const msl_config& c = h->cfg;
+    const int P = c.n_probes;
+    float2* dst = h->wf + (size_t)slot * h->wpix;
+    const long long out_is = (long long)c.n_frames * h->wpix;
+    const bool windowed = (h->wx != c.nx) || (h->wy != c.ny);
+    const bool fast_ok = h->Rx && (!windowed || (c.ny % 32 == 0 && h->wy % 32 == 0));
+    if (fast_ok) {
+        ColJob k = col_job(h, h->psi, dst, P, h->pitch, h->wy);
+        k.flags = COL_FWD | COL_SHIFT; k.out_image_stride = out_is;
+        if (windowed) { k.win_c0 = h->wy0; k.win_nc = h->wy; k.win_x0 = h->wx0; k.win_nx = h->wx; }
+        return launch_col_fast(h, k, K_OTHER);
+    }
+    LineArgs k = col_args(h, h->psi, dst, P, h->pitch, h->wy);
+    k.fft1 = +1;
+    k.out_is = out_is;
+    k.shift_n = c.nx / 2; k.shift_r = c.ny / 2;
+    if (windowed) { k.win_n0 = h->wx0; k.win_nn = h->wx; k.win_r0 = h->wy0; k.win_nr = h->wy; }
+    return launch_lines(h, h->plan_x, k, K_OTHER);
+}
+
 // ---- one-pass-per-slice path ------------------------------------------------------------------------
 // psi0 (P, nx, pitch) -> psi0T (P, ny, pitchT): needed when the first pass of the slice loop runs along x
 int transpose_probes(msl_handle* h) {
@@ -585,17 +613,7 @@ int slice_loop_onepass_b(msl_handle* h, int fused_slot) {
             r.fft1 = +1;
             if ((rc = launch_lines(h, h->plan_y, r, K_OTHER))) return rc;
         }
-        if (h->Rx) {
-            ColJob k = col_job(h, h->psi, h->wf + (size_t)fused_slot * npix, P, h->pitch, c.ny);
-            k.flags = COL_FWD | COL_SHIFT; k.out_image_stride = (long long)c.n_frames * npix;
-            if ((rc = launch_col_fast(h, k, K_OTHER))) return rc;
-        } else {
-            LineArgs k = col_args(h, h->psi, h->wf + (size_t)fused_slot * npix, P, h->pitch, c.ny);
-            k.fft1 = +1;
-            k.out_is = (long long)c.n_frames * npix;
-            k.shift_n = c.nx / 2; k.shift_r = c.ny / 2;
-            if ((rc = launch_lines(h, h->plan_x, k, K_OTHER))) return rc;
-        }
+        if ((rc = epilogue_x_pass(h, fused_slot))) return rc;
     }
     h->cur = nullptr;
     h->ctr.slice_steps += (uint64_t)P * nz;
@@ -663,11 +681,7 @@ int slice_loop_onepass(msl_handle* h, int fused_slot) {
         }
         if (rc) return rc;
     }
-    if (fused) {
-        ColJob k = col_job(h, h->psi, h->wf + (size_t)fused_slot * npix, P, h->pitch, c.ny);
-        k.flags = COL_FWD | COL_SHIFT; k.out_image_stride = (long long)c.n_frames * npix;
-        if ((rc = launch_col_fast(h, k, K_OTHER))) return rc;
-    }
+    if (fused && (rc = epilogue_x_pass(h, fused_slot))) return rc;
     h->cur = nullptr;
     h->ctr.slice_steps += (uint64_t)P * nz;
     h->ctr.frames += 1;
@@ -730,17 +744,7 @@ int slice_loop(msl_handle* h, int fused_slot) {
     }
     if (fused) {
         // epilogue: fft along x, fftshift both axes, scatter into (P, T_local, nx, ny)
-        if (h->Rx) {
-            ColJob k = col_job(h, h->psi, h->wf + (size_t)fused_slot * npix, P, h->pitch, c.ny);
-            k.flags = COL_FWD | COL_SHIFT; k.out_image_stride = (long long)c.n_frames * npix;
-            if ((rc = launch_col_fast(h, k, K_OTHER))) return rc;
-        } else {
-            LineArgs k = col_args(h, h->psi, h->wf + (size_t)fused_slot * npix, P, h->pitch, c.ny);
-            k.fft1 = +1;
-            k.out_is = (long long)c.n_frames * npix;
-            k.shift_n = c.nx / 2; k.shift_r = c.ny / 2;
-            if ((rc = launch_lines(h, h->plan_x, k, K_OTHER))) return rc;
-        }
+        if ((rc = epilogue_x_pass(h, fused_slot))) return rc;
     }
     h->cur = nullptr;
     h->ctr.slice_steps += (uint64_t)P * nz;
@@ -811,9 +815,18 @@ int msl_create(const msl_config* cfg, msl_handle** out) {
         return fail(nullptr, MSL_ERR_HIP, "msl_create: no HIP device available (%s)", hipGetErrorString(e));
     if (cfg->device < 0 || cfg->device >= ndev)
         return fail(nullptr, MSL_ERR_INVALID, "msl_create: device %d out of range (have %d)", cfg->device, ndev);
+    if (cfg->window_nx < 0 || cfg->window_nx > cfg->nx || cfg->window_ny < 0 || cfg->window_ny > cfg->ny)
+        return fail(nullptr, MSL_ERR_INVALID, "msl_create: k-window %d x %d outside the %d x %d grid", cfg->window_nx, cfg->window_ny,
+                    cfg->nx, cfg->ny);
     msl_handle* h = new (std::nothrow) msl_handle();
     if (!h) return fail(nullptr, MSL_ERR_NOMEM, "msl_create: out of host memory");
     h->cfg = *cfg;
+    // k-window, centred on the DC pixel of the fftshifted spectrum (index n/2): [n/2 - w/2, n/2 - w/2 + w)
+    h->wx = cfg->window_nx ? cfg->window_nx : cfg->nx;
+    h->wy = cfg->window_ny ? cfg->window_ny : cfg->ny;
+    h->wx0 = cfg->nx / 2 - h->wx / 2;
+    h->wy0 = cfg->ny / 2 - h->wy / 2;
+    h->wpix = (size_t)h->wx * h->wy;
     auto bail = [&](int rc) { g_create_error = h->err; msl_destroy(h); return rc; };
     if (hipSetDevice(cfg->device) != hipSuccess) return bail(fail(h, MSL_ERR_HIP, "hipSetDevice(%d) failed", cfg->device));
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(h, MSL_ERR_HIP, "hipStreamCreate failed"));
@@ -889,8 +902,8 @@ int msl_create(const msl_config* cfg, msl_handle** out) {
     if ((rc = dalloc(h, &h->trans, npix * cfg->nz))) return bail(rc);
     if (cfg->keep_potential && (rc = dalloc(h, &h->V, npix * cfg->nz))) return bail(rc);
     if (cfg->n_frames > 0) {
-        if ((rc = dalloc(h, &h->wf, npix * cfg->n_probes * cfg->n_frames))) return bail(rc);
-        if (hipMemsetAsync(h->wf, 0, npix * cfg->n_probes * cfg->n_frames * sizeof(float2), h->stream) != hipSuccess)
+        if ((rc = dalloc(h, &h->wf, h->wpix * cfg->n_probes * cfg->n_frames))) return bail(rc);
+        if (hipMemsetAsync(h->wf, 0, h->wpix * cfg->n_probes * cfg->n_frames * sizeof(float2), h->stream) != hipSuccess)
             return bail(fail(h, MSL_ERR_HIP, "memset failed"));
     }
     if ((rc = dalloc(h, &h->pxt, (size_t)cfg->nx))) return bail(rc);
@@ -1224,7 +1237,7 @@ int msl_tacaw(msl_handle* h, const void* d_src, void* d_dst, int64_t batch, int3
     float* dst = (float*)d_dst;
     if (!src) {
         if (!h->wf) return fail(h, MSL_ERR_STATE, "msl_tacaw: no wavefunction buffer");
-        src = h->wf; batch = c.n_probes; T = c.n_frames; npix = (int64_t)c.nx * c.ny;
+        src = h->wf; batch = c.n_probes; T = c.n_frames; npix = (int64_t)h->wpix;
         size_t need = (size_t)batch * T * npix;
         if (h->intensity_elems != need) {
             int rc = dalloc(h, &h->intensity, need);
@@ -1289,7 +1302,7 @@ size_t msl_buffer_bytes(const msl_handle* h, msl_buffer what) {
         case MSL_BUF_PROBES: case MSL_BUF_EXIT: return npix * c.n_probes * 8;
         case MSL_BUF_POTENTIAL: return h->V ? npix * c.nz * 4 : 0;
         case MSL_BUF_TRANSMISSION: return npix * c.nz * 8;
-        case MSL_BUF_WAVEFUNCTION: return h->wf ? npix * c.n_probes * c.n_frames * 8 : 0;
+        case MSL_BUF_WAVEFUNCTION: return h->wf ? h->wpix * c.n_probes * c.n_frames * 8 : 0;
         case MSL_BUF_INTENSITY: return h->intensity_elems * 4;
         case MSL_BUF_FORMFACTOR: return npix * h->n_species * 4;
     }
@@ -1323,7 +1336,7 @@ static int intensity_source(msl_handle* h, const char* who, const void** src, in
     if (!h) return fail(h, MSL_ERR_INVALID, "null handle");
     if (!*src) {
         if (!h->intensity || h->intensity_elems == 0) return fail(h, MSL_ERR_STATE, "%s: no intensity (call msl_tacaw)", who);
-        *src = h->intensity; *B = h->cfg.n_probes; *F = h->cfg.n_frames; *K = (int64_t)h->cfg.nx * h->cfg.ny;
+        *src = h->intensity; *B = h->cfg.n_probes; *F = h->cfg.n_frames; *K = (int64_t)h->wpix;
     }
     if (*B < 1 || *F < 1 || *K < 1) return fail(h, MSL_ERR_INVALID, "%s: bad shape (%lld,%lld,%lld)", who, (long long)*B, (long long)*F, (long long)*K);
     if (*B * *F > 0x7fffffffLL) return fail(h, MSL_ERR_UNSUPPORTED, "%s: more than 2^31 rows", who);
@@ -1377,7 +1390,7 @@ int msl_adf(msl_handle* h, const void* d_src_c64, int64_t B, int64_t T, int64_t 
     if (!h || !out) return fail(h, MSL_ERR_INVALID, "msl_adf: null argument");
     if (!d_src_c64) {
         if (!h->wf) return fail(h, MSL_ERR_STATE, "msl_adf: no wavefunction buffer");
-        d_src_c64 = h->wf; B = h->cfg.n_probes; T = h->cfg.n_frames; K = (int64_t)h->cfg.nx * h->cfg.ny;
+        d_src_c64 = h->wf; B = h->cfg.n_probes; T = h->cfg.n_frames; K = (int64_t)h->wpix;
     }
     if (B < 1 || T < 1 || K < 1) return fail(h, MSL_ERR_INVALID, "msl_adf: bad shape");
     if (T > 65535) return fail(h, MSL_ERR_UNSUPPORTED, "msl_adf: more than 65535 frames");
@@ -1481,10 +1494,10 @@ static int frame_copy(msl_handle* h, int32_t slot, void* host, size_t bytes, boo
     if (!h->wf) return fail(h, MSL_ERR_STATE, "frame copy: handle created with n_frames == 0");
     const msl_config& c = h->cfg;
     if (slot < 0 || slot >= c.n_frames) return fail(h, MSL_ERR_INVALID, "frame copy: slot %d out of range [0,%d)", slot, c.n_frames);
-    const size_t npix = (size_t)c.nx * c.ny;
+    const size_t npix = h->wpix;                    // one (wx, wy) image of the stored window
     if (bytes != npix * c.n_probes * sizeof(float2)) return fail(h, MSL_ERR_INVALID, "frame copy: buffer holds %zu bytes, a frame is %zu", bytes, npix * c.n_probes * sizeof(float2));
     HIPCHK(h, hipSetDevice(c.device));
-    // (P, T, nx, ny) device <-> (P, nx, ny) host: P strided blocks of one image
+    // (P, T, wx, wy) device <-> (P, wx, wy) host: P strided blocks of one image
     float2* dev = h->wf + (size_t)slot * npix;
     if (to_host)
         HIPCHK(h, hipMemcpy2DAsync(host, npix * sizeof(float2), dev, (size_t)c.n_frames * npix * sizeof(float2), npix * sizeof(float2),

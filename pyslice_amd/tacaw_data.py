@@ -55,7 +55,7 @@ class TACAWData(WFData):
             self._intensity_src = (eng, None)          # reductions read the library's own buffer
             if self.__dict__.get("_output") == "device":
                 ptr = eng.device_ptr(_native.BUF_INTENSITY)
-                shape = (eng.n_probes, eng.n_frames, eng.nx, eng.ny)
+                shape = (eng.n_probes, eng.n_frames, eng.wx, eng.wy)
                 self.intensity = torch.as_tensor(_native.DeviceArray(ptr, shape, "<f4", owner=eng), device=f"cuda:{eng.device}")
             else:
                 self.intensity = _as_tensor(eng.intensity().astype(np.float64))
@@ -86,7 +86,7 @@ class TACAWData(WFData):
         complete time series, one gather assembles the result."""
         from . import distributed as D
         n_frames, t_local = shard
-        P, nx, ny = eng.n_probes, eng.nx, eng.ny
+        P, nx, ny = eng.n_probes, eng.wx, eng.wy
         ptr = eng.device_ptr(_native.BUF_WAVEFUNCTION)
         dev = torch.device("cuda", eng.device)
         local = torch.as_tensor(_native.DeviceArray(ptr, (P, eng.n_frames, nx, ny), "<c8", owner=eng), device=dev)[:, :t_local]
@@ -108,7 +108,7 @@ class TACAWData(WFData):
         d = self.__dict__
         eng, dev = d.get("_intensity_src", (None, None))
         if dev is None and eng is not None:
-            return eng, None, (eng.n_probes, eng.n_frames, eng.nx * eng.ny), eng.device_ptr(_native.BUF_INTENSITY)
+            return eng, None, (eng.n_probes, eng.n_frames, eng.wx * eng.wy), eng.device_ptr(_native.BUF_INTENSITY)
         if dev is None:
             # intensity assembled elsewhere: stage a float32 copy on the device once
             if not TORCH_AVAILABLE or not torch.cuda.is_available():

@@ -389,6 +389,52 @@ def test_calculator_oracle_parity_onepass_2r2_lengths(ps, orc, nx, ny, nz, P):
     assert rel_l2(t, np.exp(1j * orc.interaction_sigma(100e3) * np.moveaxis(V, 2, 0))) < 1e-4
 
 
+@pytest.mark.parametrize("nx,ny,nz,window", [(256, 256, 4, (64, 96)), (256, 256, 3, (50, 40)), (128, 96, 3, (33, 64)),
+                                              (512, 512, 3, (128, 64)), (256, 1024, 2, (256, 128)), (64, 64, 2, (64, 1))])
+def test_k_window_is_a_crop_of_the_full_spectrum(ps, orc, nx, ny, nz, window):
+    """k_window=(wx,wy) keeps the central pixels of fftshift(fft2(exit)): equal to cropping the oracle's full result;
+    aligned windows on four-step grids only transform the kept columns, other shapes go through the generic store.
+    TACAW is per pixel, so TACAWData on the window equals the crop of the full intensity."""
+    from pyslice_amd.synthetic import synthetic_trajectory
+    tr = synthetic_trajectory(nx, nz, 4, ny=ny, density=0.03, seed=77)
+    lx, ly = tr.box_matrix[0, 0], tr.box_matrix[1, 1]
+    pp = [(lx / 2, ly / 2), (0.3 * lx, 0.8 * ly)]
+    calc = ps.MultisliceCalculator(progress=False, k_window=window)
+    calc.setup(tr, aperture=30.0, voltage_eV=100e3, probe_positions=pp)
+    wf = calc.run()
+    wx, wy = window
+    x0, y0 = nx // 2 - wx // 2, ny // 2 - wy // 2
+    ref = orc.run_frames(tr.box_matrix, tr.positions, tr.atom_types, 30.0, 100e3, pp)
+    full_wf = ref["wavefunction_data"]
+    want = full_wf[:, :, x0:x0 + wx, y0:y0 + wy]
+    got = npy(wf.wavefunction_data)
+    assert got.shape == (2, 4, wx, wy, 1)
+    scale = np.linalg.norm(full_wf) * np.sqrt(wx * wy / (nx * ny))
+    assert np.linalg.norm(got - want) / max(np.linalg.norm(want), scale) < WAVE_TOL
+    kxs, kys, time = orc.wf_axes(nx, ny, 0.1, 4, tr.timestep)
+    assert np.allclose(npy(wf.kxs), kxs[x0:x0 + wx]) and np.allclose(npy(wf.kys), kys[y0:y0 + wy])
+    tac = ps.TACAWData(wf)
+    _, full_I = orc.tacaw(full_wf, time)
+    want_I = full_I[:, :, x0:x0 + wx, y0:y0 + wy]
+    got_I = npy(tac.intensity)
+    assert got_I.shape == want_I.shape
+    assert np.linalg.norm(got_I - want_I) / max(np.linalg.norm(want_I), 1e-30) < TACAW_TOL
+    assert rel_l2(tac.spectrum(1), want_I[1].sum(axis=(1, 2))) < TACAW_TOL
+    assert rel_l2(tac.diffraction(None), want_I.sum(axis=1).mean(axis=0)) < TACAW_TOL
+
+
+def test_k_window_argument_errors(ps):
+    from pyslice_amd.synthetic import synthetic_trajectory
+    tr = synthetic_trajectory(32, 2, 1, density=0.05, seed=1)
+    with pytest.raises(ValueError):
+        ps.MultisliceCalculator(progress=False, k_window=(0, 8))
+    with pytest.raises(ValueError):
+        ps.MultisliceCalculator(progress=False, k_window=(8, 8), cache=True)
+    calc = ps.MultisliceCalculator(progress=False, k_window=(64, 8))
+    with pytest.raises(ValueError):
+        calc.setup(tr)                           # window larger than the 32 x 32 grid
+
+
 def test_oracle_parity_prime_grid(ps, orc):
     """Grid lengths with large prime factors (101 x 97, like the reference's 501 x 491 probe test grid) take the
     Bluestein path; potential, probes and slice loop must still match the oracle."""
