@@ -72,6 +72,7 @@ struct msl_handle {
     int pitchT = 0;
     int rowT_variant = 0;
     int debug_flags_mask = -1;
+    int debug_flags_or = 0;
     int row_pchunk = 0;         // 0 = auto (MSL_ROW_PCHUNK)
     int row_variant = 1;        // 0: plain row kernel, 1: software-pipelined (MSL_ROW_VARIANT)
     int pitch = 0;              // row pitch (elements) of psi0/psi; > ny de-aliases the column pass's 128-byte segments
@@ -307,20 +308,42 @@ int launch_lines(msl_handle* h, const FftPlan& pl, const LineArgs& a, int kind) 
     job.scale = a.scale; job.sigma = a.sigma;
     const int N = pl.M;         // sizing follows the transform length (M > N for Bluestein lines)
     job.M = pl.M; job.chirp = pl.chirp; job.bfilt = pl.bfilt;
-    const int max_elems = MSL_GEN_E * 1024;
-    int C;
-    if (a.contiguous_lines) C = 16; else C = std::max(1, std::min(16, 8192 / N));
-    C = (int)std::min<long long>(C, a.n_lines);
-    job.npad = a.contiguous_lines ? N + 1 : N;
-    auto lds_need = [&](int c, bool tw) { return (size_t)c * job.npad * 8 + (tw ? (size_t)N * 8 : 0); };
-    while (C > 1 && ((long long)C * N > max_elems || lds_need(C, false) > (size_t)h->lds_limit)) C >>= 1;
-    if ((long long)C * N > max_elems || lds_need(C, false) > (size_t)h->lds_limit)
-        return fail(h, MSL_ERR_UNSUPPORTED, "line length %d too long for the LDS kernel", pl.N);
-    job.C = C;
-    job.tw_in_lds = lds_need(C, true) <= (size_t)h->lds_limit ? 1 : 0;
-    size_t lds = lds_need(C, job.tw_in_lds != 0);
-    int nthreads = (int)(((long long)C * N + MSL_GEN_E - 1) / MSL_GEN_E);
-    nthreads = std::min(1024, std::max(64, (nthreads + 63) / 64 * 64));
+    bool has5 = false;
+    for (int i = 0; i < pl.n_stages; ++i) has5 |= (pl.radix[i] == 5);
+    // values per thread the plan's radices allow under either radix-5 policy (16 for powers of two, 14 with a 7, ...)
+    auto elems_per_thread = [&](bool ceil5) {
+        int e = MSL_GEN_E;
+        for (int i = 0; i < pl.n_stages; ++i) e = std::min(e, gen_elems_per_thread(pl.radix[i], ceil5));
+        return e;
+    };
+    int C = 1, nthreads = 64;
+    size_t lds = 0;
+    // tile of C lines, block size, and the resident waves per CU that result (128 VGPRs: at most 16)
+    auto configure = [&](bool ceil5) -> long long {
+        const int epl = elems_per_thread(ceil5);
+        const int max_elems = epl * 1024;
+        if (a.contiguous_lines) C = 16; else C = std::max(1, std::min(16, 8192 / N));
+        C = (int)std::min<long long>(C, a.n_lines);
+        job.npad = a.contiguous_lines ? N + 1 : N;
+        auto lds_need = [&](int c, bool tw) { return (size_t)MSL_GEN_HEADER + (size_t)c * job.npad * 8 + (tw ? (size_t)N * 8 : 0); };
+        while (C > 1 && ((long long)C * N > max_elems || lds_need(C, false) > (size_t)h->lds_limit)) C >>= 1;
+        if ((long long)C * N > max_elems || lds_need(C, false) > (size_t)h->lds_limit) return -1;
+        job.C = C;
+        job.tw_in_lds = lds_need(C, true) <= (size_t)h->lds_limit ? 1 : 0;
+        lds = lds_need(C, job.tw_in_lds != 0);
+        nthreads = (int)(((long long)C * N + epl - 1) / epl);
+        nthreads = std::min(1024, std::max(64, (nthreads + 63) / 64 * 64));
+        const int waves = nthreads / 64;
+        const long long wgs = std::min<long long>((long long)(h->lds_limit / lds), 16 / waves);
+        return std::max<long long>(1, wgs) * waves;              // resident waves per CU
+    };
+    bool ceil5 = false;
+    long long score = configure(false);
+    if (has5) {
+        const long long score5 = configure(true);
+        if (score5 > score) ceil5 = true; else score = configure(false);
+    }
+    if (score < 0) return fail(h, MSL_ERR_UNSUPPORTED, "line length %d too long for the LDS kernel", pl.N);
     long long tiles = (a.n_lines + C - 1) / C;
     if (tiles > 0x7fffffffLL) return fail(h, MSL_ERR_UNSUPPORTED, "too many FFT tiles");
     int rset = 0;
@@ -328,9 +351,12 @@ int launch_lines(msl_handle* h, const FftPlan& pl, const LineArgs& a, int kind) 
         if (pl.radix[i] == 3 || pl.radix[i] == 5 || pl.radix[i] == 7) rset = std::max(rset, 1);
         if (pl.radix[i] > 8) rset = 2;
     }
-    if (rset == 0) hipLaunchKernelGGL(line_fft_kernel<0>, dim3((unsigned)tiles), dim3(nthreads), lds, h->stream, job);
-    else if (rset == 1) hipLaunchKernelGGL(line_fft_kernel<1>, dim3((unsigned)tiles), dim3(nthreads), lds, h->stream, job);
-    else hipLaunchKernelGGL(line_fft_kernel<2>, dim3((unsigned)tiles), dim3(nthreads), lds, h->stream, job);
+    const dim3 grid((unsigned)tiles), block(nthreads);
+    if (rset == 0) hipLaunchKernelGGL((line_fft_kernel<0, false>), grid, block, lds, h->stream, job);
+    else if (rset == 1 && !ceil5) hipLaunchKernelGGL((line_fft_kernel<1, false>), grid, block, lds, h->stream, job);
+    else if (rset == 1) hipLaunchKernelGGL((line_fft_kernel<1, true>), grid, block, lds, h->stream, job);
+    else if (!ceil5) hipLaunchKernelGGL((line_fft_kernel<2, false>), grid, block, lds, h->stream, job);
+    else hipLaunchKernelGGL((line_fft_kernel<2, true>), grid, block, lds, h->stream, job);
     HIPCHK(h, hipGetLastError());
     return mark_launch(h, kind);
 }
@@ -657,6 +683,7 @@ int slice_loop_onepass(msl_handle* h, int fused_slot) {
         const bool last = (k == nz - 1);
         int flags = (k > 0 ? P2_PRE_A : 0) | (!last ? P2_POST_A : 0) | ((last && fused) ? P2_POST_F : 0);
         if (h->debug_flags_mask >= 0) flags &= h->debug_flags_mask;     // timing experiments only (MSL_DEBUG_FLAGS_MASK)
+        flags |= h->debug_flags_or;
         if (last) {
             Row2Job j{};
             j.psi = h->psi; j.trans = h->trans + (size_t)k * npix; j.py = h->pyt; j.tw = h->tw4_y;
@@ -830,9 +857,11 @@ int msl_create(const msl_config* cfg, msl_handle** out) {
     auto bail = [&](int rc) { g_create_error = h->err; msl_destroy(h); return rc; };
     if (hipSetDevice(cfg->device) != hipSuccess) return bail(fail(h, MSL_ERR_HIP, "hipSetDevice(%d) failed", cfg->device));
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(h, MSL_ERR_HIP, "hipStreamCreate failed"));
-    (void)hipFuncSetAttribute((const void*)line_fft_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
-    (void)hipFuncSetAttribute((const void*)line_fft_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
-    (void)hipFuncSetAttribute((const void*)line_fft_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
+    (void)hipFuncSetAttribute((const void*)line_fft_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
+    (void)hipFuncSetAttribute((const void*)line_fft_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
+    (void)hipFuncSetAttribute((const void*)line_fft_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
+    (void)hipFuncSetAttribute((const void*)line_fft_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
+    (void)hipFuncSetAttribute((const void*)line_fft_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
     int rc;
     if ((rc = make_plan(h, h->plan_x, cfg->nx))) return bail(rc);
     if ((rc = make_plan(h, h->plan_y, cfg->ny))) return bail(rc);
@@ -895,6 +924,7 @@ int msl_create(const msl_config* cfg, msl_handle** out) {
             if ((rc = dalloc(h, &h->transT, npix * cfg->nz))) return bail(rc);
             { const char* ev = getenv("MSL_ROWT_VARIANT"); if (ev) h->rowT_variant = atoi(ev); }
             { const char* ev = getenv("MSL_DEBUG_FLAGS_MASK"); if (ev) h->debug_flags_mask = atoi(ev); }
+            { const char* ev = getenv("MSL_DEBUG_FLAGS_OR"); if (ev) h->debug_flags_or = atoi(ev); }
             (void)hipFuncSetAttribute((const void*)row_pass2_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
             (void)hipFuncSetAttribute((const void*)row_pass2_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
         }
