@@ -16,6 +16,7 @@ namespace msl {
 
 #define MSL_MAX_STAGES 16
 #define MSL_GEN_E 16            // complex values held per thread between the two barriers of a stage
+#define MSL_GEN_STEPS 4         // FFT / multiply steps of one launch (the one-pass slice kernel needs four)
 #define MSL_GEN_HEADER 512      // bytes of per-line address bases in front of the LDS tile
 
 // complex values per thread the block size is computed from (see stockham_stage); ceil5 selects the kernel variant
@@ -30,7 +31,6 @@ struct LineJob {
     float2* out;
     float* out_real;            // STORE_POTENTIAL: V (may be null);  STORE_INTENSITY: intensity
     const float2* tw;           // W_N^j = exp(-2 pi i j / N), j < N (device)
-    const float2* m1;           // after FFT a
     const float2* m2;           // at store
     long long n_lines;
     long long in_es, in_ls, in_is;     // element / line / image strides (float2 units)
@@ -39,8 +39,13 @@ struct LineJob {
     long long m2_ls;
     int N, C, lines_per_image;
     int contiguous_lines;       // 1: neighbouring lines are neighbouring addresses (column / time pass)
-    int fft1, fft2;             // 0 none, +1 forward, -1 inverse (both unnormalised)
-    int m1_kind, m2_kind;
+    // the launch is a short program on the LDS tile: step i = [FFT fft[i]] then [x mul[i]]; then the store (x m2, scale ...)
+    int n_steps;
+    int fft[MSL_GEN_STEPS];     // 0 none, +1 forward, -1 inverse (both unnormalised)
+    int mkind[MSL_GEN_STEPS];   // MUL_NONE / MUL_VEC (mul[i][n]) / MUL_ARRAY (mul[i][r*m1_ls + n]; one array step at most)
+    const float2* mul[MSL_GEN_STEPS];
+    int m2_kind;
+    int out_contiguous;         // store mapping: 1 = neighbouring lines are neighbouring output addresses (transposing store)
     int store_mode;
     int shift_n, shift_r;       // out index: ((n+shift_n)%N, (r+shift_r)%lines_per_image)
     int win_n0, win_nn, win_r0, win_nr;   // win_nn > 0: keep only out indices [win_n0, +win_nn) x [win_r0, +win_nr), rebased to 0
@@ -283,31 +288,34 @@ __global__ void __launch_bounds__(1024) line_fft_kernel(LineJob job) {
     const int elems = C * N;
     const float inv_c = 1.0f / (float)C, inv_n = 1.0f / (float)N;
     // element e of the tile -> (line c, position n); neighbouring threads touch neighbouring addresses
-    auto split = [&](int e, int& c, int& n) {
-        if (job.contiguous_lines) { n = fast_div(e, inv_c); c = e - n * C; } else { c = fast_div(e, inv_n); n = e - c * N; }
+    auto split = [&](int e, int lines_fastest, int& c, int& n) {
+        if (lines_fastest) { n = fast_div(e, inv_c); c = e - n * C; } else { c = fast_div(e, inv_n); n = e - c * N; }
     };
     // ---- load
     for (int e = tid; e < elems; e += nthreads) {
         int c, n;
-        split(e, c, n);
+        split(e, job.contiguous_lines, c, n);
         tile[c * npad + n] = job.in[s_in[c] + (long long)n * job.in_es];
     }
     __syncthreads();
-    if (job.fft1) tile_fft<RSET, CEIL5>(tile, tw, job, C, job.fft1, tid, nthreads);
-    if (job.m1_kind != MUL_NONE) {
-        for (int e = tid; e < elems; e += nthreads) {
-            const int c = fast_div(e, inv_n), n = e - c * N;
-            const float2 m = (job.m1_kind == MUL_VEC) ? job.m1[n] : job.m1[s_m1[c] + n];
-            float2* p = tile + c * npad + n;
-            *p = cmul(*p, m);
+    for (int st = 0; st < job.n_steps; ++st) {
+        if (job.fft[st]) tile_fft<RSET, CEIL5>(tile, tw, job, C, job.fft[st], tid, nthreads);
+        if (job.mkind[st] != MUL_NONE) {
+            const float2* mp = job.mul[st];
+            const bool vec = job.mkind[st] == MUL_VEC;
+            for (int e = tid; e < elems; e += nthreads) {
+                const int c = fast_div(e, inv_n), n = e - c * N;
+                const float2 m = vec ? mp[n] : mp[s_m1[c] + n];
+                float2* p = tile + c * npad + n;
+                *p = cmul(*p, m);
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
-    if (job.fft2) tile_fft<RSET, CEIL5>(tile, tw, job, C, job.fft2, tid, nthreads);
     // ---- store
     for (int e = tid; e < elems; e += nthreads) {
         int c, n;
-        split(e, c, n);
+        split(e, job.out_contiguous, c, n);
         const long long ob = s_out[c];
         if (ob < 0) continue;
         float2 v = tile[c * npad + n];

@@ -64,8 +64,8 @@ struct msl_handle {
     size_t scratch_bytes = 0;
     bool onepass = false;
     bool scheme_b = false;         // a direction of 2R^2 points: every pass transposes, first pass along y, final transpose if nz is odd
-    // one-pass capability per direction: R (0 = none), two = line length 2 R^2, tables (tw2 / ptab only for two)
-    struct OpDir { int R = 0; bool two = false; float2* tw = nullptr; float2* tw2 = nullptr; float2* ptab = nullptr; } opx, opy;
+    // one-pass kernel per direction: R^2 register kernel, 2 R^2 (two) register kernel with its tables, or the generic LDS kernel
+    struct OpDir { int R = 0; bool two = false; bool generic = false; float2* tw = nullptr; float2* tw2 = nullptr; float2* ptab = nullptr; } opx, opy;
     float2* psiT = nullptr;
     float2* psi0T = nullptr;
     float2* transT = nullptr;
@@ -288,8 +288,12 @@ struct LineArgs {
     long long n_lines = 0; int lines_per_image = 1;
     long long in_es = 1, in_ls = 0, in_is = 0, out_es = 1, out_ls = 0, out_is = 0;
     int contiguous_lines = 0;
-    int fft1 = 0, fft2 = 0;
+    int fft1 = 0, fft2 = 0;         // the common two-step form: [fft1] x m1 [fft2] store(x m2)
     int m1_kind = MUL_NONE, m2_kind = MUL_NONE; const float2* m1 = nullptr; const float2* m2 = nullptr;
+    // general form (used when n_steps > 0): step i = [FFT fft[i]] then [x mul[i]]
+    int n_steps = 0; int fft[MSL_GEN_STEPS] = {0, 0, 0, 0}; int mkind[MSL_GEN_STEPS] = {0, 0, 0, 0};
+    const float2* mul[MSL_GEN_STEPS] = {nullptr, nullptr, nullptr, nullptr};
+    int out_contiguous = -1;        // store mapping; -1 = same as contiguous_lines
     long long m1_ls = 0, m2_ls = 0;
     int store_mode = STORE_C64; int shift_n = 0, shift_r = 0; float scale = 1.f; float sigma = 0.f;
     int win_n0 = 0, win_nn = 0, win_r0 = 0, win_nr = 0;      // win_nn > 0: store only the window of the shifted output
@@ -297,11 +301,20 @@ struct LineArgs {
 
 int launch_lines(msl_handle* h, const FftPlan& pl, const LineArgs& a, int kind) {
     LineJob job{};
-    job.in = a.in; job.out = a.out; job.out_real = a.out_real; job.tw = pl.tw; job.m1 = a.m1; job.m2 = a.m2;
+    job.in = a.in; job.out = a.out; job.out_real = a.out_real; job.tw = pl.tw; job.m2 = a.m2;
     job.n_lines = a.n_lines; job.in_es = a.in_es; job.in_ls = a.in_ls; job.in_is = a.in_is;
     job.out_es = a.out_es; job.out_ls = a.out_ls; job.out_is = a.out_is; job.m1_ls = a.m1_ls; job.m2_ls = a.m2_ls;
     job.N = pl.N; job.lines_per_image = a.lines_per_image; job.contiguous_lines = a.contiguous_lines;
-    job.fft1 = a.fft1; job.fft2 = a.fft2; job.m1_kind = a.m1_kind; job.m2_kind = a.m2_kind;
+    job.m2_kind = a.m2_kind;
+    if (a.n_steps > 0) {
+        job.n_steps = a.n_steps;
+        for (int i = 0; i < a.n_steps; ++i) { job.fft[i] = a.fft[i]; job.mkind[i] = a.mkind[i]; job.mul[i] = a.mul[i]; }
+    } else {
+        job.n_steps = 2;
+        job.fft[0] = a.fft1; job.mkind[0] = a.m1_kind; job.mul[0] = a.m1;
+        job.fft[1] = a.fft2; job.mkind[1] = MUL_NONE; job.mul[1] = nullptr;
+    }
+    job.out_contiguous = a.out_contiguous < 0 ? a.contiguous_lines : a.out_contiguous;
     job.store_mode = a.store_mode; job.shift_n = a.shift_n; job.shift_r = a.shift_r;
     job.win_n0 = a.win_n0; job.win_nn = a.win_nn; job.win_r0 = a.win_r0; job.win_nr = a.win_nr;
     job.n_stages = pl.n_stages; for (int i = 0; i < pl.n_stages; ++i) job.radix[i] = pl.radix[i];
@@ -324,7 +337,7 @@ int launch_lines(msl_handle* h, const FftPlan& pl, const LineArgs& a, int kind) 
         const int max_elems = epl * 1024;
         if (a.contiguous_lines) C = 16; else C = std::max(1, std::min(16, 8192 / N));
         C = (int)std::min<long long>(C, a.n_lines);
-        job.npad = a.contiguous_lines ? N + 1 : N;
+        job.npad = (a.contiguous_lines || job.out_contiguous) ? (N | 1) : N;      // odd pitch: conflict-free when lines are the fast index
         auto lds_need = [&](int c, bool tw) { return (size_t)MSL_GEN_HEADER + (size_t)c * job.npad * 8 + (tw ? (size_t)N * 8 : 0); };
         while (C > 1 && ((long long)C * N > max_elems || lds_need(C, false) > (size_t)h->lds_limit)) C >>= 1;
         if ((long long)C * N > max_elems || lds_need(C, false) > (size_t)h->lds_limit) return -1;
@@ -584,8 +597,32 @@ int launch_rowT2_r(msl_handle* h, RowTJob job, int kind) {
     return mark_launch(h, kind);
 }
 
-// one transposing pass along direction `o` (either line length R^2 or 2 R^2)
+// one transposing pass along direction `o`: register kernels for R^2 and 2 R^2 points, else the generic LDS kernel
+// running the same program (fft, x P, ifft, x t, fft, x P, ifft) with a transposing store
 int launch_rowT_dir(msl_handle* h, const msl_handle::OpDir& o, RowTJob job, int kind) {
+    if (o.generic) {
+        const FftPlan& pl = (&o == &h->opx) ? h->plan_x : h->plan_y;
+        LineArgs a;
+        a.in = job.in; a.out = job.out;
+        a.n_lines = (long long)job.n_images * job.n_lines; a.lines_per_image = job.n_lines;
+        a.in_es = 1; a.in_ls = job.in_pitch; a.in_is = job.in_image_stride;
+        a.out_es = job.out_pitch; a.out_ls = 1; a.out_is = job.out_image_stride;
+        a.contiguous_lines = 0; a.out_contiguous = 1;
+        a.m1_ls = pl.N;
+        int n = 0;
+        if (job.flags & P2_PRE_A) {
+            a.fft[n] = +1; a.mkind[n] = MUL_VEC; a.mul[n] = job.pl; ++n;
+            a.fft[n] = -1; a.mkind[n] = MUL_ARRAY; a.mul[n] = job.trans; ++n;
+        } else {
+            a.fft[n] = 0; a.mkind[n] = MUL_ARRAY; a.mul[n] = job.trans; ++n;
+        }
+        if (job.flags & P2_POST_A) {
+            a.fft[n] = +1; a.mkind[n] = MUL_VEC; a.mul[n] = job.pl; ++n;
+            a.fft[n] = -1; a.mkind[n] = MUL_NONE; a.mul[n] = nullptr; ++n;
+        }
+        a.n_steps = n;
+        return launch_lines(h, pl, a, kind);
+    }
     job.tw = o.tw;
     if (o.two) {
         job.tw2 = o.tw2; job.pl = o.ptab;
@@ -893,10 +930,17 @@ int msl_create(const msl_config* cfg, msl_handle** out) {
     {
         const char* e = getenv("MSL_SLICE_PATH");           // 2 = force the two-pass four-step loop
         const bool want = cfg->fft_path == 0 && !(e && atoi(e) == 2);
-        auto setup_dir = [&](msl_handle::OpDir& o, int n, int Rfast, float2* tw4) -> int {
-            if (Rfast) { o.R = Rfast; o.two = false; o.tw = tw4; return MSL_OK; }
+        // n = line length of the direction, n_other = number of lines per image (the register kernels take 16 at a time)
+        auto setup_dir = [&](msl_handle::OpDir& o, int n, int n_other, int Rfast, float2* tw4) -> int {
+            const bool lines_ok = (n_other % 16 == 0);
+            if (Rfast && lines_ok) { o.R = Rfast; o.two = false; o.tw = tw4; return MSL_OK; }
             const int R2 = (n == 512) ? 16 : (n == 2048 ? 32 : 0);
-            if (!R2 || !want || getenv("MSL_NO_TWO")) return MSL_OK;
+            if (!R2 || !lines_ok || !want || getenv("MSL_NO_TWO")) {
+                // generic LDS kernel with a transposing store: tiles of >= 8 lines keep the stores at 64 bytes or more
+                const int M = (&o == &h->opx) ? h->plan_x.M : h->plan_y.M;
+                o.generic = want && M <= 1024 && !getenv("MSL_NO_GENERIC_ONEPASS");
+                return MSL_OK;
+            }
             o.R = R2; o.two = true;
             int r = make_tw4(h, &o.tw, R2);
             if (r) return r;
@@ -910,10 +954,10 @@ int msl_create(const msl_config* cfg, msl_handle** out) {
                 return fail(h, MSL_ERR_HIP, "twiddle upload failed");
             return dalloc(h, &o.ptab, (size_t)n);
         };
-        if ((rc = setup_dir(h->opx, cfg->nx, h->Rx, h->tw4_x))) return bail(rc);
-        if ((rc = setup_dir(h->opy, cfg->ny, h->Ry, h->tw4_y))) return bail(rc);
-        h->onepass = want && h->opx.R && h->opy.R && cfg->nx % 16 == 0 && cfg->ny % 16 == 0 && !cfg->keep_potential;
-        h->scheme_b = h->onepass && (h->opx.two || h->opy.two);
+        if ((rc = setup_dir(h->opx, cfg->nx, cfg->ny, h->Rx, h->tw4_x))) return bail(rc);
+        if ((rc = setup_dir(h->opy, cfg->ny, cfg->nx, h->Ry, h->tw4_y))) return bail(rc);
+        h->onepass = want && (h->opx.R || h->opx.generic) && (h->opy.R || h->opy.generic) && !cfg->keep_potential;
+        h->scheme_b = h->onepass && (h->opx.two || h->opy.two || h->opx.generic || h->opy.generic);
         if (h->pitch == cfg->ny && h->onepass) h->pitch = cfg->ny + 16;        // pad the work buffers of 2R^2 grids too
         if ((rc = dalloc(h, &h->psi0, (size_t)cfg->nx * h->pitch * cfg->n_probes))) return bail(rc);
         if ((rc = dalloc(h, &h->psi, (size_t)cfg->nx * h->pitch * cfg->n_probes))) return bail(rc);
