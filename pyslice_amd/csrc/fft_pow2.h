@@ -390,7 +390,7 @@ __global__ void __launch_bounds__(16 * R) col_pass_kernel(ColJob job) {
 // read + write of psi per slice instead of two: 16 B/pixel/slice-step.  Same arithmetic as the
 // reference up to fp32 rounding order.
 // =================================================================================================
-enum { P2_PRE_A = 1, P2_POST_A = 2, P2_POST_F = 4, P2_PRIO_HALF = 256, P2_PRIO_ODD = 512 };
+enum { P2_PRE_A = 1, P2_POST_A = 2, P2_POST_F = 4 };
 
 struct Row2Job {
     float2* psi;
@@ -505,9 +505,6 @@ __global__ void __launch_bounds__(LINES * R) rowT_pass_kernel(RowTJob job) {
     const int grp = tid / R, ln = tid % R;
     const int q = tid % TPS, r0 = tid / TPS;
     float2* myrow = tile + grp * CS;
-    // experiment: raise the issue priority of one of the two waves of every SIMD so that they drift out of lockstep
-    if ((job.flags & P2_PRIO_HALF) && tid >= NT / 2) __builtin_amdgcn_s_setprio(3);
-    if ((job.flags & P2_PRIO_ODD) && ((tid >> 6) & 1)) __builtin_amdgcn_s_setprio(3);
     const int lblocks = job.n_lines / LINES;
     const int PC = job.pchunk;
     const int pchunks = (job.n_images + PC - 1) / PC;

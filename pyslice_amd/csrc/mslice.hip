@@ -72,7 +72,6 @@ struct msl_handle {
     int pitchT = 0;
     int rowT_variant = 0;
     int debug_flags_mask = -1;
-    int debug_flags_or = 0;
     int row_pchunk = 0;         // 0 = auto (MSL_ROW_PCHUNK)
     int row_variant = 1;        // 0: plain row kernel, 1: software-pipelined (MSL_ROW_VARIANT)
     int pitch = 0;              // row pitch (elements) of psi0/psi; > ny de-aliases the column pass's 128-byte segments
@@ -720,7 +719,6 @@ int slice_loop_onepass(msl_handle* h, int fused_slot) {
         const bool last = (k == nz - 1);
         int flags = (k > 0 ? P2_PRE_A : 0) | (!last ? P2_POST_A : 0) | ((last && fused) ? P2_POST_F : 0);
         if (h->debug_flags_mask >= 0) flags &= h->debug_flags_mask;     // timing experiments only (MSL_DEBUG_FLAGS_MASK)
-        flags |= h->debug_flags_or;
         if (last) {
             Row2Job j{};
             j.psi = h->psi; j.trans = h->trans + (size_t)k * npix; j.py = h->pyt; j.tw = h->tw4_y;
@@ -968,7 +966,6 @@ int msl_create(const msl_config* cfg, msl_handle** out) {
             if ((rc = dalloc(h, &h->transT, npix * cfg->nz))) return bail(rc);
             { const char* ev = getenv("MSL_ROWT_VARIANT"); if (ev) h->rowT_variant = atoi(ev); }
             { const char* ev = getenv("MSL_DEBUG_FLAGS_MASK"); if (ev) h->debug_flags_mask = atoi(ev); }
-            { const char* ev = getenv("MSL_DEBUG_FLAGS_OR"); if (ev) h->debug_flags_or = atoi(ev); }
             (void)hipFuncSetAttribute((const void*)row_pass2_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
             (void)hipFuncSetAttribute((const void*)row_pass2_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
         }
