@@ -423,6 +423,31 @@ def test_k_window_is_a_crop_of_the_full_spectrum(ps, orc, nx, ny, nz, window):
     assert rel_l2(tac.diffraction(None), want_I.sum(axis=1).mean(axis=0)) < TACAW_TOL
 
 
+@pytest.mark.parametrize("nx,ny,nz", [(512, 256, 5), (256, 512, 4), (96, 80, 3), (1024, 256, 2)])
+def test_engine_uploaded_potential_changed_beam_onepass(ps, orc, nx, ny, nz):
+    """C-ABI level: msl_set_beam after creation (propagator tables, also the split-order ones of 512-point lines),
+    msl_upload_potential (every x-pass slice transposed on upload) and msl_propagate leaving real-space exit waves,
+    on grids that mix the register kernels, the 2R^2 kernels and the generic kernel."""
+    from pyslice_amd import _native
+    rng = np.random.default_rng(nx + nz)
+    dx, dy, dz = 0.1, 0.1, 0.5
+    xs, ys, zs = np.arange(nx) * dx, np.arange(ny) * dy, np.arange(nz) * dz
+    V = (rng.random((nx, ny, nz)) ** 8 * 4000.0)                      # sparse peaks, a few kV.A like atoms
+    eng = _native.Engine(nx, ny, nz, dx, dy, dz, orc.wavelength(60e3), orc.interaction_sigma(60e3), n_probes=3, n_frames=0)
+    eng.set_beam(orc.wavelength(200e3), orc.interaction_sigma(200e3), dz)
+    eng.upload_potential(np.moveaxis(V, 2, 0).astype(np.float32))
+    pp = [(xs[-1] / 2, ys[-1] / 2), (3.0, 2.0), (0.0, 7.7)]
+    eng.set_probes(25.0, pp)
+    eng.propagate()
+    got = eng.exit_waves()
+    probes = orc.batched_probes(orc.probe_array(xs, ys, 25.0, 200e3), xs, ys, pp)
+    want = orc.propagate(probes, V.astype(np.float32).astype(np.float64), xs, ys, zs, 200e3)
+    assert rel_l2(got, want) < WAVE_TOL
+    t = eng.transmission()
+    assert rel_l2(t, np.exp(1j * orc.interaction_sigma(200e3) * np.moveaxis(V.astype(np.float32), 2, 0))) < 1e-5
+    eng.close()
+
+
 def test_k_window_argument_errors(ps):
     from pyslice_amd.synthetic import synthetic_trajectory
     tr = synthetic_trajectory(32, 2, 1, density=0.05, seed=1)
