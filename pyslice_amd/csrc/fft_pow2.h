@@ -643,7 +643,36 @@ __global__ void __launch_bounds__(16 * R) rowT2_pass_kernel(RowTJob job) {
     const int tid = threadIdx.x;
     for (int i = tid; i < N2; i += NT) { tw[i] = job.tw[i]; tw2[i] = job.tw2[i]; }
     if (!BIG) for (int i = tid; i < N; i += NT) pl_lds[i] = job.pl[i];
-    const float2* pl = BIG ? job.pl : pl_lds;
+    const float2* pl = pl_lds;          // small variant; the big one keeps P in the free upper quarter of the tile rows
+    __syncthreads();
+    // BIG: a tile row is CS = R^2 + 1 float2 long, the transforms only use the first R(R+1)/2 as scratch, the transposed
+    // store uses R^2.  The split-order propagator (N entries) is parked in the last N/16 entries of the 16 rows --
+    // entry m in row m / (N/16) -- and re-read from L2 after every store phase (16 KB per workgroup and iteration).
+    constexpr int PSEG = N / 16;                               // 128 entries per row
+    constexpr int POFF = CS - 1 - PSEG;                        // 896
+    static_assert(!BIG || POFF >= R * (R + 1) / 2, "propagator segment overlaps the transform scratch");
+    auto stage_p = [&]() {
+        if constexpr (BIG) {
+#pragma unroll
+            for (int i = 0; i < N / NT; ++i) {
+                const int m = tid + i * NT;
+                tile[(m / PSEG) * CS + POFF + (m % PSEG)] = job.pl[m];
+            }
+        }
+    };
+    // v[jj] *= P[jj*R + ln] from the parked copy, in chunks of 8 (register pressure, see mul_table)
+    auto mul_p_big = [&](float2 (&vv)[2 * R]) {
+#pragma unroll
+        for (int c = 0; c < 2 * R; c += 8) {
+            float2 w[8];
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) w[jj] = tile[((c + jj) * R / PSEG) * CS + POFF + ((c + jj) * R % PSEG) + (tid % R)];
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) vv[c + jj] = cmulf(vv[c + jj], w[jj]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    stage_p();
     __syncthreads();
     const int grp = tid / R, ln = tid % R;
     const int q = tid & 7, r0 = tid >> 3;
@@ -696,18 +725,20 @@ __global__ void __launch_bounds__(16 * R) rowT2_pass_kernel(RowTJob job) {
         }
         if (job.flags & P2_PRE_A) {
             line2_transform<R, false>(v, scratch, tw, tw2, ln);
-            mul_table<2 * R, 0, false, R>(v, pl, ln);
+            if constexpr (BIG) mul_p_big(v); else mul_table<2 * R, 0, false, R>(v, pl, ln);
             line2_transform<R, true>(v, scratch, tw, tw2, ln);
         }
         if constexpr (BIG) {
-            mul_table<2 * R, 0, false, R>(v, job.trans + (long long)lb * 16 * N + grp * N, ln);
+            int lnx = ln;                                      // laundered: keeps the 64-bit table addresses out of the loop-invariant set
+            asm volatile("" : "+v"(lnx));
+            mul_table<2 * R, 0, false, R>(v, job.trans + (long long)lb * 16 * N + grp * N, lnx);
         } else {
 #pragma unroll
             for (int j = 0; j < 2 * R; ++j) v[j] = cmulf(v[j], tv[j]);
         }
         if (job.flags & P2_POST_A) {
             line2_transform<R, false>(v, scratch, tw, tw2, ln);
-            mul_table<2 * R, 0, false, R>(v, pl, ln);
+            if constexpr (BIG) mul_p_big(v); else mul_table<2 * R, 0, false, R>(v, pl, ln);
             line2_transform<R, true>(v, scratch, tw, tw2, ln);
         }
         float2* dst = job.out + ((long long)p * job.out_image_stride + cur_lb * 16);
@@ -730,6 +761,7 @@ __global__ void __launch_bounds__(16 * R) rowT2_pass_kernel(RowTJob job) {
             }
         }
         lds_barrier();
+        if constexpr (BIG) { stage_p(); lds_barrier(); }       // the store phase overwrote the parked propagator
         item = nitem; lb = nlb; pc = npc; k = nk;
     }
 }
