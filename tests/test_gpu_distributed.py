@@ -46,6 +46,16 @@ def _worker(rank, world, port, q):
             out["frequencies"] = tac.frequencies
         else:
             assert tac.intensity is None
+        # the same with a k-window: shards, all-to-all and gather carry (.., 64, 96) spectra; reductions on rank 0
+        calc3 = ps.MultisliceCalculator(device=0, progress=False, gather="none", k_window=(64, 96))
+        calc3.setup(tr, aperture=30.0, voltage_eV=100e3, probe_positions=pp)
+        tac3 = ps.TACAWData(calc3.run())
+        if rank == 0:
+            out["intensity_win"] = tac3.intensity.cpu().numpy()
+            out["spectrum_win"] = tac3.spectrum(None)
+            out["diffraction_win"] = tac3.diffraction(1)
+        else:
+            assert tac3.intensity is None
         q.put((rank, out))
     finally:
         dist.destroy_process_group()
@@ -75,3 +85,8 @@ def test_two_ranks_frame_sharding_gather_and_tacaw():
     f, inten = orc.tacaw(want, np.arange(5) * tr.timestep)
     assert np.allclose(res[0]["frequencies"], f)
     assert rel_l2(res[0]["intensity"], inten) < 2e-4
+    win = inten[:, :, 128 - 32:128 + 32, 128 - 48:128 + 48]
+    assert res[0]["intensity_win"].shape == win.shape
+    assert np.linalg.norm(res[0]["intensity_win"] - win) / np.linalg.norm(win) < 2e-4
+    assert rel_l2(res[0]["spectrum_win"], win.sum(axis=(2, 3)).mean(axis=0)) < 2e-4
+    assert rel_l2(res[0]["diffraction_win"], win[1].sum(axis=0)) < 2e-4
