@@ -508,17 +508,18 @@ __global__ void __launch_bounds__(LINES * R) rowT_pass_kernel(RowTJob job) {
     const int lblocks = job.n_lines / LINES;
     const int PC = job.pchunk;
     const int pchunks = (job.n_images + PC - 1) / PC;
-    const long long n_items = (long long)lblocks * pchunks;
-    auto chunk_len = [&](long long it) { const int pc = (int)(it % pchunks); return min(PC, job.n_images - pc * PC); };
-    auto line_ptr = [&](long long it, int kk) {
-        const int lb = (int)(it / pchunks), pc = (int)(it % pchunks);
-        return job.in + (long long)(pc * PC + kk) * job.in_image_stride + (long long)(lb * LINES + grp) * job.in_pitch;
+    const int n_items = lblocks * pchunks;
+    // work item = (line block lb, probe chunk pc), item = lb * pchunks + pc; the cursor (item, lb, pc, k) advances
+    // incrementally -- a division per iteration costs ~0.3 us of scalar work on the critical path
+    const int step_lb = (int)gridDim.x / pchunks, step_pc = (int)gridDim.x % pchunks;
+    auto line_ptr = [&](int lbb, int pcc, int kk) {
+        return job.in + (long long)(pcc * PC + kk) * job.in_image_stride + (long long)(lbb * LINES + grp) * job.in_pitch;
     };
-    long long item = blockIdx.x;
-    int k = 0;
+    int item = blockIdx.x;
+    int lb = item / pchunks, pc = item - lb * pchunks, k = 0;
     float2 vn[R];
     if (item < n_items) {
-        const float2* r = line_ptr(item, 0);
+        const float2* r = line_ptr(lb, pc, 0);
 #pragma unroll
         for (int j = 0; j < R; ++j) vn[j] = r[j * R + ln];
     }
@@ -527,18 +528,20 @@ __global__ void __launch_bounds__(LINES * R) rowT_pass_kernel(RowTJob job) {
         float2 v[R];
 #pragma unroll
         for (int j = 0; j < R; ++j) v[j] = vn[j];
-        const int lb = (int)(item / pchunks);
-        const int p = (int)(item % pchunks) * PC + k;
+        const int p = pc * PC + k;
+        const int cur_lb = lb;
         if (k == 0) {
             const float2* trow = job.trans + (long long)(lb * LINES + grp) * N;
 #pragma unroll
             for (int j = 0; j < R; ++j) tv[j] = trow[j * R + ln];
         }
-        long long nitem = item;
-        int nk = k + 1;
-        if (nk >= chunk_len(item)) { nitem = item + gridDim.x; nk = 0; }
+        int nitem = item, nlb = lb, npc = pc, nk = k + 1;
+        if (nk >= min(PC, job.n_images - pc * PC)) {
+            nk = 0; nitem = item + (int)gridDim.x; nlb = lb + step_lb; npc = pc + step_pc;
+            if (npc >= pchunks) { npc -= pchunks; ++nlb; }
+        }
         if (nitem < n_items) {
-            const float2* r = line_ptr(nitem, nk);
+            const float2* r = line_ptr(nlb, npc, nk);
 #pragma unroll
             for (int j = 0; j < R; ++j) vn[j] = r[j * R + ln];
         }
@@ -560,7 +563,7 @@ __global__ void __launch_bounds__(LINES * R) rowT_pass_kernel(RowTJob job) {
         lds_barrier();
         // uniform 64-bit base + per-thread 32-bit element offset, re-derived every iteration (the asm keeps the
         // compiler from hoisting 16 loop-invariant 64-bit addresses into registers for the whole kernel)
-        float2* dst = job.out + (long long)p * job.out_image_stride + lb * LINES;
+        float2* dst = job.out + (long long)p * job.out_image_stride + cur_lb * LINES;
         int off0 = 2 * q + r0 * job.out_pitch;
         asm volatile("" : "+v"(off0));
         const int ostep = POS_PER_IT * job.out_pitch;
@@ -571,7 +574,7 @@ __global__ void __launch_bounds__(LINES * R) rowT_pass_kernel(RowTJob job) {
             *reinterpret_cast<float4*>(dst + (off0 + i * ostep)) = make_float4(a.x, a.y, b.x, b.y);
         }
         lds_barrier();
-        item = nitem; k = nk;
+        item = nitem; lb = nlb; pc = npc; k = nk;
     }
 }
 
