@@ -554,7 +554,10 @@ template <int R, int LINES, bool C64>
 int launch_rowT_v(msl_handle* h, RowTJob job, int kind) {
     constexpr int N = R * R, CS = R * (R + 1) + 1;
     const size_t lds = ((size_t)2 * N + (size_t)LINES * CS) * 8;
-    const int per_cu = std::max(1, std::min(2, (int)((size_t)h->lds_limit / lds)));
+    // R = 32: 245 VGPRs, 151 KB -> one workgroup per CU; R = 16: 135 VGPRs, 39 KB -> three (MSL_ROWT_PER_CU overrides)
+    int cap = (R == 16) ? 3 : 2;
+    { const char* e = getenv("MSL_ROWT_PER_CU"); if (e && atoi(e) > 0) cap = atoi(e); }
+    const int per_cu = std::max(1, std::min(cap, (int)((size_t)h->lds_limit / lds)));
     const long long slots = (long long)h->n_cus * per_cu;
     const long long lb = job.n_lines / LINES;
     int pc = job.n_images;
