@@ -68,6 +68,7 @@ struct msl_handle {
     struct OpDir { int R = 0; bool two = false; bool generic = false; float2* tw = nullptr; float2* tw2 = nullptr; float2* ptab = nullptr; } opx, opy;
     float2* psiT = nullptr;
     float2* psi0T = nullptr;
+    bool need_psi0T = false;
     float2* transT = nullptr;
     int pitchT = 0;
     int rowT_variant = 0;
@@ -520,7 +521,7 @@ int epilogue_x_pass(msl_handle* h, int slot) {
 // ---- one-pass-per-slice path ------------------------------------------------------------------------
 // psi0 (P, nx, pitch) -> psi0T (P, ny, pitchT): needed when the first pass of the slice loop runs along x
 int transpose_probes(msl_handle* h) {
-    if (!h->onepass || h->scheme_b) return MSL_OK;          // scheme B always starts along y, on layout A
+    if (!h->onepass || !h->need_psi0T) return MSL_OK;       // the first pass runs along y, on layout A
     const msl_config& c = h->cfg;
     dim3 grid((c.ny + 31) / 32, (c.nx + 31) / 32, c.n_probes);
     hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, h->stream, h->psi0, h->psi0T, c.nx, c.ny, h->pitch, h->pitchT,
@@ -965,7 +966,9 @@ int msl_create(const msl_config* cfg, msl_handle** out) {
         if (h->onepass) {
             h->pitchT = cfg->nx + (h->pitch - cfg->ny);
             if ((rc = dalloc(h, &h->psiT, (size_t)cfg->ny * h->pitchT * cfg->n_probes))) return bail(rc);
-            if ((rc = dalloc(h, &h->psi0T, (size_t)cfg->ny * h->pitchT * cfg->n_probes))) return bail(rc);
+            // transposed probes: only when the first pass runs along x (alternating scheme with an even slice count)
+            h->need_psi0T = !h->scheme_b && (cfg->nz % 2 == 0);
+            if (h->need_psi0T && (rc = dalloc(h, &h->psi0T, (size_t)cfg->ny * h->pitchT * cfg->n_probes))) return bail(rc);
             if ((rc = dalloc(h, &h->transT, npix * cfg->nz))) return bail(rc);
             { const char* ev = getenv("MSL_ROWT_VARIANT"); if (ev) h->rowT_variant = atoi(ev); }
             { const char* ev = getenv("MSL_DEBUG_FLAGS_MASK"); if (ev) h->debug_flags_mask = atoi(ev); }
@@ -1063,7 +1066,7 @@ int msl_resize_probes(msl_handle* h, int32_t n_probes) {
     if ((rc = dalloc(h, &h->psi, (size_t)h->cfg.nx * h->pitch * n_probes))) return rc;
     if (h->onepass) {
         if ((rc = dalloc(h, &h->psiT, (size_t)h->cfg.ny * h->pitchT * n_probes))) return rc;
-        if ((rc = dalloc(h, &h->psi0T, (size_t)h->cfg.ny * h->pitchT * n_probes))) return rc;
+        if (h->need_psi0T && (rc = dalloc(h, &h->psi0T, (size_t)h->cfg.ny * h->pitchT * n_probes))) return rc;
     }
     if ((rc = dalloc(h, &h->d_xy, (size_t)2 * n_probes))) return rc;
     h->cfg.n_probes = n_probes;
