@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-slices", type=int, default=16, help="slices of the bounded CPU sample")
     ap.add_argument("--tacaw", action="store_true", help="also time the TACAW time->frequency FFT over the K frames")
+    ap.add_argument("--no-launch-timing", action="store_true",
+                    help="run the library as production does (no per-launch HIP events, frames queue asynchronously); "
+                         "the roofline block is then null")
     return ap.parse_args()
 
 
@@ -108,7 +111,8 @@ def main():
     side = int(round(P ** 0.5))
     pp = stem_probe_grid(side) if side * side == P else np.random.default_rng(0).random((P, 2)) * [lx, ly]
     eng = _native.Engine(n, n, nz, xs[1] - xs[0], ys[1] - ys[0], zs[1] - zs[0] if nz > 1 else 0.5, wavelength(100e3),
-                         interaction_sigma(100e3), n_probes=P, n_frames=n_frames, device=local_rank)
+                         interaction_sigma(100e3), n_probes=P, n_frames=n_frames, device=local_rank,
+                         launch_timing=not a.no_launch_timing)
     eng.set_kirkland(loadKirkland())
     eng.set_slices(*slice_edges(zs))
     eng.set_probes(a.aperture, pp)

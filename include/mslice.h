@@ -59,7 +59,9 @@ typedef struct {
                                 * keep only the central window_nx x window_ny pixels of each fftshifted exit-wave spectrum,
                                 * rows [nx/2 - window_nx/2, +window_nx), columns likewise; the result, intensity and frame
                                 * buffers then have shape (.., window_nx, window_ny).  0 = the full axis. */
-    int32_t reserved[5];
+    int32_t launch_timing;     /* 1: record a HIP event after every slice-loop launch so that msl_get_counters reports per-kernel
+                                * launch counts and durations (bench.py's roofline); 0: no events (production) */
+    int32_t reserved[4];
 } msl_config;
 
 typedef enum {

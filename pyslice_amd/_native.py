@@ -33,7 +33,8 @@ class MslConfig(C.Structure):
                 ("wavelength", C.c_double), ("sigma", C.c_double),
                 ("n_probes", C.c_int32), ("n_frames", C.c_int32), ("device", C.c_int32),
                 ("keep_potential", C.c_int32), ("fft_path", C.c_int32),
-                ("window_nx", C.c_int32), ("window_ny", C.c_int32), ("reserved", C.c_int32 * 5)]
+                ("window_nx", C.c_int32), ("window_ny", C.c_int32), ("launch_timing", C.c_int32),
+                ("reserved", C.c_int32 * 4)]
 
 
 class MslCounters(C.Structure):
@@ -116,14 +117,14 @@ class Engine:
     """One libmslice handle: one HIP device, one stream, all device buffers of one grid."""
 
     def __init__(self, nx, ny, nz, dx, dy, dz, wavelength, sigma, n_probes=1, n_frames=0, device=0,
-                 keep_potential=False, fft_path=0, window=None):
+                 keep_potential=False, fft_path=0, window=None, launch_timing=False):
         self._lib = load()
         self._h = C.c_void_p()
         cfg = MslConfig(nx=int(nx), ny=int(ny), nz=int(nz), dx=float(dx), dy=float(dy), dz=float(dz),
                         wavelength=float(wavelength), sigma=float(sigma), n_probes=int(n_probes),
                         n_frames=int(n_frames), device=int(device), keep_potential=int(bool(keep_potential)),
                         fft_path=int(fft_path), window_nx=int(window[0]) if window else 0,
-                        window_ny=int(window[1]) if window else 0)
+                        window_ny=int(window[1]) if window else 0, launch_timing=int(bool(launch_timing)))
         rc = self._lib.msl_create(C.byref(cfg), C.byref(self._h))
         if rc != MSL_OK:
             msg = (self._lib.msl_last_error(None) or b"msl_create failed").decode()

@@ -69,6 +69,11 @@ struct msl_handle {
     float2* psiT = nullptr;
     float2* psi0T = nullptr;
     bool need_psi0T = false;
+    int keys_cap = 0;              // capacity of d_counts / d_start (slice x species bins)
+    // pinned host staging for the per-frame inputs (species maps, Z, positions), two slots used alternately: the call
+    // copies the caller's arrays here and returns; the H2D copies run on the stream (no pointer into caller memory is kept)
+    struct HostStage { char* buf = nullptr; size_t bytes = 0; hipEvent_t ev = nullptr; bool used = false; } stage[2];
+    unsigned stage_pos = 0;
     float2* transT = nullptr;
     int pitchT = 0;
     int rowT_variant = 0;
@@ -250,6 +255,7 @@ int resolve_set(msl_handle* h, EventSet& s) {
 }
 
 int begin_timed(msl_handle* h, int max_launches) {
+    if (!h->cfg.launch_timing) { h->cur = nullptr; return MSL_OK; }
     if (h->ring.empty()) h->ring.resize(4);
     EventSet& s = h->ring[h->ring_pos];
     h->ring_pos = (h->ring_pos + 1) % (int)h->ring.size();
@@ -541,11 +547,15 @@ int transpose_odd_slices(msl_handle* h) {
     if (!h->onepass) return MSL_OK;
     const msl_config& c = h->cfg;
     const size_t npix = (size_t)c.nx * c.ny;
-    for (int s = 0; s < c.nz; ++s) {
-        if (!slice_is_transposed(h, s)) continue;
-        dim3 grid((c.ny + 31) / 32, (c.nx + 31) / 32, 1);
-        hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, h->stream, h->trans + s * npix, h->transT + s * npix, c.nx, c.ny,
-                           c.ny, c.nx, (long long)npix, (long long)npix);
+    // the transposed slices are every second one: a single launch with the slice index on grid.z
+    const int first = slice_is_transposed(h, 0) ? 0 : 1;
+    const int count = (c.nz - first + 1) / 2;
+    for (int z0 = 0; z0 < count; z0 += 65535) {
+        const int nzb = std::min(65535, count - z0);
+        dim3 grid((c.ny + 31) / 32, (c.nx + 31) / 32, nzb);
+        const size_t off = (size_t)(first + 2 * z0) * npix;
+        hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, h->stream, h->trans + off, h->transT + off, c.nx, c.ny,
+                           c.ny, c.nx, (long long)(2 * npix), (long long)(2 * npix));
     }
     HIPCHK(h, hipGetLastError());
     return MSL_OK;
@@ -1001,6 +1011,7 @@ int msl_destroy(msl_handle* h) {
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (auto& s : h->ring) for (auto e : s.ev) (void)hipEventDestroy(e);
+    for (auto& st : h->stage) { if (st.ev) (void)hipEventDestroy(st.ev); if (st.buf) (void)hipHostFree(st.buf); }
     void* bufs[] = {h->psi0, h->psi, h->trans, h->V, h->wf, h->intensity, h->pxt, h->pyt, h->d_abcd, h->d_lo, h->d_hi,
                     h->d_pos, h->d_Z, h->d_key, h->d_order, h->d_u1, h->d_u2, h->d_ex, h->d_ey, h->d_counts, h->d_start,
                     h->d_z2s, h->d_species, h->d_ff, h->d_xy, h->plan_x.tw, h->plan_y.tw, h->plan_t.tw, h->tw4_x, h->tw4_y,
@@ -1157,24 +1168,52 @@ int msl_build_potential(msl_handle* h, const double* pos, const int32_t* Z, int6
     int species[104], nsp = 0;
     for (int z = 1; z <= 103; ++z) if (z2s[z] == 0) { z2s[z] = nsp; species[nsp++] = z; }
     int rc;
-    hipEvent_t e0, e1;
-    HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
-    HIPCHK(h, hipEventRecord(e0, h->stream));
+    // with launch timing off the call only queues work: no event, no host wait (the frames of a run pipeline on the stream)
+    const bool timed = h->cfg.launch_timing != 0;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (timed) {
+        HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
+        HIPCHK(h, hipEventRecord(e0, h->stream));
+    }
     if (nsp > h->ff_species_cap) {
         if ((rc = dalloc(h, &h->d_ff, npix * nsp))) return rc;
         h->ff_species_cap = nsp;
     }
     const int nkeys = c.nz * std::max(nsp, 1);
-    if ((rc = dalloc(h, &h->d_counts, (size_t)nkeys + 1))) return rc;
-    if ((rc = dalloc(h, &h->d_start, (size_t)nkeys + 1))) return rc;
+    if (nkeys > h->keys_cap) {
+        if ((rc = dalloc(h, &h->d_counts, (size_t)nkeys + 1))) return rc;
+        if ((rc = dalloc(h, &h->d_start, (size_t)nkeys + 1))) return rc;
+        h->keys_cap = nkeys;
+    }
     if ((rc = ensure_atoms(h, (size_t)n))) return rc;
     HIPCHK(h, hipMemsetAsync(h->d_counts, 0, ((size_t)nkeys + 1) * sizeof(int), h->stream));
     bool recip_written = false;     // the structure-factor kernels write every bin of R_s; zero-fill only when none runs
     if (n > 0 && nsp > 0) {
-        HIPCHK(h, hipMemcpyAsync(h->d_z2s, z2s, sizeof z2s, hipMemcpyHostToDevice, h->stream));
-        HIPCHK(h, hipMemcpyAsync(h->d_species, species, nsp * sizeof(int), hipMemcpyHostToDevice, h->stream));
-        HIPCHK(h, hipMemcpyAsync(h->d_pos, pos, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
-        HIPCHK(h, hipMemcpyAsync(h->d_Z, Z, (size_t)n * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        {
+            msl_handle::HostStage& st = h->stage[h->stage_pos++ & 1];
+            if (!st.ev) HIPCHK(h, hipEventCreateWithFlags(&st.ev, hipEventDisableTiming));
+            if (st.used) HIPCHK(h, hipEventSynchronize(st.ev));            // the copies queued from this slot two calls ago
+            const size_t off_sp = sizeof z2s, off_pos = (off_sp + sizeof species + 7) & ~(size_t)7;
+            const size_t off_Z = off_pos + (size_t)n * 3 * sizeof(double), need = off_Z + (size_t)n * sizeof(int);
+            if (need > st.bytes) {
+                if (st.buf) (void)hipHostFree(st.buf);
+                st.buf = nullptr; st.bytes = 0;
+                const size_t cap = need + need / 4;
+                if (hipHostMalloc((void**)&st.buf, cap, hipHostMallocDefault) != hipSuccess)
+                    return fail(h, MSL_ERR_NOMEM, "hipHostMalloc(%zu bytes) failed", cap);
+                st.bytes = cap;
+            }
+            memcpy(st.buf, z2s, sizeof z2s);
+            memcpy(st.buf + off_sp, species, sizeof species);
+            memcpy(st.buf + off_pos, pos, (size_t)n * 3 * sizeof(double));
+            memcpy(st.buf + off_Z, Z, (size_t)n * sizeof(int));
+            HIPCHK(h, hipMemcpyAsync(h->d_z2s, st.buf, sizeof z2s, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(h, hipMemcpyAsync(h->d_species, st.buf + off_sp, nsp * sizeof(int), hipMemcpyHostToDevice, h->stream));
+            HIPCHK(h, hipMemcpyAsync(h->d_pos, st.buf + off_pos, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+            HIPCHK(h, hipMemcpyAsync(h->d_Z, st.buf + off_Z, (size_t)n * sizeof(int), hipMemcpyHostToDevice, h->stream));
+            HIPCHK(h, hipEventRecord(st.ev, h->stream));
+            st.used = true;
+        }
         const double lx = c.nx * c.dx, ly = c.ny * c.dy;
         long long tot = (long long)npix * nsp;
         hipLaunchKernelGGL(formfactor_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, h->d_ff, h->d_abcd,
@@ -1185,12 +1224,11 @@ int msl_build_potential(msl_handle* h, const double* pos, const int32_t* Z, int6
         hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(64), 0, h->stream, h->d_counts, h->d_start, nkeys);
         hipLaunchKernelGGL(bin_fill_kernel, dim3(nkeys), dim3(64), 0, h->stream, h->d_key, (long long)n, h->d_start, h->d_order);
         HIPCHK(h, hipGetLastError());
-        int n_sorted = 0;
-        HIPCHK(h, hipMemcpyAsync(&n_sorted, h->d_start + nkeys, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        if (n_sorted > 0) {
+        {
+            // atoms that fell into a slice: d_start[nkeys], read by the kernels themselves (grids sized for all n atoms)
+            const int* n_sorted = h->d_start + nkeys;
             recip_written = true;
-            long long tx = (long long)n_sorted * c.nx, ty = (long long)n_sorted * c.ny;
+            long long tx = (long long)n * c.nx, ty = (long long)n * c.ny;
             hipLaunchKernelGGL(phase_table_kernel, dim3((unsigned)((tx + 255) / 256)), dim3(256), 0, h->stream, h->d_ex, h->d_u1,
                                h->d_order, n_sorted, c.nx);
             hipLaunchKernelGGL(phase_table_kernel, dim3((unsigned)((ty + 255) / 256)), dim3(256), 0, h->stream, h->d_ey, h->d_u2,
@@ -1245,12 +1283,14 @@ int msl_build_potential(msl_handle* h, const double* pos, const int32_t* Z, int6
         if ((rc = launch_lines(h, h->plan_x, k, K_OTHER))) return rc;
         if ((rc = transpose_odd_slices(h))) return rc;          // one-pass loop on a 2R^2 grid: x-pass slices transposed
     }
-    HIPCHK(h, hipEventRecord(e1, h->stream));
-    HIPCHK(h, hipEventSynchronize(e1));
-    float ms = 0.f;
-    HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
-    h->ctr.ms_potential += ms;
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (timed) {
+        HIPCHK(h, hipEventRecord(e1, h->stream));
+        HIPCHK(h, hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
+        h->ctr.ms_potential += ms;
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    }
     h->have_potential = true;
     return MSL_OK;
 }
@@ -1279,6 +1319,7 @@ static int run_loop(msl_handle* h, int slot) {
     if (!h->have_probes) return fail(h, MSL_ERR_STATE, "propagate: no probes (msl_set_probes / msl_upload_probes)");
     if (!h->have_potential) return fail(h, MSL_ERR_STATE, "propagate: no potential (msl_build_potential / msl_upload_potential)");
     HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (!h->cfg.launch_timing) return slice_loop(h, slot);         // queued; msl_synchronize / msl_download wait for it
     hipEvent_t e0, e1;
     HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
     HIPCHK(h, hipEventRecord(e0, h->stream));
@@ -1538,11 +1579,14 @@ int msl_download(msl_handle* h, msl_buffer what, void* dst, size_t bytes, int64_
     if (what == MSL_BUF_TRANSMISSION && h->onepass && h->have_potential) {
         // the one-pass loop keeps every second slice transposed in its own buffer: restore the natural copies
         const size_t npix = (size_t)h->cfg.nx * h->cfg.ny;
-        for (int s = 0; s < h->cfg.nz; ++s) {
-            if (!slice_is_transposed(h, s)) continue;
-            dim3 grid((h->cfg.nx + 31) / 32, (h->cfg.ny + 31) / 32, 1);
-            hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, h->stream, h->transT + s * npix, h->trans + s * npix,
-                               h->cfg.ny, h->cfg.nx, h->cfg.nx, h->cfg.ny, (long long)npix, (long long)npix);
+        const int first = slice_is_transposed(h, 0) ? 0 : 1;
+        const int count = (h->cfg.nz - first + 1) / 2;
+        for (int z0 = 0; z0 < count; z0 += 65535) {
+            const int nzb = std::min(65535, count - z0);
+            dim3 grid((h->cfg.nx + 31) / 32, (h->cfg.ny + 31) / 32, nzb);
+            const size_t off = (size_t)(first + 2 * z0) * npix;
+            hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, h->stream, h->transT + off, h->trans + off,
+                               h->cfg.ny, h->cfg.nx, h->cfg.nx, h->cfg.ny, (long long)(2 * npix), (long long)(2 * npix));
         }
         HIPCHK(h, hipGetLastError());
     }

@@ -94,10 +94,11 @@ __global__ void bin_fill_kernel(const int* __restrict__ key, long long n, const 
 }
 
 // table[i][m] = exp(-2 pi i * f(m) * u[order[i]]),  f = signed FFT frequency index
+// (n_sorted is read on the device -- the number of atoms that fell into a slice -- so that the host never waits for it)
 __global__ void phase_table_kernel(float2* __restrict__ table, const double* __restrict__ u,
-                                   const int* __restrict__ order, int n_sorted, int n) {
+                                   const int* __restrict__ order, const int* __restrict__ n_sorted_ptr, int n) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long long)n_sorted * n) return;
+    if (i >= (long long)(*n_sorted_ptr) * n) return;
     int a = (int)(i / n), m = (int)(i - (long long)a * n);
     double t = (double)signed_freq(m, n) * u[order[a]];
     t -= rint(t);
