@@ -1071,7 +1071,6 @@ int msl_resize_probes(msl_handle* h, int32_t n_probes) {
     if (n_probes == h->cfg.n_probes) return MSL_OK;
     HIPCHK(h, hipSetDevice(h->cfg.device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    const size_t npix = (size_t)h->cfg.nx * h->cfg.ny;
     int rc;
     if ((rc = dalloc(h, &h->psi0, (size_t)h->cfg.nx * h->pitch * n_probes))) return rc;
     if ((rc = dalloc(h, &h->psi, (size_t)h->cfg.nx * h->pitch * n_probes))) return rc;
