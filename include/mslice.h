@@ -127,6 +127,11 @@ int  msl_upload_probes(msl_handle* h, const float* c64, int32_t n_probes);
  * Replaces create_batched_probes for probes built from a caller array (multislice.py:216-227). */
 int  msl_shift_probes(msl_handle* h, const float* base_c64, const double* xy, int32_t n_probes);
 
+/* Execution model: one handle = one HIP device + one stream.  With msl_config.launch_timing == 0 the per-frame calls
+ * (msl_build_potential, msl_propagate, msl_propagate_frame) copy their host arguments into library-owned pinned memory,
+ * queue the work on the stream and return; results are complete after msl_synchronize or any msl_download* call (which
+ * wait for the stream).  With launch_timing == 1 they also wait, so that msl_get_counters can attribute time. */
+
 /* Projected Kirkland potential + transmission functions of one MD frame.
  * pos = n x 3 doubles, Z = n atomic numbers (1..103); ax1/ax2 = in-plane axes, axs = slice axis.
  * Replaces Potential.__init__ (potentials.py:188-348) and the per-slice exp(i sigma V) of
@@ -189,6 +194,7 @@ void* msl_device_ptr(msl_handle* h, msl_buffer what);
 int  msl_download_frame(msl_handle* h, int32_t slot, void* dst_c64, size_t bytes);
 int  msl_upload_frame(msl_handle* h, int32_t slot, const void* src_c64, size_t bytes);
 
+/* Wait for everything queued on the handle's stream. */
 int  msl_synchronize(msl_handle* h);
 int  msl_get_counters(const msl_handle* h, msl_counters* out);
 int  msl_reset_counters(msl_handle* h);
