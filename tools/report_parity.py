@@ -55,5 +55,6 @@ for n, ny, nz, P, T, dens in ((256, 256, 50, 2, 1, 0.102), (256, 1024, 6, 3, 1, 
     if T >= 2:
         f, inten = orc.tacaw(want, wf.time)
         tac = f"{rel(npy(ps.TACAWData(wf).intensity), inten):.2e}"
-    path = "one-pass four-step" if calc._engine and n in (256, 1024) and ny in (256, 1024) else "generic / Bluestein"
+    reg = lambda m: m in (256, 512, 1024, 2048)
+    path = "one-pass register kernels" if reg(n) and reg(ny) else "one-pass generic / Bluestein"
     print(f"oracle {n}x{ny}x{nz} P={P} T={T} ({path:19s})  {rel(d, want):.2e}      {resid(d, want):.2e}            {np.abs(V - Vg).max() / np.abs(V).max():.2e}             {tac}")
