@@ -748,6 +748,7 @@ __global__ void __launch_bounds__(16 * R) rowT2_pass_kernel(RowTJob job) {
         int off0 = 2 * q + r0 * job.out_pitch;
         asm volatile("" : "+v"(off0));
         const int ostep = POS_PER_IT * job.out_pitch;
+        if constexpr (BIG) lds_barrier();              // every wave is done with the parked propagator before rows are overwritten
 #pragma unroll
         for (int c = 0; c < NCHUNK; ++c) {
             if (c > 0) lds_barrier();                  // the previous chunk has been read out

@@ -423,7 +423,8 @@ def test_k_window_is_a_crop_of_the_full_spectrum(ps, orc, nx, ny, nz, window):
     assert rel_l2(tac.diffraction(None), want_I.sum(axis=1).mean(axis=0)) < TACAW_TOL
 
 
-@pytest.mark.parametrize("nx,ny,nz", [(512, 256, 5), (256, 512, 4), (96, 80, 3), (1024, 256, 2)])
+@pytest.mark.parametrize("nx,ny,nz", [(512, 256, 5), (256, 512, 4), (96, 80, 3), (1024, 256, 2), (2048, 2048, 6),
+                                       (2048, 512, 9), (500, 2048, 4)])
 def test_engine_uploaded_potential_changed_beam_onepass(ps, orc, nx, ny, nz):
     """C-ABI level: msl_set_beam after creation (propagator tables, also the split-order ones of 512-point lines),
     msl_upload_potential (every x-pass slice transposed on upload) and msl_propagate leaving real-space exit waves,
@@ -446,6 +447,19 @@ def test_engine_uploaded_potential_changed_beam_onepass(ps, orc, nx, ny, nz):
     t = eng.transmission()
     assert rel_l2(t, np.exp(1j * orc.interaction_sigma(200e3) * np.moveaxis(V.astype(np.float32), 2, 0))) < 1e-5
     eng.close()
+
+
+@pytest.mark.parametrize("n,nz", [(256, 400), (512, 400), (2048, 40)])
+def test_deep_stack_error_growth_stays_inside_the_contract(ps, orc, n, nz):
+    """BASELINE C5 has 400 slices: the fp32 rounding of 4 x nz line transforms per pixel must stay below the 1e-4
+    contract (measured 5e-5 at 400 slices; tools/deep_stack_parity.py runs the 1024^2 and 2048^2 x 100 cases).
+    A 40-slice 2048^2 stack also exercises every pass type of the 2048-point kernel with strong potentials."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("deep", os.path.join(os.path.dirname(__file__), "..", "tools", "deep_stack_parity.py"))
+    deep = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(deep)
+    assert deep.case(n, nz) < WAVE_TOL
 
 
 def test_k_window_argument_errors(ps):
