@@ -462,6 +462,20 @@ def test_deep_stack_error_growth_stays_inside_the_contract(ps, orc, n, nz):
     assert deep.case(n, nz) < WAVE_TOL
 
 
+def test_randomised_shape_sweep(ps, orc):
+    """40 random cases of tools/fuzz_parity.py (seed 11): grid shapes mixing the register, 2R^2, generic and Bluestein
+    kernels, 1-12 slices, 1-4 probes, 1-2 frames, random k-windows; exit waves and windowed spectra against the oracle."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("fuzz", os.path.join(os.path.dirname(__file__), "..", "tools", "fuzz_parity.py"))
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    rng = np.random.default_rng(11)
+    for c in range(40):
+        cfg, err = fuzz.one(rng, max_pix=2 ** 20)
+        assert err < WAVE_TOL, (cfg, err)
+
+
 def test_k_window_argument_errors(ps):
     from pyslice_amd.synthetic import synthetic_trajectory
     tr = synthetic_trajectory(32, 2, 1, density=0.05, seed=1)
