@@ -476,6 +476,20 @@ def test_randomised_shape_sweep(ps, orc):
         assert err < WAVE_TOL, (cfg, err)
 
 
+def test_randomised_potential_sweep(ps, orc):
+    """30 random cases of tools/fuzz_potential.py (seed 5): grid shapes over every structure-factor / inverse-FFT path,
+    1-3 species, atoms outside the box and outside every slice, one-pass and keep_potential engines."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("fuzzp", os.path.join(os.path.dirname(__file__), "..", "tools", "fuzz_potential.py"))
+    fuzzp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzzp)
+    rng = np.random.default_rng(5)
+    for c in range(30):
+        cfg, err = fuzzp.one(rng, max_pix=2 ** 18)
+        assert err < POT_TOL, (cfg, err)
+
+
 def test_k_window_argument_errors(ps):
     from pyslice_amd.synthetic import synthetic_trajectory
     tr = synthetic_trajectory(32, 2, 1, density=0.05, seed=1)
