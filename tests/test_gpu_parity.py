@@ -490,6 +490,19 @@ def test_randomised_potential_sweep(ps, orc):
         assert err < POT_TOL, (cfg, err)
 
 
+@pytest.mark.parametrize("nx,ny,nz,P", [(256, 256, 3, 700), (512, 512, 4, 70), (2048, 512, 4, 20), (1024, 512, 4, 33),
+                                         (500, 360, 3, 40)])
+def test_many_probes_per_launch(ps, orc, nx, ny, nz, P):
+    """Several work items per workgroup, probe chunks with t_k reuse in registers, the 2048-point kernel's item loop
+    with its re-parked propagator: every probe's spectrum against the oracle (tools/fuzz_many_probes.py)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("fmp", os.path.join(os.path.dirname(__file__), "..", "tools", "fuzz_many_probes.py"))
+    fmp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fmp)
+    assert fmp.case(nx, ny, nz, P) < WAVE_TOL
+
+
 def test_k_window_argument_errors(ps):
     from pyslice_amd.synthetic import synthetic_trajectory
     tr = synthetic_trajectory(32, 2, 1, density=0.05, seed=1)
