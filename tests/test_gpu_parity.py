@@ -573,6 +573,40 @@ def test_k3_single_slice_is_transmission_times_probe(ps, orc):
     assert rel_l2(ex, want) < 1e-5
 
 
+def test_k4_potential_integral_on_device(ps):
+    """K4, no oracle: sum_xy V[:,:,s] dx^2 dy^2 = sum over the atoms of slice s of f_Z(0), with
+    f_Z(0) = sum_i a_i / b_i + sum_i c_i straight from the Kirkland table -- the DC bin of every slice."""
+    from pyslice_amd.synthetic import synthetic_trajectory
+    tr = synthetic_trajectory(96, 6, 1, ny=80, density=0.08, seed=12)
+    xs, ys, zs, *_ = ps.gridFromTrajectory(tr)
+    pot = ps.Potential(xs, ys, zs, tr.positions[0], list(tr.atom_types))
+    V = npy(pot.array)
+    table = ps.loadKirkland()                                           # (103, 3, 4): a, b, c, d
+    f0 = {int(Z): float((table[Z - 1][:, 0] / table[Z - 1][:, 1]).sum() + table[Z - 1][:, 2].sum()) for Z in set(tr.atom_types)}
+    dx, dy, dz = xs[1] - xs[0], ys[1] - ys[0], zs[1] - zs[0]
+    lo = np.r_[0.0, zs[1:] - dz / 2]
+    hi = np.r_[zs[:-1] + dz / 2, zs[-1] + dz]
+    z = tr.positions[0][:, 2]
+    for s_ in range(len(zs)):
+        m = (z >= lo[s_]) & (z < hi[s_])
+        want = sum(f0[int(Z)] for Z in np.asarray(tr.atom_types)[m])
+        got = float(V[:, :, s_].astype(np.float64).sum()) * dx ** 2 * dy ** 2
+        assert abs(got - want) <= 2e-5 * max(1.0, abs(want)), (s_, got, want)
+
+
+def test_k6_probe_peak_position_on_device(ps):
+    """K6 / quirk Q3, no oracle: the probe 'at p' of create_batched_probes peaks at (L/2 - p) mod L."""
+    nx, ny, dx, dy = 128, 96, 0.1, 0.12
+    xs, ys = np.arange(nx) * dx, np.arange(ny) * dy
+    pp = [(1.0, 2.0), (6.4, 5.76), (11.3, 0.5), (0.0, 9.0)]
+    arr = npy(ps.create_batched_probes(ps.Probe(xs, ys, 30.0, 100e3), pp).array)
+    for a, (px, py) in zip(arr, pp):
+        i, j = np.unravel_index(np.argmax(np.abs(a)), a.shape)
+        ex, ey = ((nx // 2) * dx - px) % (nx * dx), ((ny // 2) * dy - py) % (ny * dy)
+        assert min(abs(i * dx - ex), nx * dx - abs(i * dx - ex)) <= dx
+        assert min(abs(j * dy - ey), ny * dy - abs(j * dy - ey)) <= dy
+
+
 def test_k2_norm_conserved_full_size(ps):
     """BASELINE full grid (1024^2, 200 slices): |t|=|P|=1, so sum|Psi_k|^2 = nx*ny * (aperture pixel count)."""
     from pyslice_amd.synthetic import synthetic_trajectory, stem_probe_grid
