@@ -12,6 +12,7 @@
 // touched exactly once per pass with 8R-byte (row pass) or 128-byte (column pass) contiguous
 // segments.  Index algebra is unit-tested on the host (tools/fft_regs_host.cpp).
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include "fft_regs.h"
 
@@ -540,33 +541,46 @@ __global__ void __launch_bounds__(LINES * R) rowT_pass_kernel(RowTJob job) {
             nk = 0; nitem = item + (int)gridDim.x; nlb = lb + step_lb; npc = pc + step_pc;
             if (npc >= pchunks) { npc -= pchunks; ++nlb; }
         }
-        // The prefetch of the next line is issued in the middle of the iteration, not at its top: right after the
-        // previous iteration's 16 stores the address unit is still busy with them and 32 loads would stall the wave
-        // in issue; half an iteration later they go out freely and still have ~7 us to land (measured 322 -> 306 us).
-        auto prefetch = [&]() {
-            __builtin_amdgcn_sched_barrier(0);
-            if (nitem < n_items) {
-                const float2* r = line_ptr(nlb, npc, nk);
+        // The prefetch of the next line is spread over the iteration, a quarter of the loads after each of the four
+        // transforms, instead of 32 loads at the top: right after the previous iteration's 16 stores the address unit is
+        // still busy with them and a burst of loads stalls the wave in issue (measured per 1024^2 pass: 322 us at the
+        // top, 306 us all after the third transform, 294 us half after the second and half after the third, 287 us in
+        // quarters).
+        auto prefetch_part = [&](auto lo_c, auto hi_c) {
+            // R = 32: quarters; R = 16 (256-point lines, three workgroups per CU): everything at the first call, measured faster
+            constexpr int LO = (R == 32) ? decltype(lo_c)::value : (decltype(lo_c)::value == 0 ? 0 : R);
+            constexpr int HI = (R == 32) ? decltype(hi_c)::value : R;
+            if constexpr (HI > LO) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (nitem < n_items) {
+                    const float2* r = line_ptr(nlb, npc, nk);
 #pragma unroll
-                for (int j = 0; j < R; ++j) vn[j] = r[j * R + ln];
+                    for (int j = LO; j < HI; ++j) vn[j] = r[j * R + ln];
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
         };
+#define MSL_IC(x) std::integral_constant<int, (x)>{}              // quarter boundaries in 32nds of the line's registers
         if (job.flags & P2_PRE_A) {
             if constexpr (C64) fourstep_c64<R, false>(v, myrow, tw, ln); else fourstep_split<R, false>(v, reinterpret_cast<float*>(myrow), tw, ln);
+        }
+        prefetch_part(MSL_IC(0), MSL_IC(8));
+        if (job.flags & P2_PRE_A) {
             mul_table<R, 0, false>(v, pl, ln);
             if constexpr (C64) fourstep_c64<R, true>(v, myrow, tw, ln); else fourstep_split<R, true>(v, reinterpret_cast<float*>(myrow), tw, ln);
         }
+        prefetch_part(MSL_IC(8), MSL_IC(16));
 #pragma unroll
         for (int j = 0; j < R; ++j) v[j] = cmulf(v[j], tv[j]);
         if (job.flags & P2_POST_A) {
             if constexpr (C64) fourstep_c64<R, false>(v, myrow, tw, ln); else fourstep_split<R, false>(v, reinterpret_cast<float*>(myrow), tw, ln);
         }
-        prefetch();
+        prefetch_part(MSL_IC(16), MSL_IC(24));
         if (job.flags & P2_POST_A) {
             mul_table<R, 0, false>(v, pl, ln);
             if constexpr (C64) fourstep_c64<R, true>(v, myrow, tw, ln); else fourstep_split<R, true>(v, reinterpret_cast<float*>(myrow), tw, ln);
         }
+        prefetch_part(MSL_IC(24), MSL_IC(32));
         wave_lds_fence();
 #pragma unroll
         for (int j = 0; j < R; ++j) myrow[j * R + ln] = v[j];
