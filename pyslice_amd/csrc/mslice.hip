@@ -1221,7 +1221,7 @@ int msl_build_potential(msl_handle* h, const double* pos, const int32_t* Z, int6
                            (long long)n, h->d_z2s, h->d_lo, h->d_hi, c.nz, nsp, ax1, ax2, axs, 1.0 / lx, 1.0 / ly, h->d_key,
                            h->d_u1, h->d_u2, h->d_counts);
         hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(64), 0, h->stream, h->d_counts, h->d_start, nkeys);
-        hipLaunchKernelGGL(bin_fill_kernel, dim3(nkeys), dim3(64), 0, h->stream, h->d_key, (long long)n, h->d_start, h->d_order);
+        hipLaunchKernelGGL(bin_fill_kernel, dim3(nkeys), dim3(1024), 0, h->stream, h->d_key, (long long)n, h->d_start, h->d_order);
         HIPCHK(h, hipGetLastError());
         {
             // atoms that fell into a slice: d_start[nkeys], read by the kernels themselves (grids sized for all n atoms)

@@ -77,17 +77,31 @@ __global__ void bin_scan_kernel(const int* __restrict__ counts, int* __restrict_
     }
 }
 
-// Stable compaction: one wave per key collects its atoms in original order (deterministic sums).
-__global__ void bin_fill_kernel(const int* __restrict__ key, long long n, const int* __restrict__ start,
-                                int* __restrict__ order) {
+// Stable compaction: one 1024-thread workgroup per key collects its atoms in original order (deterministic sums).
+// Every wave scans a contiguous share of the atoms twice: once to count its matches, then -- after an exclusive prefix
+// over the 16 waves -- to write them.
+__global__ void __launch_bounds__(1024) bin_fill_kernel(const int* __restrict__ key, long long n, const int* __restrict__ start,
+                                                        int* __restrict__ order) {
+    __shared__ int wave_count[16];
     const int mykey = blockIdx.x;
-    const int lane = threadIdx.x;
-    int pos = start[mykey];
-    if (start[mykey + 1] == pos) return;
-    for (long long a0 = 0; a0 < n; a0 += 64) {
-        long long a = a0 + lane;
-        bool f = (a < n) && (key[a] == mykey);
-        unsigned long long m = __ballot(f);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int base = start[mykey];
+    if (start[mykey + 1] == base) return;                       // uniform for the workgroup
+    const long long per = ((n + 16 * 64 - 1) / (16 * 64)) * 64;   // atoms per wave, a multiple of 64
+    const long long lo = per * wave, hi = (lo + per < n) ? lo + per : n;
+    int cnt = 0;
+    for (long long a0 = lo; a0 < hi; a0 += 64) {
+        const long long a = a0 + lane;
+        cnt += __popcll(__ballot((a < hi) && (key[a] == mykey)));
+    }
+    if (lane == 0) wave_count[wave] = cnt;
+    __syncthreads();
+    int pos = base;
+    for (int w = 0; w < wave; ++w) pos += wave_count[w];
+    for (long long a0 = lo; a0 < hi; a0 += 64) {
+        const long long a = a0 + lane;
+        const bool f = (a < hi) && (key[a] == mykey);
+        const unsigned long long m = __ballot(f);
         if (f) order[pos + __popcll(m & ((1ull << lane) - 1ull))] = (int)a;
         pos += __popcll(m);
     }
