@@ -286,7 +286,18 @@ __global__ void structure_factor_nyquist_kernel(float2* __restrict__ recip, cons
     for (int sp = 0; sp < n_species; ++sp) {
         const int a0 = start[s * n_species + sp], a1 = start[s * n_species + sp + 1];
         float2 acc = make_float2(0.f, 0.f);
-        for (int a = a0; a < a1; ++a) {
+        int a = a0;
+        for (; a + 8 <= a1; a += 8) {                           // eight atoms' loads in flight; summation order unchanged
+            float2 vx[8], vy[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { vx[u] = ex[(size_t)(a + u) * nx + mx]; vy[u] = ey[(size_t)(a + u) * ny + my]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                acc.x = fmaf(vx[u].x, vy[u].x, fmaf(-vx[u].y, vy[u].y, acc.x));
+                acc.y = fmaf(vx[u].x, vy[u].y, fmaf(vx[u].y, vy[u].x, acc.y));
+            }
+        }
+        for (; a < a1; ++a) {
             const float2 vx = ex[(size_t)a * nx + mx], vy = ey[(size_t)a * ny + my];
             acc.x = fmaf(vx.x, vy.x, fmaf(-vx.y, vy.y, acc.x));
             acc.y = fmaf(vx.x, vy.y, fmaf(vx.y, vy.x, acc.y));
