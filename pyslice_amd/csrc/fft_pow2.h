@@ -38,11 +38,11 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// Multiply v[j] (j = J0..R-1) by tab[j*R + ln] (conjugated when CONJ) in chunks of 8 with a scheduling
-// barrier between chunks, so the compiler cannot hoist all R table loads at once (register pressure).
-template <int R, int J0, bool CONJ, int STRIDE = R, typename TabPtr>
+// Multiply v[j] (j = J0..R-1) by tab[j*R + ln] (conjugated when CONJ) in chunks of CH with a scheduling
+// barrier between chunks, so the compiler cannot hoist all R table loads at once (register pressure).  Every chunk
+// is one exposed LDS round trip: the transposing kernel, which has the registers, uses chunks of 16 (291 -> 288 us).
+template <int R, int J0, bool CONJ, int STRIDE = R, int CH = 8, typename TabPtr>
 __device__ __forceinline__ void mul_table(float2 (&v)[R], TabPtr tab, int ln) {
-    constexpr int CH = 8;
 #pragma unroll
     for (int c = 0; c < R; c += CH) {
         float2 w[CH];
@@ -58,10 +58,10 @@ __device__ __forceinline__ void mul_table(float2 (&v)[R], TabPtr tab, int ln) {
 // tw: LDS table T[k1*R + lane] = exp(-2 pi i lane k1 / N) (forward); conjugated for INV.
 // Transpose through a float scratch of R*(R+1) words, real and imaginary parts one after the other
 // (row pass: halves the LDS footprint so more waves fit a CU).
-template <int R, bool INV>
+template <int R, bool INV, int CH = 8>
 __device__ __forceinline__ void fourstep_split(float2 (&v)[R], float* scratch, const float2* tw, int ln) {
     fft_regs<R, INV>(v);
-    mul_table<R, 1, INV>(v, tw, ln);
+    mul_table<R, 1, INV, R, CH>(v, tw, ln);
 #pragma unroll
     for (int k1 = 0; k1 < R; ++k1) scratch[k1 * (R + 1) + ln] = v[k1].x;
     wave_lds_fence();
@@ -78,10 +78,10 @@ __device__ __forceinline__ void fourstep_split(float2 (&v)[R], float* scratch, c
 }
 
 // same with a complex scratch of R*(R+1) float2 (column pass: the tile is in LDS anyway)
-template <int R, bool INV>
+template <int R, bool INV, int CH = 8>
 __device__ __forceinline__ void fourstep_c64(float2 (&v)[R], float2* scratch, const float2* tw, int ln) {
     fft_regs<R, INV>(v);
-    mul_table<R, 1, INV>(v, tw, ln);
+    mul_table<R, 1, INV, R, CH>(v, tw, ln);
 #pragma unroll
     for (int k1 = 0; k1 < R; ++k1) scratch[k1 * (R + 1) + ln] = v[k1];
     wave_lds_fence();
@@ -490,6 +490,7 @@ struct RowTJob {
 template <int R, int LINES, bool C64>
 __global__ void __launch_bounds__(LINES * R) rowT_pass_kernel(RowTJob job) {
     constexpr int N = R * R;
+    constexpr int TCH = (R == 32) ? 16 : 8;             // table-multiply chunk (see mul_table)
     constexpr int NT = LINES * R;
     constexpr int CS = R * (R + 1) + 1;
     constexpr int TPS = LINES / 2;                    // threads (16 B = 2 lines each) per output segment of LINES*8 bytes
@@ -562,23 +563,23 @@ __global__ void __launch_bounds__(LINES * R) rowT_pass_kernel(RowTJob job) {
         };
 #define MSL_IC(x) std::integral_constant<int, (x)>{}              // quarter boundaries in 32nds of the line's registers
         if (job.flags & P2_PRE_A) {
-            if constexpr (C64) fourstep_c64<R, false>(v, myrow, tw, ln); else fourstep_split<R, false>(v, reinterpret_cast<float*>(myrow), tw, ln);
+            if constexpr (C64) fourstep_c64<R, false, TCH>(v, myrow, tw, ln); else fourstep_split<R, false, TCH>(v, reinterpret_cast<float*>(myrow), tw, ln);
         }
         prefetch_part(MSL_IC(0), MSL_IC(8));
         if (job.flags & P2_PRE_A) {
-            mul_table<R, 0, false>(v, pl, ln);
-            if constexpr (C64) fourstep_c64<R, true>(v, myrow, tw, ln); else fourstep_split<R, true>(v, reinterpret_cast<float*>(myrow), tw, ln);
+            mul_table<R, 0, false, R, TCH>(v, pl, ln);
+            if constexpr (C64) fourstep_c64<R, true, TCH>(v, myrow, tw, ln); else fourstep_split<R, true, TCH>(v, reinterpret_cast<float*>(myrow), tw, ln);
         }
         prefetch_part(MSL_IC(8), MSL_IC(16));
 #pragma unroll
         for (int j = 0; j < R; ++j) v[j] = cmulf(v[j], tv[j]);
         if (job.flags & P2_POST_A) {
-            if constexpr (C64) fourstep_c64<R, false>(v, myrow, tw, ln); else fourstep_split<R, false>(v, reinterpret_cast<float*>(myrow), tw, ln);
+            if constexpr (C64) fourstep_c64<R, false, TCH>(v, myrow, tw, ln); else fourstep_split<R, false, TCH>(v, reinterpret_cast<float*>(myrow), tw, ln);
         }
         prefetch_part(MSL_IC(16), MSL_IC(24));
         if (job.flags & P2_POST_A) {
-            mul_table<R, 0, false>(v, pl, ln);
-            if constexpr (C64) fourstep_c64<R, true>(v, myrow, tw, ln); else fourstep_split<R, true>(v, reinterpret_cast<float*>(myrow), tw, ln);
+            mul_table<R, 0, false, R, TCH>(v, pl, ln);
+            if constexpr (C64) fourstep_c64<R, true, TCH>(v, myrow, tw, ln); else fourstep_split<R, true, TCH>(v, reinterpret_cast<float*>(myrow), tw, ln);
         }
         prefetch_part(MSL_IC(24), MSL_IC(32));
         wave_lds_fence();
