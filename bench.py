@@ -40,7 +40,8 @@ def parse():
     ap.add_argument("--probes", type=int, default=64)
     ap.add_argument("--aperture", type=float, default=30.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-slices", type=int, default=16, help="slices of the bounded CPU sample")
+    ap.add_argument("--cpu-slices", type=int, default=100,
+                    help="slices of the bounded CPU sample (100 of 200 at 1024^2: about 12 s of single-thread work)")
     ap.add_argument("--tacaw", action="store_true", help="also time the TACAW time->frequency FFT over the K frames")
     ap.add_argument("--no-launch-timing", action="store_true",
                     help="run the library as production does (no per-launch HIP events, frames queue asynchronously); "
