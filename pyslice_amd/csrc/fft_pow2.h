@@ -27,10 +27,22 @@ __device__ __forceinline__ float2 cmulf_conj(float2 a, float2 b) {      // a * c
 
 // LDS ordering inside one wave: DS instructions of a wave execute in order, so only the compiler
 // must be kept from reordering the accesses of the transpose.
+#ifndef MSL_LDS_ORDER_ONLY
+#define MSL_LDS_ORDER_ONLY 1
+#endif
+// Ordering point between LDS phases of ONE wave (write a scratch, read it back transposed, write the next part ...).
+// The LDS executes the operations of a wave in issue order, so no wait is needed for correctness -- only the compiler
+// must not reorder the accesses: a scheduling barrier and a compiler memory barrier.  (With real wavefront-scope fences
+// every phase change costs a full s_waitcnt lgkmcnt(0); MSL_LDS_ORDER_ONLY=0 restores them.)
 __device__ __forceinline__ void wave_lds_fence() {
+#if MSL_LDS_ORDER_ONLY
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+#else
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
 }
 
 // workgroup barrier that drains LDS traffic only (global loads/stores stay in flight across it)
