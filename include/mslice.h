@@ -77,7 +77,7 @@ typedef enum {
 typedef struct {
     uint64_t slice_steps;      /* probes x slices propagated since create/reset             */
     uint64_t frames;           /* frames propagated                                         */
-    uint64_t algorithmic_bytes;/* 32 B x nx x ny per slice-step (+ V/t and epilogue terms)  */
+    uint64_t algorithmic_bytes;/* 16 B x nx x ny per slice-step on the one-pass loop, 32 B on the two-pass loop (+ t and epilogue terms) */
     double   ms_potential;     /* device time (HIP events) spent in potential builds        */
     double   ms_propagate;     /* ... in slice loops (+ epilogue)                           */
     double   ms_tacaw;

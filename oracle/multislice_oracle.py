@@ -160,6 +160,32 @@ def batched_probes(base: np.ndarray, xs, ys, positions_xy) -> np.ndarray:
     return out
 
 
+def defocus(array: np.ndarray, xs, ys, eV, dz) -> np.ndarray:
+    """Probe.defocus; reference: multislice.py:183-190.
+
+    P = exp(-i pi lambda dz k^2); dz > 0 multiplies the spectrum by P, dz < 0 DIVIDES by it -- and since P(dz<0) is
+    exp(+i pi lambda |dz| k^2), the division applies exp(-i pi lambda |dz| k^2) again: both signs give the same
+    result (a reference quirk the product reproduces); dz == 0 leaves the array alone.
+    """
+    if dz == 0:
+        return np.asarray(array)
+    kxs = np.fft.fftfreq(len(xs), d=xs[1] - xs[0])
+    kys = np.fft.fftfreq(len(ys), d=ys[1] - ys[0])
+    ph = np.exp(-1j * np.pi * wavelength(eV) * abs(dz) * (kxs[:, None] ** 2 + kys[None, :] ** 2))
+    return np.fft.ifft2(ph * np.fft.fft2(array))
+
+
+def cache_dir_name(n_frames, n_atoms, box_matrix, atom_types, aperture, voltage_eV, slice_thickness, sampling,
+                   probe_positions, backend="pytorch") -> str:
+    """Name of the reference's per-run cache directory below psi_data/; reference: calculators.py:78-94, 139."""
+    import hashlib
+    params = {'n_frames': n_frames, 'n_atoms': n_atoms, 'box_matrix': np.asarray(box_matrix).tolist(),
+              'atom_types': np.asarray(atom_types).tolist(), 'aperture': aperture, 'voltage_eV': voltage_eV,
+              'slice_thickness': slice_thickness, 'sampling': sampling, 'probe_positions': probe_positions,
+              'backend': backend}
+    return "torch_" + hashlib.md5(str(sorted(params.items())).encode()).hexdigest()[:12]
+
+
 def propagate(probes: np.ndarray, V: np.ndarray, xs, ys, zs, eV) -> np.ndarray:
     """Multislice loop; reference: multislice.py:254-299.
 

@@ -13,7 +13,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libmslice.so")
 SOURCES = ["mslice.hip"]
-DEPS = ["mslice.hip", "fft_generic.h", "fft_pow2.h", "fft_regs.h", "potential.h", os.path.join("..", "..", "include", "mslice.h")]
+def _deps():
+    """every source and header of csrc/ plus the public header"""
+    return sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))) + [os.path.join("..", "..", "include", "mslice.h")]
 ARCH = "gfx950"
 
 
@@ -28,7 +30,7 @@ def needs_build() -> bool:
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    for d in DEPS:
+    for d in _deps():
         p = os.path.join(CSRC, d)
         if os.path.exists(p) and os.path.getmtime(p) > t:
             return True

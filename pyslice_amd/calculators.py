@@ -146,8 +146,9 @@ class MultisliceCalculator:
         slice_coords = np.asarray([xs, ys, zs][slice_axis], dtype=np.float64)
         n_slices = len(slice_coords)
         dz = zs[1] - zs[0] if nz > 1 else 0.5
-        if self._engine is not None:
-            self._engine.close()
+        # A previous run's WFData (and zero-copy device views of its buffers) may still hold the old engine: drop our
+        # reference and let the last owner free it, instead of closing it under them.
+        self._engine = None
         self._engine = _native.Engine(nx, ny, n_slices, self.dx, self.dy, dz, wavelength(voltage_eV),
                                       interaction_sigma(voltage_eV), n_probes=self.n_probes,
                                       n_frames=max(1, len(self._frames)), device=_device_index(dev),

@@ -26,7 +26,10 @@ __device__ __forceinline__ float2 cmulf_conj(float2 a, float2 b) {      // a * c
 }
 
 // LDS ordering inside one wave: DS instructions of a wave execute in order, so only the compiler
-// must be kept from reordering the accesses of the transpose.
+// must be kept from reordering the accesses of the transpose (LLVM AMDGPU memory model: LDS operations of one
+// wavefront are issued and complete in program order -- "ds" instructions return in order and lgkmcnt counts them
+// in order).  This holds only while a scratch area is touched by ONE wave: every transform below asserts that an
+// R-lane group never straddles a wave (64 % R == 0).  A/B check: build with -DMSL_LDS_ORDER_ONLY=0.
 #ifndef MSL_LDS_ORDER_ONLY
 #define MSL_LDS_ORDER_ONLY 1
 #endif
@@ -72,6 +75,7 @@ __device__ __forceinline__ void mul_table(float2 (&v)[R], TabPtr tab, int ln) {
 // (row pass: halves the LDS footprint so more waves fit a CU).
 template <int R, bool INV, int CH = 8>
 __device__ __forceinline__ void fourstep_split(float2 (&v)[R], float* scratch, const float2* tw, int ln) {
+    static_assert(64 % R == 0, "an R-lane group must lie inside one wave: the scratch is ordered per wave only");
     fft_regs<R, INV>(v);
     mul_table<R, 1, INV, R, CH>(v, tw, ln);
 #pragma unroll
@@ -92,6 +96,7 @@ __device__ __forceinline__ void fourstep_split(float2 (&v)[R], float* scratch, c
 // same with a complex scratch of R*(R+1) float2 (column pass: the tile is in LDS anyway)
 template <int R, bool INV, int CH = 8>
 __device__ __forceinline__ void fourstep_c64(float2 (&v)[R], float2* scratch, const float2* tw, int ln) {
+    static_assert(64 % R == 0, "an R-lane group must lie inside one wave: the scratch is ordered per wave only");
     fft_regs<R, INV>(v);
     mul_table<R, 1, INV, R, CH>(v, tw, ln);
 #pragma unroll
@@ -623,6 +628,7 @@ __global__ void __launch_bounds__(LINES * R) rowT_pass_kernel(RowTJob job) {
 // holds X[2k+b] -- which never leaves the kernel: the propagator table is stored in the same order.
 template <int R, bool INV>
 __device__ __forceinline__ void line2_transform(float2 (&v)[2 * R], float* scratch, const float2* tw, const float2* tw2, int ln) {
+    static_assert(64 % R == 0, "an R-lane group must lie inside one wave: the scratch is ordered per wave only");
     float2 (&lo)[R] = reinterpret_cast<float2 (&)[R]>(v[0]);
     float2 (&hi)[R] = reinterpret_cast<float2 (&)[R]>(v[R]);
     constexpr int CH = 8;                              // table chunks with scheduling barriers: see mul_table

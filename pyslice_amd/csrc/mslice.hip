@@ -1151,8 +1151,7 @@ int msl_build_potential(msl_handle* h, const double* pos, const int32_t* Z, int6
     if (!h->have_kirkland) return fail(h, MSL_ERR_STATE, "msl_build_potential: call msl_set_kirkland first");
     if (!h->have_slices) return fail(h, MSL_ERR_STATE, "msl_build_potential: call msl_set_slices first");
     if (n < 0 || n > 0x7fffffff) return fail(h, MSL_ERR_INVALID, "msl_build_potential: bad atom count");
-    int axes_seen = (1 << ax1) | (1 << ax2) | (1 << axs);
-    if (ax1 < 0 || ax1 > 2 || ax2 < 0 || ax2 > 2 || axs < 0 || axs > 2 || axes_seen != 7)
+    if (ax1 < 0 || ax1 > 2 || ax2 < 0 || ax2 > 2 || axs < 0 || axs > 2 || ((1 << ax1) | (1 << ax2) | (1 << axs)) != 7)
         return fail(h, MSL_ERR_INVALID, "msl_build_potential: axes must be a permutation of 0,1,2");
     const msl_config& c = h->cfg;
     HIPCHK(h, hipSetDevice(c.device));

@@ -113,7 +113,10 @@ class Probe:
         return self
 
     def defocus(self, dz):
-        """reference multislice.py:183-190: psi <- ifft2(P(dz) fft2(psi)) (dz<0: divide by P == P(-|dz|)).
+        """reference multislice.py:183-190: psi <- ifft2(P fft2(psi)) with P = exp(-i pi lambda dz k^2) for dz > 0 and
+        psi <- ifft2(fft2(psi) / P) for dz < 0.  Dividing by P(dz<0) = exp(+i pi lambda |dz| k^2) applies
+        exp(-i pi lambda |dz| k^2) again, so in the reference BOTH signs defocus by +|dz| (quirk Q19, pinned by
+        tests/golden/g10_defocus.npz); the same here.  dz == 0 leaves the array alone.
 
         Evaluated on the device as one Fresnel step of the slice loop through vacuum (two empty slices).
         """
@@ -122,7 +125,7 @@ class Probe:
         base = _to_numpy(self.array).astype(np.complex64)
         if base.ndim != 2:
             raise ValueError("defocus() applies to a single (nx,ny) probe")
-        eng = _native.Engine(self._nx, self._ny, 2, self._dx, self._dy, float(dz), self.wavelength, 0.0,
+        eng = _native.Engine(self._nx, self._ny, 2, self._dx, self._dy, abs(float(dz)), self.wavelength, 0.0,
                              n_probes=1, n_frames=0, device=_device_index(self.device))
         try:
             eng.upload_potential(np.zeros((2, self._nx, self._ny), dtype=np.float32))

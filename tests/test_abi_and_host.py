@@ -83,6 +83,20 @@ def test_host_constants_match_golden(golden):
         assert wavelength(e) == l and interaction_sigma(e) == s
 
 
+def test_cache_key_matches_reference_directory_names(golden):
+    """MultisliceCalculator._generate_cache_key names the directory the reference names for the same run
+    (calculators.py:78-94, 139): reference and build can share psi_data/."""
+    import pyslice_amd as ps
+    g = golden("g11_cache")
+    for c in ("a", "b"):
+        pp = [tuple(float(v) for v in p) for p in g[f"probe_positions_{c}"]] if bool(g[f"has_positions_{c}"]) else None
+        pos = g[f"positions_{c}"]
+        tr = ps.Trajectory(g[f"Z_{c}"], pos, np.zeros_like(pos), g[f"box_{c}"], 0.005)
+        calc = ps.MultisliceCalculator.__new__(ps.MultisliceCalculator)        # no device needed for the key
+        key = calc._generate_cache_key(tr, float(g[f"aperture_{c}"]), float(g[f"eV_{c}"]), 0.5, 0.1, pp)
+        assert "torch_" + key == str(g[f"dir_name_{c}"])
+
+
 def test_kirkland_table_and_names():
     import pyslice_amd as ps
     t = ps.loadKirkland()

@@ -762,6 +762,42 @@ def test_frame_cache_format_and_resume(ps, golden, tmp_path, monkeypatch):
     assert not (tmp_path / "psi_data" / "psi_data").exists()
 
 
+def test_frame_cache_shared_with_reference(ps, golden, tmp_path, monkeypatch):
+    """A psi_data/ directory written by the REFERENCE (g11: its directory name and its frame_0.npy) is found and
+    resumed from by the build, and the frames the build writes have the reference's name, shape, dtype and values."""
+    g = golden("g11_cache")
+    monkeypatch.chdir(tmp_path)
+    for c in ("a", "b"):
+        pp = [tuple(float(v) for v in p) for p in g[f"probe_positions_{c}"]] if bool(g[f"has_positions_{c}"]) else None
+        pos = g[f"positions_{c}"]
+        tr = ps.Trajectory(g[f"Z_{c}"], pos, np.zeros_like(pos), g[f"box_{c}"], 0.005)
+        calc = ps.MultisliceCalculator(progress=False, cache=True)
+        calc.setup(tr, aperture=float(g[f"aperture_{c}"]), voltage_eV=float(g[f"eV_{c}"]), probe_positions=pp)
+        assert calc.output_dir.name == str(g[f"dir_name_{c}"])
+        np.save(calc.output_dir / "frame_0.npy", g[f"frame0_{c}"])           # the reference's own cache file
+        wf = npy(calc.run().wavefunction_data)
+        assert (calc.frames_computed, calc.frames_cached) == (pos.shape[0] - 1, 1)
+        assert rel_l2(wf[:, 0], g[f"wavefunction_frame0_{c}"]) < 1e-6           # loaded (complex64 on the device)
+        f1 = np.load(calc.output_dir / "frame_1.npy")
+        assert f1.shape == g[f"frame0_{c}"].shape and f1.dtype == np.complex128
+
+
+def test_g10_probe_defocus(ps, golden):
+    """Probe.defocus (reference multislice.py:183-190) for dz > 0 and dz < 0 -- the reference defocuses by +|dz| for
+    either sign (it divides by P(dz<0)); 07_defocus.py's 1000 A included."""
+    g = golden("g10_defocus")
+    for tag in ("64", "96x80"):
+        xs, ys = g[f"xs_{tag}"], g[f"ys_{tag}"]
+        for dz in g["dz"]:
+            pr = ps.Probe(xs, ys, float(g["mrad"]), float(g["eV"]))
+            pr.defocus(float(dz))
+            assert rel_l2(npy(pr.array), g[f"defocus_{tag}_{dz:g}"]) < 5e-6
+    pr = ps.Probe(g["xs_64"], g["ys_64"], 30.0, 100e3)
+    before = npy(pr.array).copy()
+    pr.defocus(0)
+    assert np.array_equal(npy(pr.array), before)
+
+
 def test_tacaw_fourstep_time_axis_256_frames(ps, orc):
     """T = 256 frames (BASELINE C3's frame count) takes the four-step time-FFT kernel (pixels as columns of a
     (T, npix) image, DC zeroed, fftshifted |.|^2 epilogue); compare with the oracle and with the generic kernel."""

@@ -134,6 +134,33 @@ def test_g9_haadf(golden):
     assert rel_l2(adf, g["adf"]) < 1e-6      # the reference accumulates this image in float32
 
 
+def test_g10_defocus(golden):
+    """Probe.defocus for both signs of dz (reference multislice.py:183-190): the sign does not matter (quirk Q19)."""
+    g = golden("g10_defocus")
+    for tag in ("64", "96x80"):
+        xs, ys = g[f"xs_{tag}"], g[f"ys_{tag}"]
+        base = orc.probe_array(xs, ys, float(g["mrad"]), float(g["eV"]))
+        for dz in g["dz"]:
+            assert rel_l2(orc.defocus(base, xs, ys, float(g["eV"]), float(dz)), g[f"defocus_{tag}_{dz:g}"]) < TOL
+        assert rel_l2(g[f"defocus_{tag}_100"], g[f"defocus_{tag}_-100"]) < TOL
+
+
+def test_g11_cache_dir_name(golden):
+    """The cache directory name the reference derives from the run parameters (calculators.py:78-94, 139)."""
+    g = golden("g11_cache")
+    for c in ("a", "b"):
+        pp = [tuple(float(v) for v in p) for p in g[f"probe_positions_{c}"]] if bool(g[f"has_positions_{c}"]) else None
+        pos = g[f"positions_{c}"]
+        name = orc.cache_dir_name(pos.shape[0], pos.shape[1], g[f"box_{c}"], g[f"Z_{c}"], float(g[f"aperture_{c}"]),
+                                  float(g[f"eV_{c}"]), 0.5, 0.1, pp)
+        assert name == str(g[f"dir_name_{c}"])
+        assert list(g[f"files_{c}"]) == [f"frame_{i}.npy" for i in range(pos.shape[0])]
+        f0 = g[f"frame0_{c}"]
+        assert f0.ndim == 5 and f0.shape[0] == (len(pp) if pp else 1) and f0.shape[3:] == (1, 1)
+        assert np.array_equal(f0[:, :, :, 0, 0], g[f"wavefunction_frame0_{c}"][:, :, :, 0])
+        assert str(g[f"frame0_dtype_{c}"]) == "complex128"
+
+
 def test_k1_vacuum_plane_wave():
     """K1: V=0, plane wave -> Psi = nx*ny at DC (fftshifted centre), 0 elsewhere."""
     xs = np.linspace(0, 3.2, 32, endpoint=False); ys = xs.copy(); zs = np.linspace(0, 2.0, 4, endpoint=False)
