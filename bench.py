@@ -7,27 +7,39 @@ A "step" is one MD frame through the hot path on one GPU: projected Kirkland pot
 (P probes x nz slices) fused FFT / transmission / Fresnel slice loop -> exit-wave FFT epilogue,
 all inputs already resident in HBM except the frame's atom positions (a few MB).  Workload at
 N=1 is BASELINE.json configs[2]: 64-probe STEM grid, 1024^2 grid, 200 slices (the configuration
-the metric is quoted on).  With N>1 every rank runs its own K frames (frame sharding, no
-data-path collective): weak scaling, value = all ranks' slice-steps / max-over-ranks time.
+the metric is quoted on).
+
+N > 1: one process per GPU over RCCL.  Launched under torch.distributed.run the ranks come from
+the environment; launched plainly (`python bench.py --gpus N`) the script starts the N rank
+processes itself, before anything touches a GPU.  Default "weak" scaling: every rank runs its own
+K frames (frame sharding, no data-path collective), value = all ranks' slice-steps / max-over-ranks
+time.  `--scaling strong`: every step is one round of --frames-per-step frames sharded over the
+ranks, so the total work is fixed as N grows.  After the timed region the end-of-run exchanges
+of the sharded path are timed on the frames just computed and reported as `exchange_ms`:
+gather of the frame shards on rank 0 (WFData), and all-to-all frames->probes + device time FFT +
+gather of the intensities (TACAW).
 
 Prints ONE JSON line on rank 0 with the throughput plus
   roofline     -- dominant slice-loop kernel: algorithmic bytes per launch / mean launch duration
                   (HIP events on the library's stream, taken inside the timed region)
+  tacaw        -- (N=1) the time->frequency FFT over T=256 resident frame slots (BASELINE C3's T)
   cpu_baseline -- the NumPy oracle (port of the reference's NumPy path) timed on this host on a
-                  bounded sample of the same workload (rank 0, N=1 only).
+                  bounded sample of the same workload (rank 0, N=1 only): single thread, and
+                  `cpu_baseline_allcores` with scipy.fft workers + threaded BLAS.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-import numpy as np  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
+TACAW_T = 256             # BASELINE C3's frame count; the four-step time-FFT kernel serves T = 256 and 1024
 
 
 def parse():
@@ -39,48 +51,107 @@ def parse():
     ap.add_argument("--slices", type=int, default=200)
     ap.add_argument("--probes", type=int, default=64)
     ap.add_argument("--aperture", type=float, default=30.0)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--frames-per-step", type=int, default=8,
+                    help="--scaling strong: MD frames per step, sharded over the ranks (fixed total work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-slices", type=int, default=100,
                     help="slices of the bounded CPU sample (100 of 200 at 1024^2: about 12 s of single-thread work)")
-    ap.add_argument("--tacaw", action="store_true", help="also time the TACAW time->frequency FFT over the K frames")
+    ap.add_argument("--no-tacaw", action="store_true", help="skip the TACAW time->frequency FFT leg (N=1)")
+    ap.add_argument("--no-exchange", action="store_true", help="skip the end-of-run exchange timing (N>1)")
     ap.add_argument("--no-launch-timing", action="store_true",
                     help="run the library as production does (no per-launch HIP events, frames queue asynchronously); "
                          "the roofline block is then null")
     return ap.parse_args()
 
 
+# ---------------------------------------------------------------------------------------------------------
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N rank processes (fresh interpreters, nothing in this
+    process has touched a GPU or imported torch), wait for them, relay the first failure."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            code = p.poll()
+            if code is None:
+                continue
+            pending.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in pending:           # a rank died: the others would wait in the rendezvous for ever
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------------------
+def _sample(grid, nz_sample, seed=0):
+    from oracle import multislice_oracle as orc
+    from pyslice_amd.synthetic import synthetic_trajectory
+    tr = synthetic_trajectory(grid, nz_sample, 1, seed=seed)
+    return orc, tr, orc.grid_from_box(tr.box_matrix)
+
+
 def cpu_baseline(grid, nz_full, probes, aperture, nz_sample):
     """Oracle (NumPy complex128, single thread) on a bounded sample: same grid, same atom density,
     `nz_sample` slices, 1 probe; extrapolated exactly linearly to `probes` probes sharing the potential."""
-    from oracle import multislice_oracle as orc
-    from pyslice_amd.synthetic import synthetic_trajectory
-    try:
-        from threadpoolctl import threadpool_limits
-        ctx = threadpool_limits(limits=1)
-    except Exception:  # pragma: no cover
-        ctx = None
-    tr = synthetic_trajectory(grid, nz_sample, 1, seed=0)
-    xs, ys, zs, lx, ly, lz = orc.grid_from_box(tr.box_matrix)
-    t0 = time.perf_counter()
-    V = orc.potential(xs, ys, zs, tr.positions[0], tr.atom_types)
-    t_pot = time.perf_counter() - t0
-    pr = orc.batched_probes(orc.probe_array(xs, ys, aperture, 100e3), xs, ys, [(lx / 2, ly / 2)])
-    t0 = time.perf_counter()
-    ex = orc.propagate(pr, V, xs, ys, zs, 100e3)
-    orc.diffraction(ex)
-    t_prop = time.perf_counter() - t0
-    if ctx is not None:
-        ctx.restore_original_limits() if hasattr(ctx, "restore_original_limits") else None
+    from threadpoolctl import threadpool_limits
+    orc, tr, (xs, ys, zs, lx, ly, lz) = _sample(grid, nz_sample)
+    with threadpool_limits(limits=1):
+        t0 = time.perf_counter()
+        V = orc.potential(xs, ys, zs, tr.positions[0], tr.atom_types)
+        t_pot = time.perf_counter() - t0
+        pr = orc.batched_probes(orc.probe_array(xs, ys, aperture, 100e3), xs, ys, [(lx / 2, ly / 2)])
+        t0 = time.perf_counter()
+        ex = orc.propagate(pr, V, xs, ys, zs, 100e3)
+        orc.diffraction(ex)
+        t_prop = time.perf_counter() - t0
     value = probes * nz_sample / (t_pot + probes * t_prop)
     return {"value": round(value, 3), "unit": "slice-steps/s", "cores": 1, "kind": "port",
             "sample": f"NumPy c128 oracle, {grid}^2 grid, {nz_sample} of {nz_full} slices at full atom density "
                       f"({tr.n_atoms} atoms), 1 frame, 1 probe measured (potential {t_pot:.2f}s + slice loop "
                       f"{t_prop:.2f}s) and extrapolated linearly to {probes} probes sharing the potential",
+            "host_cpus": os.cpu_count()}, V
+
+
+def cpu_baseline_allcores(grid, nz_full, probes, aperture, nz_sample, V):
+    """The same oracle with every core this process may use: scipy.fft (pocketfft, `workers` threads, the measured probes
+    batched in one call) for the slice loop, threaded BLAS for the structure-factor products of the potential
+    (SURVEY 8d's second CPU leg).  Bounded sample: `nz_sample` slices, 4 probes measured, extrapolated to `probes`."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    orc, tr, (xs, ys, zs, lx, ly, lz) = _sample(grid, nz_sample)
+    pm = min(4, probes)
+    t0 = time.perf_counter()
+    V2 = orc.potential(xs, ys, zs, tr.positions[0], tr.atom_types)            # BLAS threads: library default = all cores
+    t_pot = time.perf_counter() - t0
+    pos = [(lx * (i + 1) / (pm + 1), ly / 2) for i in range(pm)]
+    pr = orc.batched_probes(orc.probe_array(xs, ys, aperture, 100e3), xs, ys, pos)
+    t0 = time.perf_counter()
+    ex = orc.propagate(pr, V2 if V is None else V, xs, ys, zs, 100e3, workers=cores)
+    orc.diffraction(ex, workers=cores)
+    t_prop = (time.perf_counter() - t0) / pm
+    value = probes * nz_sample / (t_pot + probes * t_prop)
+    return {"value": round(value, 3), "unit": "slice-steps/s", "cores": cores, "kind": "port",
+            "sample": f"NumPy c128 oracle with scipy.fft workers={cores} and threaded BLAS, {grid}^2 grid, {nz_sample} of "
+                      f"{nz_full} slices, 1 frame, {pm} probes measured in one batch (potential {t_pot:.2f}s + slice loop "
+                      f"{t_prop:.2f}s per probe) and extrapolated linearly to {probes} probes sharing the potential",
             "host_cpus": os.cpu_count()}
 
 
-def main():
-    a = parse()
+# ---------------------------------------------------------------------------------------------------------
+def run(a):
+    import numpy as np
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -96,32 +167,61 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
+        assert dist.get_world_size() == world
     if world != a.gpus and rank == 0:
         print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
     from pyslice_amd import _native
+    from pyslice_amd import distributed as D
     from pyslice_amd.multislice import interaction_sigma, wavelength
     from pyslice_amd.potentials import gridFromTrajectory, loadKirkland, slice_edges
     from pyslice_amd.synthetic import stem_probe_grid, synthetic_trajectory
 
     n, nz, P = a.grid, a.slices, a.probes
-    n_frames = a.steps + a.warmup
-    tr = synthetic_trajectory(n, nz, n_frames, seed=100 * rank)        # every rank has its own frames
+    npix = n * n
+    strong = a.scaling == "strong"
+    if strong:
+        # one trajectory for the whole job; step s = frames [s*F, (s+1)*F), each rank takes its contiguous part
+        F = a.frames_per_step
+        tr = synthetic_trajectory(n, nz, (a.steps + a.warmup) * F, seed=0)
+        lo, hi = D.shard_bounds(F, world, rank)
+        my_frames = [[s * F + f for f in range(lo, hi)] for s in range(a.steps + a.warmup)]
+    else:
+        tr = synthetic_trajectory(n, nz, a.steps + a.warmup, seed=100 * rank)        # every rank has its own frames
+        my_frames = [[s] for s in range(a.steps + a.warmup)]
+    n_local = sum(len(f) for f in my_frames)
     xs, ys, zs, lx, ly, lz = gridFromTrajectory(tr)
     assert (len(xs), len(ys), len(zs)) == (n, n, nz), (len(xs), len(ys), len(zs))
     side = int(round(P ** 0.5))
     pp = stem_probe_grid(side) if side * side == P else np.random.default_rng(0).random((P, 2)) * [lx, ly]
+
+    # N=1: hold T = 256 frame slots like the full C3 run (137 GB of spectra + 69 GB of intensities at 64 probes x 1024^2)
+    # when the device has the room, so that the TACAW leg runs the kernel a C3 run uses
+    slots = max(1, n_local)
+    tacaw_T = None
+    if world == 1 and not a.no_tacaw and n_local >= 2:
+        free_b, _ = torch.cuda.mem_get_info(local_rank)
+        want = max(TACAW_T, n_local)
+        if 12.0 * P * want * npix + 24e9 < free_b and n_local <= TACAW_T:
+            slots, tacaw_T = want, want
+        else:
+            tacaw_T = n_local
     eng = _native.Engine(n, n, nz, xs[1] - xs[0], ys[1] - ys[0], zs[1] - zs[0] if nz > 1 else 0.5, wavelength(100e3),
-                         interaction_sigma(100e3), n_probes=P, n_frames=n_frames, device=local_rank,
+                         interaction_sigma(100e3), n_probes=P, n_frames=slots, device=local_rank,
                          launch_timing=not a.no_launch_timing)
     eng.set_kirkland(loadKirkland())
     eng.set_slices(*slice_edges(zs))
     eng.set_probes(a.aperture, pp)
     Z = np.asarray(tr.atom_types, dtype=np.int32)
+    slot_of = {}
+    for fs in my_frames:
+        for f in fs:
+            slot_of[f] = len(slot_of)
 
-    def step(i):
-        eng.build_potential(tr.positions[i], Z, 2)
-        eng.propagate_frame(i)
+    def step(s):
+        for f in my_frames[s]:
+            eng.build_potential(tr.positions[f], Z, 2)
+            eng.propagate_frame(slot_of[f])
 
     def fence():
         eng.synchronize()
@@ -130,13 +230,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(a.warmup):
-        step(i)
+    for s in range(a.warmup):
+        step(s)
     fence()
     eng.reset_counters()
     t0 = time.perf_counter()
-    for i in range(a.warmup, n_frames):
-        step(i)
+    for s in range(a.warmup, a.warmup + a.steps):
+        step(s)
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -144,15 +244,69 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ctr = eng.counters()
+    frames_timed_local = sum(len(my_frames[s]) for s in range(a.warmup, a.warmup + a.steps))
+    frames_timed = a.steps * a.frames_per_step if strong else world * a.steps
 
-    tacaw_ms = None
-    if a.tacaw and n_frames >= 2:
+    dev = torch.device("cuda", local_rank)
+    wf_view = torch.as_tensor(_native.DeviceArray(eng.device_ptr(_native.BUF_WAVEFUNCTION), (P, slots, npix), "<c8", owner=eng),
+                              device=dev)
+
+    # ---- TACAW leg (N=1): time FFT over the resident frame slots; slots beyond the computed frames are filled with copies
+    tacaw = None
+    if tacaw_T is not None:
+        for j in range(n_local, tacaw_T):
+            wf_view[:, j].copy_(wf_view[:, j % n_local])
+        torch.cuda.synchronize()
+        before = eng.counters()["ms_tacaw"]
         eng.tacaw()
-        tacaw_ms = eng.counters()["ms_tacaw"]
+        ms = eng.counters()["ms_tacaw"] - before
+        tacaw = {"ms": round(ms, 3), "GBps": round(12.0 * P * tacaw_T * npix / (ms * 1e-3) / 1e9, 1), "frames": tacaw_T,
+                 "probes": P, "kernel": "four-step time FFT" if tacaw_T in (256, 1024) else "generic LDS kernel",
+                 "algorithmic_bytes": 12.0 * P * tacaw_T * npix, "frac_of_hbm_peak": round(12.0 * P * tacaw_T * npix / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                 "note": f"{n_local} computed frames, remaining slots filled with copies (timing is data-independent)"}
+
+    # ---- end-of-run exchanges of the sharded path (N>1), on the frames just computed
+    exchange = None
+    if world > 1 and not a.no_exchange:
+        def sync():
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+        def timed(fn):
+            sync()
+            t1 = time.perf_counter()
+            out = fn()
+            sync()
+            return out, (time.perf_counter() - t1) * 1e3
+
+        # equal shards of the timed frames; a total the ranks can hold: at most ~100 GB gathered on rank 0
+        per_rank = max(1, min(frames_timed_local, int(100e9 / (8.0 * P * npix * world))))
+        T_x = per_rank * world
+        first = n_local - frames_timed_local
+        local = wf_view[:, first:first + per_rank]
+        full, ms_gather = timed(lambda: D.gather_frames(local, T_x, dst=0))
+        del full
+        mine, ms_a2a = timed(lambda: D.frames_to_probes(local, T_x))
+        out = torch.empty(mine.shape, dtype=torch.float32, device=dev)
+
+        def do_tacaw():
+            if mine.shape[0] > 0 and T_x >= 2:
+                eng.tacaw(mine.data_ptr(), out.data_ptr(), mine.shape[0], T_x, npix)
+                eng.synchronize()
+        _, ms_t = timed(do_tacaw)
+        inten, ms_gp = timed(lambda: D.gather_probes(out, P, dst=0))
+        del inten, mine, out
+        shard_b = 8.0 * P * per_rank * npix
+        exchange = {"backend": backend, "frames": T_x, "frames_per_rank": per_rank,
+                    "gather_frames": round(ms_gather, 3), "frames_to_probes": round(ms_a2a, 3), "tacaw": round(ms_t, 3),
+                    "gather_probes": round(ms_gp, 3),
+                    "gather_frames_GBps_into_rank0": round(shard_b * (world - 1) / (ms_gather * 1e-3) / 1e9, 1),
+                    "frames_to_probes_GBps_out_per_rank": round(shard_b * (world - 1) / world / (ms_a2a * 1e-3) / 1e9, 1),
+                    "bytes_per_rank_shard": shard_b}
 
     if rank == 0:
-        npix = n * n
-        steps_total = world * a.steps * P * nz
+        steps_total = frames_timed * P * nz
         value = steps_total / dt
         # Slice-loop kernels.  Every launch streams the P wave functions of the frame once: 8 B read + 8 B write per
         # pixel = 16 B x nx x ny x P algorithmic bytes per launch.  The default one-pass loop needs ONE
@@ -161,48 +315,66 @@ def main():
         rows, cols = (ctr["row_launches"], ctr["ms_row"]), (ctr["col_launches"], ctr["ms_col"])
         name, (cnt, ms) = max((("pass_along_y", rows), ("pass_along_x", cols)), key=lambda kv: kv[1][1])
         bytes_per_launch = 16.0 * npix * P
-        passes_per_slice = (rows[0] + cols[0]) / float(a.steps * nz) if nz else 0.0
+        passes_per_slice = (rows[0] + cols[0]) / float(frames_timed_local * nz) if nz and frames_timed_local else 0.0
         roof = None
         if cnt:
             avg_s = ms * 1e-3 / cnt
             ach = bytes_per_launch / avg_s / 1e9
-            traffic = None
+            traffic, tsrc = None, None
             tpath = os.path.join(REPO, "profiles", "pmc_traffic_current.json")
             if os.path.exists(tpath):
                 tj = json.load(open(tpath))
                 if tj.get("grid") == n and tj.get("probes") == P and round(passes_per_slice) == tj.get("passes_per_slice"):
                     traffic = tj.get("hbm_bytes_per_launch")
+                    tsrc = "profiles/pmc_traffic_current.json (rocprofv3 --pmc passes of this command, committed; not re-measured in this run)"
+            loop_32 = (32.0 * npix * P * nz * frames_timed_local / (ctr["ms_slice_kernels"] * 1e-3) / 1e9) if ctr["ms_slice_kernels"] else None
             roof = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
                     "avg_launch_us": round(avg_s * 1e6, 2), "launches": int(cnt),
                     "algorithmic_bytes_per_launch": bytes_per_launch,
                     "passes_per_slice": round(passes_per_slice, 3),
                     "pass_along_y_GBps": round(bytes_per_launch * rows[0] / (rows[1] * 1e-3) / 1e9, 1) if rows[1] else None,
                     "pass_along_x_GBps": round(bytes_per_launch * cols[0] / (cols[1] * 1e-3) / 1e9, 1) if cols[1] else None,
-                    "slice_loop_GBps_on_32B_per_slice_step_basis":
-                        round(32.0 * npix * P * nz * a.steps / (ctr["ms_slice_kernels"] * 1e-3) / 1e9, 1)
-                        if ctr["ms_slice_kernels"] else None}
+                    "slice_loop_GBps_on_32B_per_slice_step_basis": round(loop_32, 1) if loop_32 else None,
+                    "frac_on_32B_basis": round(loop_32 / HBM_PEAK_GBS, 4) if loop_32 else None}
+        per_gpu = f"{a.steps} MD frames per GPU" if not strong else f"{a.steps} steps of {a.frames_per_step} MD frames sharded over the ranks"
         out = {
             "metric": "slice-steps/sec (probes x frames x slices / s), potential + slice loop + exit FFT",
             "value": round(value, 1), "unit": "slice-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": a.scaling,
             "vs_baseline": None, "dtype": "complex64 (f32)", "data": "synthetic",
-            "config": {"workload": f"{P}-probe STEM grid, {n}x{n} grid, {nz} slices, {a.steps} MD frames per GPU "
+            "config": {"workload": f"{P}-probe STEM grid, {n}x{n} grid, {nz} slices, {per_gpu} "
                                    f"(BASELINE configs[2] per-frame work), {tr.n_atoms} atoms, 30 mrad, 100 keV",
-                       "grid": n, "slices": nz, "probes": P, "frames_per_gpu": a.steps, "parallelism": f"frames x{world}"},
+                       "grid": n, "slices": nz, "probes": P, "frames_timed": frames_timed,
+                       "parallelism": f"frames x{world}", "backend": backend if world > 1 else None,
+                       "world_size_checked": world, "frame_slots": slots},
             "breakdown_ms_per_step": {"potential": round(ctr["ms_potential"] / a.steps, 3),
                                       "slice_loop_and_epilogue": round(ctr["ms_propagate"] / a.steps, 3)},
             "roofline": roof,
         }
-        if tacaw_ms is not None:
-            out["tacaw"] = {"ms": round(tacaw_ms, 3), "GBps": round(12.0 * P * n_frames * npix / (tacaw_ms * 1e-3) / 1e9, 1),
-                            "frames": n_frames}
+        if tacaw is not None:
+            out["tacaw"] = tacaw
+        if exchange is not None:
+            out["exchange_ms"] = exchange
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(n, nz, P, a.aperture, a.cpu_slices)
+            out["cpu_baseline"], V = cpu_baseline(n, nz, P, a.aperture, a.cpu_slices)
+            try:
+                out["cpu_baseline_allcores"] = cpu_baseline_allcores(n, nz, P, a.aperture, a.cpu_slices, V)
+            except Exception as exc:  # pragma: no cover  (scipy missing: the single-thread leg stands alone)
+                out["cpu_baseline_allcores"] = {"error": repr(exc)}
         print(json.dumps(out), flush=True)
+    del wf_view
     eng.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+def main():
+    a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(spawn_ranks(a.gpus))
+    run(a)
 
 
 if __name__ == "__main__":

@@ -186,7 +186,16 @@ def cache_dir_name(n_frames, n_atoms, box_matrix, atom_types, aperture, voltage_
     return "torch_" + hashlib.md5(str(sorted(params.items())).encode()).hexdigest()[:12]
 
 
-def propagate(probes: np.ndarray, V: np.ndarray, xs, ys, zs, eV) -> np.ndarray:
+def _fft_pair(workers):
+    """(fft2, ifft2) over the last two axes: numpy.fft (the reference's NumPy path) or, for the all-core CPU baseline
+    of bench.py, scipy.fft with `workers` threads (same pocketfft kernels, batched over the probe axis)."""
+    if not workers:
+        return (lambda a: np.fft.fft2(a, axes=(-2, -1))), (lambda a: np.fft.ifft2(a, axes=(-2, -1)))
+    import scipy.fft as sfft
+    return (lambda a: sfft.fft2(a, axes=(-2, -1), workers=workers)), (lambda a: sfft.ifft2(a, axes=(-2, -1), workers=workers))
+
+
+def propagate(probes: np.ndarray, V: np.ndarray, xs, ys, zs, eV, workers=None) -> np.ndarray:
     """Multislice loop; reference: multislice.py:254-299.
 
     probes (P,nx,ny) -> exit waves (P,nx,ny): nz transmissions, nz-1 Fresnel propagations.
@@ -202,16 +211,17 @@ def propagate(probes: np.ndarray, V: np.ndarray, xs, ys, zs, eV) -> np.ndarray:
     kxs = np.fft.fftfreq(nx, d=xs[1] - xs[0])
     kys = np.fft.fftfreq(ny, d=ys[1] - ys[0])
     prop = np.exp(-1j * np.pi * lam * dz * (kxs[:, None] ** 2 + kys[None, :] ** 2))
+    fft2, ifft2 = _fft_pair(workers)
     for z in range(nz):
         psi = np.exp(1j * sig * V[:, :, z])[None] * psi
         if z < nz - 1:
-            psi = np.fft.ifft2(prop[None] * np.fft.fft2(psi, axes=(-2, -1)), axes=(-2, -1))
+            psi = ifft2(prop[None] * fft2(psi))
     return psi
 
 
-def diffraction(exit_waves: np.ndarray) -> np.ndarray:
+def diffraction(exit_waves: np.ndarray, workers=None) -> np.ndarray:
     """fftshift(fft2(exit)) over the last two axes; reference: calculators.py:285-287."""
-    return np.fft.fftshift(np.fft.fft2(exit_waves, axes=(-2, -1)), axes=(-2, -1))
+    return np.fft.fftshift(_fft_pair(workers)[0](exit_waves), axes=(-2, -1))
 
 
 def run_frames(box_matrix, positions_t, atomic_numbers, aperture, eV, probe_positions=None,

@@ -2,16 +2,27 @@
 
 The reference has no distributed path.  Every (frame, probe) exit wave is
 independent (calculators.py:172-186), so MD frames are sharded in contiguous blocks over the ranks
-and nothing is exchanged while frames are propagated.  Two collectives exist, both at the end:
+and nothing is exchanged while frames are propagated.  Two exchanges exist, both at the end:
 
   * gather_frames      -- assemble (P, T, nx, ny) from the (P, T_r, nx, ny) shards (WFData);
   * frames_to_probes   -- all-to-all re-shard from frame-sharded to probe-sharded so every rank
                           holds complete time series for its probes and can run the TACAW time FFT
-                          locally (tacaw_data.py:94-96 couples all frames of one probe/pixel).
+                          locally (tacaw_data.py:94-96 couples all frames of one probe/pixel),
+                          followed by gather_probes of the intensities.
+
+Every exchange receives STRAIGHT INTO THE DESTINATION: the result array is allocated once in its final
+(P, T, ...) layout and each peer's contribution -- for one probe a contiguous run of T_r frames -- is
+received into its slice by a point-to-point operation; senders send slices of their shard in place.
+All operations of one exchange are issued as ONE group (torch.distributed.batch_isend_irecv =
+ncclGroupStart/End on RCCL), so every pair of GPUs uses its own xGMI link concurrently.  No padded
+copies, no list of per-rank buffers, no concatenation: the only allocation is the result itself
+(`alloc_log` records it; tests/test_distributed.py asserts it).  Footprint on rank 0 of BASELINE
+config C4 (64 probes x 256 frames x 1024^2 on 8 GPUs, gather="rank0", output="device"): 137.4 GB result
++ 17.2 GB own shard (the engine's buffer) = 154.6 GB of 288 GB; TACAW: 17.2 GB probe shard + 8.6 GB
+intensities per rank, 68.7 GB gathered on rank 0.
 
 Backend: "nccl" (RCCL over xGMI) on GPUs; the same code runs under "gloo" on CPU tensors, which is
-how tests/test_distributed.py covers it without a GPU.  xGMI is point-to-point, so the all-to-all
-(each pair its own link) is the natural pattern; no ring all-reduce is used anywhere.
+how tests/test_distributed.py covers it without a GPU.  No ring all-reduce is used anywhere.
 """
 from __future__ import annotations
 
@@ -23,6 +34,15 @@ try:
 except ImportError:  # pragma: no cover
     torch = None
     dist = None
+
+# bytes allocated by the exchanges since the last reset (test hook: the gathers must allocate the result and nothing else)
+alloc_log: List[int] = []
+
+
+def _alloc(shape, dtype, device):
+    t = torch.empty(tuple(int(s) for s in shape), dtype=dtype, device=device)
+    alloc_log.append(t.numel() * t.element_size())
+    return t
 
 
 def rank_world():
@@ -44,21 +64,36 @@ def shard_frames(n_frames: int, world: int, rank: int) -> List[int]:
 
 
 def _as_real(t):
-    """Collectives move real views (gloo has no complex support; RCCL moves bytes either way).  Under gloo (CPU
-    rehearsal of the multi-process path, possibly with device-resident data) tensors are staged through the host."""
-    t = torch.view_as_real(t) if t.is_complex() else t
+    """Exchanges move real views (gloo has no complex support; RCCL moves bytes either way).  Under gloo with
+    device-resident data (CPU rehearsal of the multi-process path on a GPU box) the shard is staged through the host."""
+    cplx = t.is_complex()
+    t = torch.view_as_real(t) if cplx else t
     if dist.get_backend() == "gloo" and t.is_cuda:
-        return t.cpu(), True, t.device
-    return t, True, None
+        return t.cpu(), cplx, t.device
+    return t, cplx, None
 
 
-def _restore(t, meta):
+def _restore(t, cplx, dev):
     if t is None:
         return None
-    was_complex, dev = meta
     if dev is not None:
         t = t.to(dev)
-    return torch.view_as_complex(t.contiguous()) if was_complex else t
+    return torch.view_as_complex(t) if cplx else t
+
+
+def _chunk(t):
+    """a view usable as a point-to-point operand (inner dimensions dense); copies only if the caller's shard is strided"""
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _exchange(sends, recvs):
+    """sends: [(tensor, peer)], recvs: [(tensor, peer)] -- one grouped launch, every pair its own link"""
+    ops = [dist.P2POp(dist.irecv, t, peer) for t, peer in recvs if t.numel()]
+    ops += [dist.P2POp(dist.isend, t, peer) for t, peer in sends if t.numel()]
+    if not ops:
+        return
+    for req in dist.batch_isend_irecv(ops):
+        req.wait()
 
 
 def gather_frames(local, n_frames: int, dst: Optional[int] = 0):
@@ -66,29 +101,25 @@ def gather_frames(local, n_frames: int, dst: Optional[int] = 0):
     rank, world = rank_world()
     if world == 1:
         return local
-    cplx = local.is_complex()
-    local, _, dev = _as_real(local)
-    return _restore(_gather_frames_real(local, n_frames, dst, rank, world), (cplx, dev))
-
-
-def _gather_frames_real(local, n_frames, dst, rank, world):
+    local, cplx, dev = _as_real(local)
     P = local.shape[0]
-    rest = tuple(local.shape[2:])
-    counts = [shard_bounds(n_frames, world, r)[1] - shard_bounds(n_frames, world, r)[0] for r in range(world)]
-    tmax = max(counts)
-    # equal-size buffers (frame axis first so that shards are contiguous), padded to the largest shard
-    send = torch.zeros((tmax, P) + rest, dtype=local.dtype, device=local.device)
-    send[: local.shape[1]] = local.transpose(0, 1)
-    if dst is None:
-        bufs = [torch.empty_like(send) for _ in range(world)]
-        dist.all_gather(bufs, send)
-    else:
-        bufs = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
-        dist.gather(send, bufs, dst=dst)
-        if rank != dst:
-            return None
-    full = torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)       # (T, P, ...)
-    return full.transpose(0, 1).contiguous()
+    bounds = [shard_bounds(n_frames, world, r) for r in range(world)]
+    receivers = range(world) if dst is None else [dst]
+    full = None
+    sends, recvs = [], []
+    if rank in receivers:
+        full = _alloc((P, n_frames) + tuple(local.shape[2:]), local.dtype, local.device)
+        lo, hi = bounds[rank]
+        full[:, lo:hi].copy_(local)
+        for r in range(world):
+            if r != rank:
+                lo, hi = bounds[r]
+                recvs += [(full[p, lo:hi], r) for p in range(P)]
+    for d in receivers:
+        if d != rank:
+            sends += [(_chunk(local[p]), d) for p in range(P)]
+    _exchange(sends, recvs)
+    return _restore(full, cplx, dev)
 
 
 def frames_to_probes(local, n_frames: int):
@@ -96,59 +127,39 @@ def frames_to_probes(local, n_frames: int):
     rank, world = rank_world()
     if world == 1:
         return local
-    cplx = local.is_complex()
-    local, _, dev = _as_real(local)
-    return _restore(_frames_to_probes_real(local, n_frames, rank, world), (cplx, dev))
-
-
-def _frames_to_probes_real(local, n_frames, rank, world):
+    local, cplx, dev = _as_real(local)
     P = local.shape[0]
-    rest = tuple(local.shape[2:])
-    tcounts = [shard_bounds(n_frames, world, r)[1] - shard_bounds(n_frames, world, r)[0] for r in range(world)]
+    tb = [shard_bounds(n_frames, world, r) for r in range(world)]
     pb = [shard_bounds(P, world, r) for r in range(world)]
-    my_p = pb[rank][1] - pb[rank][0]
-    send = [local[pb[r][0]:pb[r][1]].contiguous() for r in range(world)]          # to rank r: its probes, my frames
-    recv = [torch.empty((my_p, tcounts[r]) + rest, dtype=local.dtype, device=local.device) for r in range(world)]
-    dist.all_to_all(recv, send) if dist.get_backend() != "gloo" else _all_to_all_p2p(recv, send, rank, world)
-    return torch.cat(recv, dim=1).contiguous()                                      # (P_r, T, ...)
-
-
-def _all_to_all_p2p(recv, send, rank, world):
-    """gloo has no all_to_all for uneven lists on every build: pairwise isend/irecv instead."""
-    recv[rank].copy_(send[rank])
-    reqs = []
+    p0, p1 = pb[rank]
+    mine = _alloc((p1 - p0, n_frames) + tuple(local.shape[2:]), local.dtype, local.device)
+    lo, hi = tb[rank]
+    mine[:, lo:hi].copy_(local[p0:p1])
+    sends, recvs = [], []
     for r in range(world):
         if r == rank:
             continue
-        if send[r].numel():
-            reqs.append(dist.isend(send[r], dst=r))
-        if recv[r].numel():
-            reqs.append(dist.irecv(recv[r], src=r))
-    for q in reqs:
-        q.wait()
+        lo, hi = tb[r]
+        recvs += [(mine[p - p0, lo:hi], r) for p in range(p0, p1)]                  # my probes, rank r's frames
+        sends += [(_chunk(local[p]), r) for p in range(pb[r][0], pb[r][1])]         # rank r's probes, my frames
+    _exchange(sends, recvs)
+    return _restore(mine, cplx, dev)
 
 
 def gather_probes(local, n_probes: int, dst: Optional[int] = 0):
-    """(P_r, ...) probe shards -> (P, ...) on dst (None: everywhere)."""
+    """(P_r, ...) probe shards -> (P, ...) on dst (None: everywhere).  Returns None elsewhere."""
     rank, world = rank_world()
     if world == 1:
         return local
-    cplx = local.is_complex()
-    local, _, dev = _as_real(local)
-    return _restore(_gather_probes_real(local, n_probes, dst, rank, world), (cplx, dev))
-
-
-def _gather_probes_real(local, n_probes, dst, rank, world):
-    counts = [shard_bounds(n_probes, world, r)[1] - shard_bounds(n_probes, world, r)[0] for r in range(world)]
-    pmax = max(counts)
-    send = torch.zeros((pmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    send[: local.shape[0]] = local
-    if dst is None:
-        bufs = [torch.empty_like(send) for _ in range(world)]
-        dist.all_gather(bufs, send)
-    else:
-        bufs = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
-        dist.gather(send, bufs, dst=dst)
-        if rank != dst:
-            return None
-    return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
+    local, cplx, dev = _as_real(local)
+    pb = [shard_bounds(n_probes, world, r) for r in range(world)]
+    receivers = range(world) if dst is None else [dst]
+    full = None
+    sends, recvs = [], []
+    if rank in receivers:
+        full = _alloc((n_probes,) + tuple(local.shape[1:]), local.dtype, local.device)
+        full[pb[rank][0]:pb[rank][1]].copy_(local)
+        recvs = [(full[pb[r][0]:pb[r][1]], r) for r in range(world) if r != rank]
+    sends = [(_chunk(local), d) for d in receivers if d != rank]
+    _exchange(sends, recvs)
+    return _restore(full, cplx, dev)

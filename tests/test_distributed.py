@@ -29,19 +29,32 @@ def _worker(rank, world, port, P, T, npix, q):
         frames = D.shard_frames(T, world, rank)
         local = full[:, frames[0]:frames[-1] + 1].contiguous() if frames else full[:, :0]
         ok = True
+        full_bytes = full.numel() * full.element_size()
+        D.alloc_log.clear()
         g = D.gather_frames(local, T, dst=0)
         ok &= (g is None) if rank != 0 else bool(torch.equal(g, full))
+        # the exchange allocates the result in its final layout on the receiver and nothing else anywhere
+        ok &= D.alloc_log == ([full_bytes] if rank == 0 else [])
+        D.alloc_log.clear()
         ga = D.gather_frames(local, T, dst=None)
-        ok &= bool(torch.equal(ga, full))
+        ok &= bool(torch.equal(ga, full)) and D.alloc_log == [full_bytes]
+        # a shard that is a strided view (the engine's buffer holds more frame slots than the shard uses)
+        padded = torch.zeros((P, local.shape[1] + 2, npix), dtype=local.dtype)
+        padded[:, :local.shape[1]] = local
+        ok &= bool(torch.equal(D.gather_frames(padded[:, :local.shape[1]], T, dst=None), full))
+        D.alloc_log.clear()
         mine = D.frames_to_probes(local, T)
         lo, hi = D.shard_bounds(P, world, rank)
         ok &= bool(torch.equal(mine, full[lo:hi]))
+        ok &= D.alloc_log == [(hi - lo) * T * npix * 8]
         # TACAW on the probe shard == TACAW on the full array restricted to those probes
         if mine.shape[0]:
             inten = (torch.fft.fftshift(torch.fft.fft(mine - mine.mean(dim=1, keepdim=True), dim=1), dim=1).abs() ** 2)
         else:       # a rank can own zero probes (P < world); MKL rejects empty FFTs
             inten = torch.zeros(mine.shape, dtype=torch.float32)
+        D.alloc_log.clear()
         gi = D.gather_probes(inten, P, dst=0)
+        ok &= D.alloc_log == ([P * T * npix * 4] if rank == 0 else [])
         if rank == 0:
             want = (torch.fft.fftshift(torch.fft.fft(full - full.mean(dim=1, keepdim=True), dim=1), dim=1).abs() ** 2)
             ok &= bool(torch.allclose(gi, want, rtol=1e-5, atol=1e-5))
@@ -77,3 +90,19 @@ def test_shard_bounds_cover():
             assert cover == list(range(n))
             sizes = [shard_bounds(n, w, r)[1] - shard_bounds(n, w, r)[0] for r in range(w)]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_bench_starts_its_own_ranks_and_relays_a_failure():
+    """`python bench.py --gpus 2` without a launcher starts two rank processes itself (fresh interpreters, before
+    anything touches a GPU).  Here there is no GPU, so both ranks fail: the parent must return their failure
+    instead of hanging in the rendezvous, and must not print a result line."""
+    import subprocess
+    import sys
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the run itself is covered by the -m gpu suite")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--grid", "64", "--slices", "2",
+                        "--probes", "1", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert '"metric"' not in r.stdout

@@ -31,9 +31,16 @@ def _worker(rank, world, port, q):
         tr = synthetic_trajectory(256, 5, 5, density=0.05, seed=41)          # 5 frames -> shards of 3 and 2
         pp = [(12.0, 12.0), (3.0, 20.0), (17.5, 6.25)]
         out = {}
-        calc = ps.MultisliceCalculator(device=0, progress=False, gather="rank0")
+        calc = ps.MultisliceCalculator(device=0, progress=False, gather="rank0", output="device")
         calc.setup(tr, aperture=30.0, voltage_eV=100e3, probe_positions=pp)
+        torch.cuda.reset_peak_memory_stats(0)
+        base = torch.cuda.memory_allocated(0)
         wf = calc.run()
+        # torch-side device memory of the gather: the (P,T,nx,ny) result on rank 0 and nothing else (the shard itself
+        # lives in the engine's own buffer); the old implementation held a padded copy, per-rank buffers and a cat
+        full_bytes, shard_bytes = 3 * 5 * 256 * 256 * 8, 3 * 3 * 256 * 256 * 8
+        peak = torch.cuda.max_memory_allocated(0) - base
+        assert peak <= (full_bytes if rank == 0 else 0) + shard_bytes + (1 << 20), (rank, peak)
         if rank == 0:
             out["wf"] = wf.wavefunction_data.cpu().numpy()
         else:
@@ -90,3 +97,26 @@ def test_two_ranks_frame_sharding_gather_and_tacaw():
     assert np.linalg.norm(res[0]["intensity_win"] - win) / np.linalg.norm(win) < 2e-4
     assert rel_l2(res[0]["spectrum_win"], win.sum(axis=(2, 3)).mean(axis=0)) < 2e-4
     assert rel_l2(res[0]["diffraction_win"], win[1].sum(axis=0)) < 2e-4
+
+
+def test_bench_two_ranks_gloo_rehearsal(tmp_path):
+    """`python bench.py --gpus 2` starts its own two ranks (both on this one GPU, gloo instead of RCCL), reports
+    n_gpus = 2 and times the end-of-run exchanges."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["MSL_BENCH_BACKEND"] = "gloo"
+    for extra in ([], ["--scaling", "strong", "--frames-per-step", "4"]):
+        r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--grid", "256", "--slices", "6",
+                            "--probes", "4", "--steps", "2", "--warmup", "1"] + extra, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(line) == 1, r.stdout
+        j = json.loads(line[0])
+        assert j["n_gpus"] == 2 and j["config"]["world_size_checked"] == 2 and j["scaling"] == ("strong" if extra else "weak")
+        ex = j["exchange_ms"]
+        assert ex["backend"] == "gloo" and ex["gather_frames"] > 0 and ex["frames_to_probes"] > 0 and ex["gather_probes"] > 0
+        assert j["config"]["frames_timed"] == (8 if extra else 4)
+        assert j["value"] > 0 and j["roofline"]["launches"] > 0

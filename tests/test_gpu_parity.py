@@ -449,17 +449,74 @@ def test_engine_uploaded_potential_changed_beam_onepass(ps, orc, nx, ny, nz):
     eng.close()
 
 
-@pytest.mark.parametrize("n,nz", [(256, 400), (512, 400), (2048, 40)])
-def test_deep_stack_error_growth_stays_inside_the_contract(ps, orc, n, nz):
-    """BASELINE C5 has 400 slices: the fp32 rounding of 4 x nz line transforms per pixel must stay below the 1e-4
-    contract (measured 5e-5 at 400 slices; tools/deep_stack_parity.py runs the 1024^2 and 2048^2 x 100 cases).
-    A 40-slice 2048^2 stack also exercises every pass type of the 2048-point kernel with strong potentials."""
+def _deep():
     import importlib.util
-    import os
     spec = importlib.util.spec_from_file_location("deep", os.path.join(os.path.dirname(__file__), "..", "tools", "deep_stack_parity.py"))
     deep = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(deep)
-    assert deep.case(n, nz) < WAVE_TOL
+    return deep
+
+
+@pytest.mark.parametrize("n,nz", [(256, 400), (512, 400), (1024, 400), (2048, 40), (2048, 100)])
+def test_deep_stack_error_growth_stays_inside_the_contract(ps, orc, n, nz):
+    """BASELINE C5 has 400 slices: the fp32 rounding of 4 x nz line transforms per pixel must stay below the 1e-4
+    contract (measured 5e-5 at 400 slices).  1024^2 x 400 runs C3's grid at twice its depth; the 2048^2 stacks
+    exercise every pass type of the 2048-point kernel with strong potentials."""
+    assert _deep().case(n, nz) < WAVE_TOL
+
+
+def test_config_c5_grid_2048_400_slices(ps, orc):
+    """BASELINE C5's grid and depth (2048^2, 400 slices) for one probe against the oracle slice loop (8 distinct
+    potential slices cycled along z keep the synthesis of the input short; the loop still runs 400 different passes)."""
+    assert _deep().case(2048, 400, distinct=8) < WAVE_TOL
+
+
+def test_config_c3_64_probes_1024_200_slices_vs_oracle(ps, orc):
+    """BASELINE C3's per-frame work exactly as bench.py runs it -- 1024^2 grid, 200 slices at full atom density,
+    the 8 x 8 STEM probe grid of 03_manyprobes.py:16-28, so the launcher picks chunks of 16 probes per work item and the
+    transposing kernel reuses t_k from registers across a chunk -- checked against the oracle for probes at the start
+    and end of chunks and in the middle of one (the oracle costs ~8 s per probe here)."""
+    from pyslice_amd.synthetic import synthetic_trajectory, stem_probe_grid
+    n, nz = 1024, 200
+    tr = synthetic_trajectory(n, nz, 1, seed=0)
+    pp = [tuple(p) for p in stem_probe_grid(8)]
+    calc = ps.MultisliceCalculator(progress=False, dtype="complex64")
+    calc.setup(tr, aperture=30.0, voltage_eV=100e3, probe_positions=pp)
+    got = npy(calc.run().wavefunction_data)[:, 0, :, :, 0]
+    assert got.shape == (64, n, n)
+    check = [0, 15, 16, 37, 63]
+    want = orc.run_frames(tr.box_matrix, tr.positions, tr.atom_types, 30.0, 100e3, [pp[i] for i in check])["wavefunction_data"]
+    for j, i in enumerate(check):
+        assert rel_l2(got[i], want[j, 0, :, :, 0]) < WAVE_TOL, i
+        assert ref_residual(got[i], want[j, 0, :, :, 0]) < RESID_TOL, i
+    # every probe: norm conserved, and no two probes share a pattern
+    k = np.fft.fftfreq(n, d=calc.dx)
+    count = int((np.sqrt(k[:, None] ** 2 + k[None, :] ** 2) < 30e-3 / ps.wavelength(100e3)).sum())
+    norms = (np.abs(got.astype(np.complex128)) ** 2).sum(axis=(1, 2))
+    assert np.allclose(norms, count, rtol=2e-4)
+    assert rel_l2(got[1], got[0]) > 1e-3 and rel_l2(got[62], got[63]) > 1e-3
+
+
+def test_tacaw_1024_grid_k_window_256_frames_vs_oracle(ps, orc):
+    """TACAW on C3's grid and frame count: 1024^2, T = 256 frames (four-step time-FFT kernel), a 64 x 64 k-window so that
+    the resident result stays small; against the oracle's time FFT of the oracle's own exit-wave spectra, cropped."""
+    from pyslice_amd.synthetic import synthetic_trajectory
+    n, nz, T = 1024, 2, 256
+    tr = synthetic_trajectory(n, nz, T, density=0.02, seed=5)
+    pp = [(40.0, 61.0)]
+    calc = ps.MultisliceCalculator(progress=False, k_window=(64, 64))
+    calc.setup(tr, aperture=30.0, voltage_eV=100e3, probe_positions=pp)
+    wf = calc.run()
+    tac = ps.TACAWData(wf)
+    want = orc.run_frames(tr.box_matrix, tr.positions, tr.atom_types, 30.0, 100e3, pp)["wavefunction_data"]
+    win = want[:, :, n // 2 - 32:n // 2 + 32, n // 2 - 32:n // 2 + 32]
+    assert rel_l2(npy(wf.wavefunction_data), win) < WAVE_TOL
+    f, inten = orc.tacaw(win, wf.time)
+    assert np.allclose(tac.frequencies, f)
+    got = npy(tac.intensity)
+    assert got.shape == (1, T, 64, 64)
+    assert rel_l2(got, inten) < TACAW_TOL
+    assert rel_l2(tac.spectrum(0), inten[0].sum(axis=(1, 2))) < TACAW_TOL
 
 
 def test_randomised_shape_sweep(ps, orc):

@@ -7,7 +7,8 @@ sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__im
 from oracle import multislice_oracle as orc
 from pyslice_amd import _native
 
-def case(n, nz, seed=0):
+def case(n, nz, seed=0, distinct=None):
+    """distinct: number of different potential slices to synthesise (cycled along z); None = all nz different"""
     rng = np.random.default_rng(seed)
     dx = 0.1; dz = 0.5
     xs = np.arange(n) * dx; zs = np.arange(nz) * dz
@@ -15,11 +16,14 @@ def case(n, nz, seed=0):
     V = np.zeros((n, n, nz), dtype=np.float32)
     k = np.fft.fftfreq(n, dx)
     g = np.exp(-(np.pi * 0.35) ** 2 * (k[:, None] ** 2 + k[None, :] ** 2))
-    for z in range(nz):
+    nd = nz if distinct is None else min(nz, distinct)
+    for z in range(nd):
         img = np.zeros((n, n))
         idx = rng.integers(0, n, size=(max(4, n * n // 2000), 2))
         img[idx[:, 0], idx[:, 1]] = 2500.0
         V[:, :, z] = np.fft.ifft2(np.fft.fft2(img) * g).real.astype(np.float32)
+    for z in range(nd, nz):
+        V[:, :, z] = V[:, :, z % nd]
     eng = _native.Engine(n, n, nz, dx, dx, dz, orc.wavelength(100e3), orc.interaction_sigma(100e3), n_probes=1, n_frames=0)
     eng.upload_potential(np.moveaxis(V, 2, 0))
     eng.set_probes(30.0, [(xs[-1] / 2, xs[-1] / 2)])
