@@ -125,16 +125,34 @@ def cpu_baseline(grid, nz_full, probes, aperture, nz_sample):
             "host_cpus": os.cpu_count()}, V
 
 
+def usable_cores():
+    """Cores this process may really use: the cgroup CPU quota when there is one (the GPU box gives one GPU's share of
+    the host, 16 of 256 -- running 256 threads on it is slower than one), else the affinity mask; MSL_BENCH_CPU_WORKERS
+    overrides."""
+    if os.environ.get("MSL_BENCH_CPU_WORKERS"):
+        return max(1, int(os.environ["MSL_BENCH_CPU_WORKERS"]))
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return min(n, 16) if n > 64 else n          # no quota visible on a 256-thread host: the documented share of one GPU
+
+
 def cpu_baseline_allcores(grid, nz_full, probes, aperture, nz_sample, V):
     """The same oracle with every core this process may use: scipy.fft (pocketfft, `workers` threads, the measured probes
     batched in one call) for the slice loop, threaded BLAS for the structure-factor products of the potential
     (SURVEY 8d's second CPU leg).  Bounded sample: `nz_sample` slices, 4 probes measured, extrapolated to `probes`."""
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    from threadpoolctl import threadpool_limits
+    cores = usable_cores()
     orc, tr, (xs, ys, zs, lx, ly, lz) = _sample(grid, nz_sample)
     pm = min(4, probes)
-    t0 = time.perf_counter()
-    V2 = orc.potential(xs, ys, zs, tr.positions[0], tr.atom_types)            # BLAS threads: library default = all cores
-    t_pot = time.perf_counter() - t0
+    with threadpool_limits(limits=cores):
+        t0 = time.perf_counter()
+        V2 = orc.potential(xs, ys, zs, tr.positions[0], tr.atom_types)        # structure-factor products on `cores` BLAS threads
+        t_pot = time.perf_counter() - t0
     pos = [(lx * (i + 1) / (pm + 1), ly / 2) for i in range(pm)]
     pr = orc.batched_probes(orc.probe_array(xs, ys, aperture, 100e3), xs, ys, pos)
     t0 = time.perf_counter()

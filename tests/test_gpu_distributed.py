@@ -33,6 +33,8 @@ def _worker(rank, world, port, q):
         out = {}
         calc = ps.MultisliceCalculator(device=0, progress=False, gather="rank0", output="device")
         calc.setup(tr, aperture=30.0, voltage_eV=100e3, probe_positions=pp)
+        torch.cuda.set_device(0)
+        torch.zeros(1, device="cuda")                      # create the context before the allocator statistics are reset
         torch.cuda.reset_peak_memory_stats(0)
         base = torch.cuda.memory_allocated(0)
         wf = calc.run()
@@ -79,7 +81,14 @@ def test_two_ranks_frame_sharding_gather_and_tacaw():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=300) for _ in range(2))
+    import queue
+    res = {}
+    while len(res) < 2:
+        try:
+            r, out = q.get(timeout=2)
+            res[r] = out
+        except queue.Empty:        # a rank that died will never report: fail now instead of waiting out the timeout
+            assert all(p.exitcode in (None, 0) for p in procs), [p.exitcode for p in procs]
     for p in procs:
         p.join(timeout=60)
     assert all(p.exitcode == 0 for p in procs)
