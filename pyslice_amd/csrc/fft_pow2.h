@@ -108,6 +108,42 @@ __device__ __forceinline__ void fourstep_c64(float2 (&v)[R], float2* scratch, co
     fft_regs<R, INV>(v);
 }
 
+// The two halves of a four-step transform (diagnostic build of the transposing pass: phase timing per half):
+// head = first register FFT and the inter-FFT twiddles (no scratch access), tail = lane<->register transpose through the
+// scratch and the second register FFT.
+template <int R, bool INV, int CH = 8>
+__device__ __forceinline__ void fourstep_head(float2 (&v)[R], const float2* tw, int ln) {
+    fft_regs<R, INV>(v);
+    mul_table<R, 1, INV, R, CH>(v, tw, ln);
+}
+template <int R, bool INV, bool C64>
+__device__ __forceinline__ void fourstep_tail(float2 (&v)[R], float2* scratch2, int ln) {
+    static_assert(64 % R == 0, "an R-lane group must lie inside one wave: the scratch is ordered per wave only");
+    if constexpr (C64) {
+#pragma unroll
+        for (int k1 = 0; k1 < R; ++k1) scratch2[k1 * (R + 1) + ln] = v[k1];
+        wave_lds_fence();
+#pragma unroll
+        for (int n2 = 0; n2 < R; ++n2) v[n2] = scratch2[ln * (R + 1) + n2];
+        wave_lds_fence();
+    } else {
+        float* scratch = reinterpret_cast<float*>(scratch2);
+#pragma unroll
+        for (int k1 = 0; k1 < R; ++k1) scratch[k1 * (R + 1) + ln] = v[k1].x;
+        wave_lds_fence();
+#pragma unroll
+        for (int n2 = 0; n2 < R; ++n2) v[n2].x = scratch[ln * (R + 1) + n2];
+        wave_lds_fence();
+#pragma unroll
+        for (int k1 = 0; k1 < R; ++k1) scratch[k1 * (R + 1) + ln] = v[k1].y;
+        wave_lds_fence();
+#pragma unroll
+        for (int n2 = 0; n2 < R; ++n2) v[n2].y = scratch[ln * (R + 1) + n2];
+        wave_lds_fence();
+    }
+    fft_regs<R, INV>(v);
+}
+
 struct RowJob {
     float2* psi;            // (P, nx, pitch) working waves, rows contiguous
     const float2* trans;    // t_z (nx, ny) of this slice, or null
@@ -502,12 +538,29 @@ struct RowTJob {
     const float2* tw2;      // N = 2R^2 only: W_N^m, m < R^2
     long long in_image_stride, out_image_stride;
     int in_pitch, out_pitch, n_lines, n_images, flags, pchunk;
+#ifdef MSL_STAMPS
+    unsigned* stamps;       // tools/rowt_timeline.hip: per wave, cycles spent in each of MSL_NSTAMP phases of the iteration
+#endif
 };
+
+// Phase timing for tools/rowt_timeline.hip (diagnostic build only: -DMSL_STAMPS; s_memtime costs an SMEM round trip and
+// drains the wave's LDS queue at every stamp, so the stamped kernel runs slower than the shipped one)
+#ifdef MSL_STAMPS
+#define MSL_NSTAMP 24
+#define MSL_STAMP(id) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+                           acc_[id] += (unsigned)(now_ - last_); last_ = now_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define MSL_STAMP(id)
+#endif
 
 template <int R, int LINES, bool C64>
 __global__ void __launch_bounds__(LINES * R) rowT_pass_kernel(RowTJob job) {
     constexpr int N = R * R;
+#ifdef MSL_STAMPS
+    constexpr int TCH = 8;                              // the diagnostic build needs the registers for its counters
+#else
     constexpr int TCH = (R == 32) ? 16 : 8;             // table-multiply chunk (see mul_table)
+#endif
     constexpr int NT = LINES * R;
     constexpr int CS = R * (R + 1) + 1;
     constexpr int TPS = LINES / 2;                    // threads (16 B = 2 lines each) per output segment of LINES*8 bytes
@@ -543,10 +596,19 @@ __global__ void __launch_bounds__(LINES * R) rowT_pass_kernel(RowTJob job) {
         for (int j = 0; j < R; ++j) vn[j] = r[j * R + ln];
     }
     float2 tv[R];
+#ifdef MSL_STAMPS
+    unsigned acc_[MSL_NSTAMP] = {0};
+    unsigned long long last_ = __builtin_amdgcn_s_memtime();
+#endif
     while (item < n_items) {
+        MSL_STAMP(0);
         float2 v[R];
 #pragma unroll
         for (int j = 0; j < R; ++j) v[j] = vn[j];
+#ifdef MSL_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        MSL_STAMP(1);
         const int p = pc * PC + k;
         const int cur_lb = lb;
         if (k == 0) {
@@ -579,6 +641,27 @@ __global__ void __launch_bounds__(LINES * R) rowT_pass_kernel(RowTJob job) {
             }
         };
 #define MSL_IC(x) std::integral_constant<int, (x)>{}              // quarter boundaries in 32nds of the line's registers
+        MSL_STAMP(2);                                                   // t_k load (k == 0) + cursor
+#ifdef MSL_STAMPS
+        // diagnostic build: the four transforms in halves (head = register FFT + twiddles, tail = transpose + register FFT)
+        fourstep_head<R, false, TCH>(v, tw, ln); MSL_STAMP(3);
+        fourstep_tail<R, false, C64>(v, myrow, ln); MSL_STAMP(4);
+        prefetch_part(MSL_IC(0), MSL_IC(8)); MSL_STAMP(5);
+        mul_table<R, 0, false, R, TCH>(v, pl, ln); MSL_STAMP(6);
+        fourstep_head<R, true, TCH>(v, tw, ln); MSL_STAMP(7);
+        fourstep_tail<R, true, C64>(v, myrow, ln); MSL_STAMP(8);
+        prefetch_part(MSL_IC(8), MSL_IC(16)); MSL_STAMP(9);
+#pragma unroll
+        for (int j = 0; j < R; ++j) v[j] = cmulf(v[j], tv[j]);
+        MSL_STAMP(10);
+        fourstep_head<R, false, TCH>(v, tw, ln); MSL_STAMP(11);
+        fourstep_tail<R, false, C64>(v, myrow, ln); MSL_STAMP(12);
+        prefetch_part(MSL_IC(16), MSL_IC(24)); MSL_STAMP(13);
+        mul_table<R, 0, false, R, TCH>(v, pl, ln); MSL_STAMP(14);
+        fourstep_head<R, true, TCH>(v, tw, ln); MSL_STAMP(15);
+        fourstep_tail<R, true, C64>(v, myrow, ln); MSL_STAMP(16);
+        prefetch_part(MSL_IC(24), MSL_IC(32)); MSL_STAMP(17);
+#else
         if (job.flags & P2_PRE_A) {
             if constexpr (C64) fourstep_c64<R, false, TCH>(v, myrow, tw, ln); else fourstep_split<R, false, TCH>(v, reinterpret_cast<float*>(myrow), tw, ln);
         }
@@ -599,10 +682,13 @@ __global__ void __launch_bounds__(LINES * R) rowT_pass_kernel(RowTJob job) {
             if constexpr (C64) fourstep_c64<R, true, TCH>(v, myrow, tw, ln); else fourstep_split<R, true, TCH>(v, reinterpret_cast<float*>(myrow), tw, ln);
         }
         prefetch_part(MSL_IC(24), MSL_IC(32));
+#endif
         wave_lds_fence();
 #pragma unroll
         for (int j = 0; j < R; ++j) myrow[j * R + ln] = v[j];
+        MSL_STAMP(18);
         lds_barrier();
+        MSL_STAMP(19);
         // uniform 64-bit base + per-thread 32-bit element offset, re-derived every iteration (the asm keeps the
         // compiler from hoisting 16 loop-invariant 64-bit addresses into registers for the whole kernel)
         float2* dst = job.out + (long long)p * job.out_image_stride + cur_lb * LINES;
@@ -615,9 +701,15 @@ __global__ void __launch_bounds__(LINES * R) rowT_pass_kernel(RowTJob job) {
             const float2 a = tile[(2 * q) * CS + pos], b = tile[(2 * q + 1) * CS + pos];
             *reinterpret_cast<float4*>(dst + (off0 + i * ostep)) = make_float4(a.x, a.y, b.x, b.y);
         }
+        MSL_STAMP(20);
         lds_barrier();
+        MSL_STAMP(21);
         item = nitem; lb = nlb; pc = npc; k = nk;
     }
+#ifdef MSL_STAMPS
+    if ((tid & 63) == 0 && job.stamps)
+        for (int i = 0; i < MSL_NSTAMP; ++i) job.stamps[((size_t)blockIdx.x * (NT / 64) + tid / 64) * MSL_NSTAMP + i] = acc_[i];
+#endif
 }
 
 // ---- lines of N = 2 R^2 points (512 = 2*16^2, 2048 = 2*32^2) ----------------------------------------------
