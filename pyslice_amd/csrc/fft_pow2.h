@@ -643,24 +643,47 @@ __global__ void __launch_bounds__(LINES * R) rowT_pass_kernel(RowTJob job) {
 #define MSL_IC(x) std::integral_constant<int, (x)>{}              // quarter boundaries in 32nds of the line's registers
         MSL_STAMP(2);                                                   // t_k load (k == 0) + cursor
 #ifdef MSL_STAMPS
-        // diagnostic build: the four transforms in halves (head = register FFT + twiddles, tail = transpose + register FFT)
-        fourstep_head<R, false, TCH>(v, tw, ln); MSL_STAMP(3);
-        fourstep_tail<R, false, C64>(v, myrow, ln); MSL_STAMP(4);
-        prefetch_part(MSL_IC(0), MSL_IC(8)); MSL_STAMP(5);
-        mul_table<R, 0, false, R, TCH>(v, pl, ln); MSL_STAMP(6);
-        fourstep_head<R, true, TCH>(v, tw, ln); MSL_STAMP(7);
-        fourstep_tail<R, true, C64>(v, myrow, ln); MSL_STAMP(8);
-        prefetch_part(MSL_IC(8), MSL_IC(16)); MSL_STAMP(9);
+        // diagnostic build: the four transforms in halves (head = register FFT + twiddles, tail = transpose + register FFT);
+        // MSL_ABL bits remove parts of the work (wrong results, timing only): 1 = no prefetch loads, 2 = no stores,
+        // 4 = no LDS transposes, 8 = no LDS table reads (tables replaced by a register)
+#ifndef MSL_ABL
+#define MSL_ABL 0
+#endif
+        auto head = [&](auto inv_c) {
+            constexpr bool INV = decltype(inv_c)::value;
+            if constexpr (MSL_ABL & 8) { fft_regs<R, INV>(v);
+#pragma unroll
+                for (int j = 1; j < R; ++j) v[j] = cmulf(v[j], tv[j]);
+            } else fourstep_head<R, INV, TCH>(v, tw, ln);
+        };
+        auto tail = [&](auto inv_c) {
+            constexpr bool INV = decltype(inv_c)::value;
+            if constexpr (MSL_ABL & 4) fft_regs<R, INV>(v); else fourstep_tail<R, INV, C64>(v, myrow, ln);
+        };
+        auto mulp = [&]() {
+            if constexpr (MSL_ABL & 8) {
+#pragma unroll
+                for (int j = 0; j < R; ++j) v[j] = cmulf(v[j], tv[R - 1 - j]);
+            } else mul_table<R, 0, false, R, TCH>(v, pl, ln);
+        };
+        auto pf = [&](auto lo, auto hi) { if constexpr (!(MSL_ABL & 1)) prefetch_part(lo, hi); };
+        head(std::false_type{}); MSL_STAMP(3);
+        tail(std::false_type{}); MSL_STAMP(4);
+        pf(MSL_IC(0), MSL_IC(8)); MSL_STAMP(5);
+        mulp(); MSL_STAMP(6);
+        head(std::true_type{}); MSL_STAMP(7);
+        tail(std::true_type{}); MSL_STAMP(8);
+        pf(MSL_IC(8), MSL_IC(16)); MSL_STAMP(9);
 #pragma unroll
         for (int j = 0; j < R; ++j) v[j] = cmulf(v[j], tv[j]);
         MSL_STAMP(10);
-        fourstep_head<R, false, TCH>(v, tw, ln); MSL_STAMP(11);
-        fourstep_tail<R, false, C64>(v, myrow, ln); MSL_STAMP(12);
-        prefetch_part(MSL_IC(16), MSL_IC(24)); MSL_STAMP(13);
-        mul_table<R, 0, false, R, TCH>(v, pl, ln); MSL_STAMP(14);
-        fourstep_head<R, true, TCH>(v, tw, ln); MSL_STAMP(15);
-        fourstep_tail<R, true, C64>(v, myrow, ln); MSL_STAMP(16);
-        prefetch_part(MSL_IC(24), MSL_IC(32)); MSL_STAMP(17);
+        head(std::false_type{}); MSL_STAMP(11);
+        tail(std::false_type{}); MSL_STAMP(12);
+        pf(MSL_IC(16), MSL_IC(24)); MSL_STAMP(13);
+        mulp(); MSL_STAMP(14);
+        head(std::true_type{}); MSL_STAMP(15);
+        tail(std::true_type{}); MSL_STAMP(16);
+        pf(MSL_IC(24), MSL_IC(32)); MSL_STAMP(17);
 #else
         if (job.flags & P2_PRE_A) {
             if constexpr (C64) fourstep_c64<R, false, TCH>(v, myrow, tw, ln); else fourstep_split<R, false, TCH>(v, reinterpret_cast<float*>(myrow), tw, ln);
@@ -699,6 +722,9 @@ __global__ void __launch_bounds__(LINES * R) rowT_pass_kernel(RowTJob job) {
         for (int i = 0; i < NIT; ++i) {
             const int pos = r0 + POS_PER_IT * i;
             const float2 a = tile[(2 * q) * CS + pos], b = tile[(2 * q + 1) * CS + pos];
+#if defined(MSL_STAMPS) && (MSL_ABL & 2)
+            if (a.x == 1.2345e-30f)                 // never true: the LDS reads stay, the store goes
+#endif
             *reinterpret_cast<float4*>(dst + (off0 + i * ostep)) = make_float4(a.x, a.y, b.x, b.y);
         }
         MSL_STAMP(20);
@@ -710,6 +736,151 @@ __global__ void __launch_bounds__(LINES * R) rowT_pass_kernel(RowTJob job) {
     if ((tid & 63) == 0 && job.stamps)
         for (int i = 0; i < MSL_NSTAMP; ++i) job.stamps[((size_t)blockIdx.x * (NT / 64) + tid / 64) * MSL_NSTAMP + i] = acc_[i];
 #endif
+}
+
+// ---- transposing pass on PAIRED lines: two independent workgroups per CU ----------------------------------------
+// rowT_pass_kernel needs 16 lines per tile for 128-byte transposed segments, i.e. one 512-thread workgroup per CU whose
+// 8 waves run in lockstep: they all issue their loads, transpose through the LDS, store and wait at the barriers at the
+// same time, and the phase timeline (tools/rowt_timeline.hip) shows a wave computing only ~60% of its life.  Here the
+// work buffers between two passes hold the lines in PAIRS: element e of line L lives at
+//     (L/2) * (2*pitch) + 2*e + (L & 1)                                 [float2 units]
+// so the two lines of a pair are interleaved element by element.  Reading is as coalesced as before (the two 32-lane groups
+// of a wave take the two lines of a pair: one load instruction covers 512 contiguous bytes), and a transposed segment of
+// 128 bytes now consists of TWO neighbouring positions of EIGHT lines -- the tile shrinks to 8 lines (66 KB), a workgroup
+// to 256 threads, and two workgroups fit a CU (2 x 80 KB of LDS, 2 x 4 waves x 256 VGPRs).  They are independent: while
+// one waits for memory or at its barrier the other one has the SIMDs to itself.  Only the passes between two transposing
+// passes use the layout; the first pass reads and the last one writes the natural layout (IN_P / OUT_P), so probes, the
+// final in-place pass and the exit FFT are untouched.  The Fresnel table is symmetric, P[m] = P[N - m], and only its
+// first N/2 + 1 entries are kept in the LDS to make the two workgroups fit.
+template <int R, bool IN_P, bool OUT_P>
+__global__ void __launch_bounds__(8 * R, 2) rowTP_pass_kernel(RowTJob job) {
+    static_assert(R == 32, "1024-point lines");
+    constexpr int N = R * R, LINES = 8, NT = LINES * R, TCH = 8;
+    constexpr int CS = R * (R + 1) + 1;               // tile line pitch (odd: conflict-free staging), also the transpose scratch
+    constexpr int NH = N / 2 + 2;                     // stored part of the symmetric propagator table (+1 pad)
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float2* tw = reinterpret_cast<float2*>(smem_raw);
+    float2* plh = tw + N;
+    float2* tile = plh + NH;                          // LINES * CS
+    const int tid = threadIdx.x;
+    for (int i = tid; i < N; i += NT) tw[i] = job.tw[i];
+    for (int i = tid; i <= N / 2; i += NT) plh[i] = job.pl[i];
+    __syncthreads();
+    const int grp = tid / R, ln = tid % R;
+    float2* myrow = tile + grp * CS;
+    const float2* pa = plh + ln;                      // P[j R + ln],           j <  R/2
+    const float2* pb = plh - ln;                      // P[N - (j R + ln)] = plh[(R - j) R - ln],  j >= R/2
+    auto mul_p = [&](float2 (&vv)[R]) {
+#pragma unroll
+        for (int c = 0; c < R; c += TCH) {
+            float2 w[TCH];
+#pragma unroll
+            for (int j = 0; j < TCH; ++j) w[j] = (c + j < R / 2) ? pa[(c + j) * R] : pb[(R - (c + j)) * R];
+#pragma unroll
+            for (int j = 0; j < TCH; ++j) vv[c + j] = cmulf(vv[c + j], w[j]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    const int lblocks = job.n_lines / LINES;
+    const int PC = job.pchunk;
+    const int pchunks = (job.n_images + PC - 1) / PC;
+    const int n_items = lblocks * pchunks;
+    const int step_lb = (int)gridDim.x / pchunks, step_pc = (int)gridDim.x % pchunks;
+    // element e of this thread's line: base[e * ES]
+    constexpr int ES = IN_P ? 2 : 1;
+    auto line_ptr = [&](int lbb, int pcc, int kk) {
+        const int L = lbb * LINES + grp;
+        const long long off = IN_P ? (long long)(L >> 1) * (2 * job.in_pitch) + (L & 1) : (long long)L * job.in_pitch;
+        return job.in + (long long)(pcc * PC + kk) * job.in_image_stride + off + ln * ES;
+    };
+    int item = blockIdx.x;
+    int lb = item / pchunks, pc = item - lb * pchunks, k = 0;
+    float2 vn[R];
+    if (item < n_items) {
+        const float2* r = line_ptr(lb, pc, 0);
+#pragma unroll
+        for (int j = 0; j < R; ++j) vn[j] = r[j * R * ES];
+    }
+    float2 tv[R];
+    while (item < n_items) {
+        float2 v[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) v[j] = vn[j];
+        const int p = pc * PC + k;
+        const int cur_lb = lb;
+        if (k == 0) {
+            const float2* trow = job.trans + (long long)(lb * LINES + grp) * N;
+#pragma unroll
+            for (int j = 0; j < R; ++j) tv[j] = trow[j * R + ln];
+        }
+        int nitem = item, nlb = lb, npc = pc, nk = k + 1;
+        if (nk >= min(PC, job.n_images - pc * PC)) {
+            nk = 0; nitem = item + (int)gridDim.x; nlb = lb + step_lb; npc = pc + step_pc;
+            if (npc >= pchunks) { npc -= pchunks; ++nlb; }
+        }
+        auto prefetch_part = [&](auto lo_c, auto hi_c) {
+            constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
+            __builtin_amdgcn_sched_barrier(0);
+            if (nitem < n_items) {
+                const float2* r = line_ptr(nlb, npc, nk);
+#pragma unroll
+                for (int j = LO; j < HI; ++j) vn[j] = r[j * R * ES];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        if (job.flags & P2_PRE_A) fourstep_split<R, false, TCH>(v, reinterpret_cast<float*>(myrow), tw, ln);
+        prefetch_part(MSL_IC(0), MSL_IC(8));
+        if (job.flags & P2_PRE_A) {
+            mul_p(v);
+            fourstep_split<R, true, TCH>(v, reinterpret_cast<float*>(myrow), tw, ln);
+        }
+        prefetch_part(MSL_IC(8), MSL_IC(16));
+#pragma unroll
+        for (int j = 0; j < R; ++j) v[j] = cmulf(v[j], tv[j]);
+        if (job.flags & P2_POST_A) fourstep_split<R, false, TCH>(v, reinterpret_cast<float*>(myrow), tw, ln);
+        prefetch_part(MSL_IC(16), MSL_IC(24));
+        if (job.flags & P2_POST_A) {
+            mul_p(v);
+            fourstep_split<R, true, TCH>(v, reinterpret_cast<float*>(myrow), tw, ln);
+        }
+        prefetch_part(MSL_IC(24), MSL_IC(32));
+        wave_lds_fence();
+#pragma unroll
+        for (int j = 0; j < R; ++j) myrow[j * R + ln] = v[j];
+        lds_barrier();
+        if constexpr (OUT_P) {
+            // segment = positions (2 mm, 2 mm + 1) of the tile's 8 lines = 128 contiguous bytes of the paired output; thread =
+            // (line i, pair mm).  The four octets of a half-wave take pairs 4 apart: with the odd line pitch their LDS reads
+            // then fall into different banks.
+            const int i = tid & 7, oct = tid >> 3, q = oct & 3, hh = oct >> 2;
+            const int mm0 = (hh & 3) + 4 * q + 16 * (hh >> 2);
+            const float2* src = tile + i * CS + 2 * mm0;
+            float2* dst = job.out + (long long)p * job.out_image_stride + 2 * (cur_lb * LINES + i);
+            int off0 = mm0 * 2 * job.out_pitch;
+            asm volatile("" : "+v"(off0));
+            const int ostep = 32 * 2 * job.out_pitch;
+#pragma unroll
+            for (int it = 0; it < N / 2 / 32; ++it) {
+                const float2 a = src[it * 64], b = src[it * 64 + 1];
+                *reinterpret_cast<float4*>(dst + (off0 + it * ostep)) = make_float4(a.x, a.y, b.x, b.y);
+            }
+        } else {
+            // natural output (last transposing pass): out[e][L], 8 lines = 64-byte segments, thread = (position e, two lines)
+            const int q4 = tid & 3, e0 = tid >> 2;
+            float2* dst = job.out + (long long)p * job.out_image_stride + cur_lb * LINES + 2 * q4;
+            int off0 = e0 * job.out_pitch;
+            asm volatile("" : "+v"(off0));
+            const int ostep = (NT / 4) * job.out_pitch;
+#pragma unroll
+            for (int it = 0; it < N / (NT / 4); ++it) {
+                const int e = e0 + (NT / 4) * it;
+                const float2 a = tile[(2 * q4) * CS + e], b = tile[(2 * q4 + 1) * CS + e];
+                *reinterpret_cast<float4*>(dst + (off0 + it * ostep)) = make_float4(a.x, a.y, b.x, b.y);
+            }
+        }
+        lds_barrier();
+        item = nitem; lb = nlb; pc = npc; k = nk;
+    }
 }
 
 // ---- lines of N = 2 R^2 points (512 = 2*16^2, 2048 = 2*32^2) ----------------------------------------------

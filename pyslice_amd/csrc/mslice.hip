@@ -77,6 +77,7 @@ struct msl_handle {
     float2* transT = nullptr;
     int pitchT = 0;
     int rowT_variant = 0;
+    int rowT_paired = 0;           // MSL_ROWT_PAIRED=1: 8-line tiles in the paired-lines layout, two workgroups per CU (measured equal: DESIGN 4.1)
     int debug_flags_mask = -1;
     int row_pchunk = 0;         // 0 = auto (MSL_ROW_PCHUNK)
     int row_variant = 1;        // 0: plain row kernel, 1: software-pipelined (MSL_ROW_VARIANT)
@@ -589,6 +590,30 @@ int launch_rowT_r(msl_handle* h, RowTJob job, int kind) {
     return h->rowT_variant == 1 ? launch_rowT_v<R, 16, true>(h, job, kind) : launch_rowT_v<R, 16, false>(h, job, kind);
 }
 
+// paired-lines transposing pass (1024-point lines in both directions): two 256-thread workgroups per CU
+template <bool IN_P, bool OUT_P>
+int launch_rowTP_io(msl_handle* h, RowTJob job, int kind) {
+    constexpr int R = 32, N = R * R, CS = R * (R + 1) + 1, LINES = 8;
+    const size_t lds = ((size_t)N + N / 2 + 2 + (size_t)LINES * CS) * 8;
+    const int per_cu = std::max(1, std::min(2, (int)((size_t)h->lds_limit / lds)));
+    const long long slots = (long long)h->n_cus * per_cu;
+    const long long lb = job.n_lines / LINES;
+    int pc = job.n_images;
+    while (pc > 1 && lb * ((job.n_images + pc - 1) / pc) < slots) pc = (pc + 1) / 2;
+    if (h->row_pchunk > 0) pc = std::min(h->row_pchunk, job.n_images);
+    job.pchunk = pc;
+    const long long items = lb * ((job.n_images + pc - 1) / pc);
+    const int grid = (int)std::min<long long>(items, slots);
+    (void)hipFuncSetAttribute((const void*)rowTP_pass_kernel<R, IN_P, OUT_P>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
+    hipLaunchKernelGGL((rowTP_pass_kernel<R, IN_P, OUT_P>), dim3(grid), dim3(LINES * R), lds, h->stream, job);
+    HIPCHK(h, hipGetLastError());
+    return mark_launch(h, kind);
+}
+int launch_rowTP(msl_handle* h, const RowTJob& job, bool in_p, bool out_p, int kind) {
+    if (in_p) return out_p ? launch_rowTP_io<true, true>(h, job, kind) : launch_rowTP_io<true, false>(h, job, kind);
+    return out_p ? launch_rowTP_io<false, true>(h, job, kind) : launch_rowTP_io<false, false>(h, job, kind);
+}
+
 // lines of 2 R^2 points (512, 2048)
 template <int R>
 int launch_rowT2_r(msl_handle* h, RowTJob job, int kind) {
@@ -744,16 +769,20 @@ int slice_loop_onepass(msl_handle* h, int fused_slot) {
         const bool along_y = !slice_is_transposed(h, k);
         RowTJob j{};
         j.flags = flags; j.n_images = P;
+        // 1024-point lines in both directions: paired-lines kernel, work buffers between two transposing passes in the
+        // paired layout (the first pass reads, the last one writes the natural layout)
+        const bool paired = h->rowT_paired && h->Rx == 32 && h->Ry == 32;
+        const bool in_p = paired && k > 0, out_p = paired && k < nz - 2;
         if (along_y) {
             j.in = (k == 0) ? h->psi0 : h->psi; j.out = h->psiT;
             j.trans = h->trans + (size_t)k * npix; j.pl = h->pyt; j.tw = h->tw4_y;
             j.in_image_stride = isA; j.out_image_stride = isB; j.in_pitch = h->pitch; j.out_pitch = h->pitchT; j.n_lines = c.nx;
-            rc = h->Ry == 32 ? launch_rowT_r<32>(h, j, K_ROW) : launch_rowT_r<16>(h, j, K_ROW);
+            rc = paired ? launch_rowTP(h, j, in_p, out_p, K_ROW) : (h->Ry == 32 ? launch_rowT_r<32>(h, j, K_ROW) : launch_rowT_r<16>(h, j, K_ROW));
         } else {
             j.in = (k == 0) ? h->psi0T : h->psiT; j.out = h->psi;
             j.trans = h->transT + (size_t)k * npix; j.pl = h->pxt; j.tw = h->tw4_x;
             j.in_image_stride = isB; j.out_image_stride = isA; j.in_pitch = h->pitchT; j.out_pitch = h->pitch; j.n_lines = c.ny;
-            rc = h->Rx == 32 ? launch_rowT_r<32>(h, j, K_COL) : launch_rowT_r<16>(h, j, K_COL);
+            rc = paired ? launch_rowTP(h, j, in_p, out_p, K_COL) : (h->Rx == 32 ? launch_rowT_r<32>(h, j, K_COL) : launch_rowT_r<16>(h, j, K_COL));
         }
         if (rc) return rc;
     }
@@ -981,6 +1010,7 @@ int msl_create(const msl_config* cfg, msl_handle** out) {
             if (h->need_psi0T && (rc = dalloc(h, &h->psi0T, (size_t)cfg->ny * h->pitchT * cfg->n_probes))) return bail(rc);
             if ((rc = dalloc(h, &h->transT, npix * cfg->nz))) return bail(rc);
             { const char* ev = getenv("MSL_ROWT_VARIANT"); if (ev) h->rowT_variant = atoi(ev); }
+            { const char* ev = getenv("MSL_ROWT_PAIRED"); if (ev) h->rowT_paired = atoi(ev); }
             { const char* ev = getenv("MSL_DEBUG_FLAGS_MASK"); if (ev) h->debug_flags_mask = atoi(ev); }
             (void)hipFuncSetAttribute((const void*)row_pass2_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
             (void)hipFuncSetAttribute((const void*)row_pass2_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
