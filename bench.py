@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--frames-per-step", type=int, default=8,
                     help="--scaling strong: MD frames per step, sharded over the ranks (fixed total work)")
+    ap.add_argument("--frame-batch", type=int, default=0,
+                    help="MD frames sharing every slice-loop launch (0 = the calculator's rule: about 64 images per launch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-slices", type=int, default=100,
                     help="slices of the bounded CPU sample (100 of 200 at 1024^2: about 12 s of single-thread work)")
@@ -224,9 +226,11 @@ def run(a):
             slots, tacaw_T = want, want
         else:
             tacaw_T = n_local
+    fb = a.frame_batch if a.frame_batch > 0 else max(1, min(-(-64 // P), int(16e9 // (16.0 * nz * npix))))
+    fb = max(1, min(fb, a.steps))
     eng = _native.Engine(n, n, nz, xs[1] - xs[0], ys[1] - ys[0], zs[1] - zs[0] if nz > 1 else 0.5, wavelength(100e3),
                          interaction_sigma(100e3), n_probes=P, n_frames=slots, device=local_rank,
-                         launch_timing=not a.no_launch_timing)
+                         launch_timing=not a.no_launch_timing, frame_batch=fb)
     eng.set_kirkland(loadKirkland())
     eng.set_slices(*slice_edges(zs))
     eng.set_probes(a.aperture, pp)
@@ -241,6 +245,20 @@ def run(a):
             eng.build_potential(tr.positions[f], Z, 2)
             eng.propagate_frame(slot_of[f])
 
+    def steps(s0, s1):
+        """steps [s0, s1): frame by frame, or -- frame batching -- in groups of B frames per sequence of launches"""
+        if eng.frame_batch == 1:
+            for s in range(s0, s1):
+                step(s)
+            return
+        todo = [f for s in range(s0, s1) for f in my_frames[s]]
+        for i in range(0, len(todo), eng.frame_batch):
+            chunk = todo[i:i + eng.frame_batch]
+            for b, f in enumerate(chunk):
+                eng.select_batch_slot(b)
+                eng.build_potential(tr.positions[f], Z, 2)
+            eng.propagate_frames(slot_of[chunk[0]], len(chunk))
+
     def fence():
         eng.synchronize()
         torch.cuda.synchronize()
@@ -248,13 +266,11 @@ def run(a):
             dist.barrier()
         torch.cuda.synchronize()
 
-    for s in range(a.warmup):
-        step(s)
+    steps(0, a.warmup)
     fence()
     eng.reset_counters()
     t0 = time.perf_counter()
-    for s in range(a.warmup, a.warmup + a.steps):
-        step(s)
+    steps(a.warmup, a.warmup + a.steps)
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -332,8 +348,8 @@ def run(a):
         # propagation and start the next); the two-pass loop (MSL_SLICE_PATH=2) needs two (SURVEY 8d's 32 B).
         rows, cols = (ctr["row_launches"], ctr["ms_row"]), (ctr["col_launches"], ctr["ms_col"])
         name, (cnt, ms) = max((("pass_along_y", rows), ("pass_along_x", cols)), key=lambda kv: kv[1][1])
-        bytes_per_launch = 16.0 * npix * P
-        passes_per_slice = (rows[0] + cols[0]) / float(frames_timed_local * nz) if nz and frames_timed_local else 0.0
+        bytes_per_launch = 16.0 * npix * P * eng.frame_batch
+        passes_per_slice = (rows[0] + cols[0]) * eng.frame_batch / float(frames_timed_local * nz) if nz and frames_timed_local else 0.0
         roof = None
         if cnt:
             avg_s = ms * 1e-3 / cnt
@@ -365,7 +381,7 @@ def run(a):
                                    f"(BASELINE configs[2] per-frame work), {tr.n_atoms} atoms, 30 mrad, 100 keV",
                        "grid": n, "slices": nz, "probes": P, "frames_timed": frames_timed,
                        "parallelism": f"frames x{world}", "backend": backend if world > 1 else None,
-                       "world_size_checked": world, "frame_slots": slots},
+                       "world_size_checked": world, "frame_slots": slots, "frame_batch": eng.frame_batch},
             "breakdown_ms_per_step": {"potential": round(ctr["ms_potential"] / a.steps, 3),
                                       "slice_loop_and_epilogue": round(ctr["ms_propagate"] / a.steps, 3)},
             "roofline": roof,

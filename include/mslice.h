@@ -61,7 +61,12 @@ typedef struct {
                                 * buffers then have shape (.., window_nx, window_ny).  0 = the full axis. */
     int32_t launch_timing;     /* 1: record a HIP event after every slice-loop launch so that msl_get_counters reports per-kernel
                                 * launch counts and durations (bench.py's roofline); 0: no events (production) */
-    int32_t reserved[4];
+    int32_t frame_batch;       /* B > 1: up to B MD frames share every slice-loop launch (image index = frame * P + probe, each frame with
+                                * its own transmission stack): the single-probe default of the reference (calculators.py:152-153) is
+                                * otherwise launch-bound.  Potentials are built into batch slots (msl_select_batch_slot) and run by
+                                * msl_propagate_frames.  Costs B x the work buffers and transmission stacks.  0 / 1 = off; ignored
+                                * (treated as 1) with keep_potential. */
+    int32_t reserved[3];
 } msl_config;
 
 typedef enum {
@@ -151,6 +156,16 @@ int  msl_propagate(msl_handle* h);
  * (P,T_local,nx,ny) result.  Replaces _process_frame_worker_torch after the potential
  * (calculators.py:281-290) and the scatter loop (calculators.py:185-186). */
 int  msl_propagate_frame(msl_handle* h, int32_t slot);
+
+/* Frame batching (msl_config.frame_batch = B > 1).  msl_select_batch_slot picks the transmission stack (0 <= b < B) that the
+ * next msl_build_potential / msl_upload_potential fills and that msl_propagate / msl_propagate_frame use;
+ * msl_propagate_frames runs the slice loop + exit FFT for the frames in batch slots 0..count-1 in ONE sequence of
+ * launches and writes them to frame slots first_slot .. first_slot+count-1 of the (P,T_local,wx,wy) result.
+ * msl_frame_batch returns the batch size the handle really uses (1 when batching is off).
+ * Replaces count iterations of the reference's serial frame loop (calculators.py:172-186). */
+int  msl_select_batch_slot(msl_handle* h, int32_t b);
+int  msl_propagate_frames(msl_handle* h, int32_t first_slot, int32_t count);
+int  msl_frame_batch(const msl_handle* h);
 
 /* TACAW: intensity[p,w,kx,ky] = | fftshift_t fft_t( Psi - <Psi>_t ) |^2 over a (B,T,npix) c64 device
  * array.  src == NULL uses the handle's own wavefunction buffer (B=P, T=T_local, npix=nx*ny) and

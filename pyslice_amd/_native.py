@@ -24,6 +24,7 @@ EXPORTS = [
     "msl_get_counters",
     "msl_reset_counters", "msl_fft2_host",
     "msl_tacaw_spectrum", "msl_tacaw_diffraction", "msl_tacaw_dispersion", "msl_adf",
+    "msl_select_batch_slot", "msl_propagate_frames", "msl_frame_batch",
 ]
 
 
@@ -34,7 +35,7 @@ class MslConfig(C.Structure):
                 ("n_probes", C.c_int32), ("n_frames", C.c_int32), ("device", C.c_int32),
                 ("keep_potential", C.c_int32), ("fft_path", C.c_int32),
                 ("window_nx", C.c_int32), ("window_ny", C.c_int32), ("launch_timing", C.c_int32),
-                ("reserved", C.c_int32 * 4)]
+                ("frame_batch", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 class MslCounters(C.Structure):
@@ -90,6 +91,9 @@ def load():
         "msl_tacaw_diffraction": (C.c_int, [vp, vp, i64, i64, i64, i64, i64, i64, i64, dbl, vp]),
         "msl_tacaw_dispersion": (C.c_int, [vp, vp, i64, i64, i64, vp, i64, vp]),
         "msl_adf": (C.c_int, [vp, vp, i64, i64, i64, vp, vp]),
+        "msl_select_batch_slot": (C.c_int, [vp, i32]),
+        "msl_propagate_frames": (C.c_int, [vp, i32, i32]),
+        "msl_frame_batch": (C.c_int, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -117,14 +121,15 @@ class Engine:
     """One libmslice handle: one HIP device, one stream, all device buffers of one grid."""
 
     def __init__(self, nx, ny, nz, dx, dy, dz, wavelength, sigma, n_probes=1, n_frames=0, device=0,
-                 keep_potential=False, fft_path=0, window=None, launch_timing=False):
+                 keep_potential=False, fft_path=0, window=None, launch_timing=False, frame_batch=1):
         self._lib = load()
         self._h = C.c_void_p()
         cfg = MslConfig(nx=int(nx), ny=int(ny), nz=int(nz), dx=float(dx), dy=float(dy), dz=float(dz),
                         wavelength=float(wavelength), sigma=float(sigma), n_probes=int(n_probes),
                         n_frames=int(n_frames), device=int(device), keep_potential=int(bool(keep_potential)),
                         fft_path=int(fft_path), window_nx=int(window[0]) if window else 0,
-                        window_ny=int(window[1]) if window else 0, launch_timing=int(bool(launch_timing)))
+                        window_ny=int(window[1]) if window else 0, launch_timing=int(bool(launch_timing)),
+                        frame_batch=int(frame_batch))
         rc = self._lib.msl_create(C.byref(cfg), C.byref(self._h))
         if rc != MSL_OK:
             msg = (self._lib.msl_last_error(None) or b"msl_create failed").decode()
@@ -136,6 +141,7 @@ class Engine:
         # stored shape of one exit-wave spectrum: the k-window, or the whole grid
         self.wx = int(window[0]) if window and window[0] else self.nx
         self.wy = int(window[1]) if window and window[1] else self.ny
+        self.frame_batch = int(self._lib.msl_frame_batch(self._h))      # frames that share one sequence of launches
 
     # -- lifetime
     def close(self):
@@ -218,6 +224,14 @@ class Engine:
 
     def propagate_frame(self, slot):
         self._chk(self._lib.msl_propagate_frame(self._h, int(slot)))
+
+    def select_batch_slot(self, b):
+        """transmission stack (0 <= b < frame_batch) the next build_potential / upload_potential fills"""
+        self._chk(self._lib.msl_select_batch_slot(self._h, int(b)))
+
+    def propagate_frames(self, first_slot, count):
+        """slice loop + exit FFT of the frames in batch slots 0..count-1 -> frame slots first_slot..first_slot+count-1"""
+        self._chk(self._lib.msl_propagate_frames(self._h, int(first_slot), int(count)))
 
     def tacaw(self, src_ptr=None, dst_ptr=None, batch=0, T=0, npix=0):
         self._chk(self._lib.msl_tacaw(self._h, C.c_void_p(src_ptr) if src_ptr else None,

@@ -36,7 +36,7 @@ logger = logging.getLogger(__name__)
 class MultisliceCalculator:
 
     def __init__(self, device=None, force_cpu=False, *, output="host", dtype="complex128", progress=True,
-                 gather="rank0", cache=False, k_window=None):
+                 gather="rank0", cache=False, k_window=None, frame_batch=None):
         """
         device / force_cpu: as the reference (calculators.py:41).  There is no CPU path here, so
         force_cpu=True raises.  Keyword-only extras (not in the reference):
@@ -72,6 +72,9 @@ class MultisliceCalculator:
                 raise ValueError("the frame cache stores full (P,nx,ny,1,1) frames: cache=True cannot be combined with k_window")
             k_window = (int(k_window[0]), int(k_window[1]))
         self._k_window = k_window
+        if frame_batch is not None and int(frame_batch) < 1:
+            raise ValueError("frame_batch must be a positive frame count")
+        self._frame_batch = None if frame_batch is None else int(frame_batch)
         self._engine = None
         # reference calculators.py:70-76 (display names for Z <= 36)
         self.element_map = {
@@ -149,10 +152,15 @@ class MultisliceCalculator:
         # A previous run's WFData (and zero-copy device views of its buffers) may still hold the old engine: drop our
         # reference and let the last owner free it, instead of closing it under them.
         self._engine = None
+        batch = self._frame_batch
+        if batch is None:
+            # about 64 images per launch, at most 16 GB for the two orientations of the batch's transmission stacks
+            batch = max(1, min(-(-64 // self.n_probes), int(16e9 // (16.0 * n_slices * nx * ny))))
+        batch = 1 if self._cache else max(1, min(batch, len(self._frames)))
         self._engine = _native.Engine(nx, ny, n_slices, self.dx, self.dy, dz, wavelength(voltage_eV),
                                       interaction_sigma(voltage_eV), n_probes=self.n_probes,
                                       n_frames=max(1, len(self._frames)), device=_device_index(dev),
-                                      window=self._k_window)
+                                      window=self._k_window, frame_batch=batch)
         self._engine.set_kirkland(loadKirkland())
         lo, hi = slice_edges(slice_coords)
         self._engine.set_slices(lo, hi)
@@ -174,7 +182,22 @@ class MultisliceCalculator:
             except ImportError:
                 bar = None
         self.frames_computed = self.frames_cached = 0
-        for slot, frame_idx in enumerate(frames):
+        B = eng.frame_batch
+        if B > 1:
+            # batches of B frames: B potentials into the batch slots, then one slice loop over B x P images
+            for s0 in range(0, len(frames), B):
+                chunk = frames[s0:s0 + B]
+                for b, frame_idx in enumerate(chunk):
+                    eng.select_batch_slot(b)
+                    eng.build_potential(self.trajectory.positions[frame_idx], self._Z, self.slice_axis)
+                eng.propagate_frames(s0, len(chunk))
+                self.frames_computed += len(chunk)
+                if bar is not None:
+                    bar.update(len(chunk))
+            frames_iter = []
+        else:
+            frames_iter = list(enumerate(frames))
+        for slot, frame_idx in frames_iter:
             cache_file = self.output_dir / f"frame_{frame_idx}.npy"
             if self._cache and cache_file.exists():
                 eng.upload_frame(slot, np.load(cache_file)[:, :, :, 0, 0])

@@ -54,6 +54,10 @@ struct LineJob {
     int M;                      // transform length of the Stockham stages: N, or >= 2N-1 for Bluestein lines
     const float2* chirp;        // Bluestein: w[n] = exp(-i pi n^2 / N), n < N
     const float2* bfilt;        // Bluestein: FFT_M of the wrapped conj chirp, pre-divided by M
+    // frame batching: image i is member i % group of frame i / group; its output goes to (i % group) * out_is +
+    // (i / group) * out_gs and its MUL_ARRAY factors start (i / group) * m_gs further on (group == 0: off)
+    int group;
+    long long out_gs, m_gs;
     int npad;                   // LDS line pitch (float2)
     int tw_in_lds;
     float scale;
@@ -273,10 +277,12 @@ __global__ void __launch_bounds__(1024) line_fft_kernel(LineJob job) {
         if (ro >= job.lines_per_image) ro -= job.lines_per_image;
         bool keep = true;
         if (job.win_nn > 0) { ro -= job.win_r0; keep = (ro >= 0 && ro < job.win_nr); }
+        const long long frame = job.group > 0 ? img / job.group : 0;
+        const long long member = job.group > 0 ? img - frame * job.group : img;
         s_in[tid] = img * job.in_is + r * job.in_ls;
-        s_out[tid] = keep ? img * job.out_is + ro * job.out_ls : -1;
-        s_m1[tid] = r * job.m1_ls;
-        s_m2[tid] = r * job.m2_ls;
+        s_out[tid] = keep ? member * job.out_is + frame * job.out_gs + ro * job.out_ls : -1;
+        s_m1[tid] = r * job.m1_ls + frame * job.m_gs;
+        s_m2[tid] = r * job.m2_ls + frame * job.m_gs;
     }
     const float2* tw = job.tw;
     if (job.tw_in_lds) {

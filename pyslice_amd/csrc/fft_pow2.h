@@ -155,7 +155,17 @@ struct RowJob {
     int n_images;           // P
     int do_ifft, do_fft;
     int pchunk;             // probes per work item of the pipelined row kernel (t_z row reuse in registers)
+    // frame batching: images [g*t_group, (g+1)*t_group) belong to frame g of the batch, whose transmission stack starts
+    // t_stride elements after the previous frame's (t_group == 0: one frame, every image uses `trans`)
+    int t_group;
+    long long t_stride;
 };
+
+// transmission stack of the frame that image p belongs to
+template <typename Job>
+__device__ __forceinline__ const float2* frame_trans(const Job& job, int p) {
+    return job.t_group > 0 ? job.trans + (long long)(p / job.t_group) * job.t_stride : job.trans;
+}
 
 // Row pass.  Workgroup = 256 threads = 256/R lines per iteration, persistent over line groups.
 // Line-group order is x-major, probe-minor, so the t_z rows one group needs are being read by the
@@ -190,7 +200,7 @@ __global__ void __launch_bounds__(256, R == 32 ? 3 : 4) row_pass_kernel(RowJob j
         for (int j = 0; j < R; ++j) v[j] = row[j * R + ln];
         if (job.do_ifft) fourstep_split<R, true>(v, scratch, tw, ln);
         if (job.trans) {
-            const float2* trow = job.trans + (long long)x * N;
+            const float2* trow = frame_trans(job, p) + (long long)x * N;
             mul_table<R, 0, false>(v, trow, ln);
         }
         if (job.do_fft) {
@@ -249,7 +259,7 @@ __global__ void __launch_bounds__(256, 2) row_pass_pf_kernel(RowJob job) {
         float2* cur_row = row_of(item, k);
         if (k == 0 && job.trans) {          // new x-group: its transmission rows first (L2), before the next HBM loads
             const int x = (int)(item / pchunks) * G + grp;
-            const float2* trow = job.trans + (long long)x * N;
+            const float2* trow = frame_trans(job, (int)(item % pchunks) * PC) + (long long)x * N;
 #pragma unroll
             for (int j = 0; j < R; ++j) tv[j] = trow[j * R + ln];
         }
@@ -295,6 +305,10 @@ struct ColJob {
     // COL_SHIFT only: k-window in fftshifted coordinates.  Columns [win_c0, win_c0 + win_nc) are transformed (win_nc == 0:
     // all ny), rows [win_x0, win_x0 + win_nx) are stored, both rebased to 0.  win_c0, win_nc and ny/2 are multiples of 16.
     int win_c0, win_nc, win_x0, win_nx;
+    // frame batching (COL_SHIFT epilogue): image p is probe p % out_group of frame p / out_group and goes to
+    // out + (p % out_group) * out_image_stride + (p / out_group) * out_group_stride   (out_group == 0: p * out_image_stride)
+    int out_group;
+    long long out_group_stride;
 };
 // COL_POTENTIAL: epilogue of the potential build, V = Re(x)*scale, out = exp(i sigma V)  (potentials.py:336-342, multislice.py:282)
 // COL_TPOT (with COL_POTENTIAL): every second slice's t is stored transposed, (ny, nx), for the one-pass slice loop
@@ -397,7 +411,9 @@ __global__ void __launch_bounds__(16 * R) col_pass_kernel(ColJob job) {
             int cshift = c0, xshift = 0;
             if (job.flags & COL_SHIFT) { cshift = (c0 + job.ny / 2) % job.ny; xshift = N / 2; }
             if (windowed) cshift -= job.win_c0;
-            float2* dst = job.out + p * job.out_image_stride + cshift + 2 * q;
+            const long long obase = job.out_group > 0 ? (p % job.out_group) * job.out_image_stride + (p / job.out_group) * job.out_group_stride
+                                                      : p * job.out_image_stride;
+            float2* dst = job.out + obase + cshift + 2 * q;
 #pragma unroll
             for (int i = 0; i < NIT; ++i) {
                 const int x = r0 + ROWS_PER_IT * i;
@@ -453,6 +469,8 @@ struct Row2Job {
     const float2* tw;
     long long image_stride;
     int pitch, nx, n_images, flags, pchunk;
+    int t_group;            // frame batching, see RowJob
+    long long t_stride;
 };
 
 template <int R>
@@ -494,7 +512,7 @@ __global__ void __launch_bounds__(256, 2) row_pass2_kernel(Row2Job job) {
         float2* cur_row = row_of(item, k);
         if (k == 0) {
             const int x = (int)(item / pchunks) * G + grp;
-            const float2* trow = job.trans + (long long)x * N;
+            const float2* trow = frame_trans(job, (int)(item % pchunks) * PC) + (long long)x * N;
 #pragma unroll
             for (int j = 0; j < R; ++j) tv[j] = trow[j * R + ln];
         }
@@ -538,6 +556,8 @@ struct RowTJob {
     const float2* tw2;      // N = 2R^2 only: W_N^m, m < R^2
     long long in_image_stride, out_image_stride;
     int in_pitch, out_pitch, n_lines, n_images, flags, pchunk;
+    int t_group;            // frame batching, see RowJob
+    long long t_stride;
 #ifdef MSL_STAMPS
     unsigned* stamps;       // tools/rowt_timeline.hip: per wave, cycles spent in each of MSL_NSTAMP phases of the iteration
 #endif
@@ -612,7 +632,7 @@ __global__ void __launch_bounds__(LINES * R) rowT_pass_kernel(RowTJob job) {
         const int p = pc * PC + k;
         const int cur_lb = lb;
         if (k == 0) {
-            const float2* trow = job.trans + (long long)(lb * LINES + grp) * N;
+            const float2* trow = frame_trans(job, pc * PC) + (long long)(lb * LINES + grp) * N;
 #pragma unroll
             for (int j = 0; j < R; ++j) tv[j] = trow[j * R + ln];
         }
@@ -809,7 +829,7 @@ __global__ void __launch_bounds__(8 * R, 2) rowTP_pass_kernel(RowTJob job) {
         const int p = pc * PC + k;
         const int cur_lb = lb;
         if (k == 0) {
-            const float2* trow = job.trans + (long long)(lb * LINES + grp) * N;
+            const float2* trow = frame_trans(job, pc * PC) + (long long)(lb * LINES + grp) * N;
 #pragma unroll
             for (int j = 0; j < R; ++j) tv[j] = trow[j * R + ln];
         }
@@ -1018,7 +1038,7 @@ __global__ void __launch_bounds__(16 * R) rowT2_pass_kernel(RowTJob job) {
         const int p = pc * PC + k;
         const int cur_lb = lb;
         if (!BIG && k == 0) {
-            const float2* trow = job.trans + (long long)lb * 16 * N;
+            const float2* trow = frame_trans(job, pc * PC) + (long long)lb * 16 * N;
 #pragma unroll
             for (int j = 0; j < 2 * R; ++j) tv[j] = trow[t_off + j * R];
         }
@@ -1040,7 +1060,7 @@ __global__ void __launch_bounds__(16 * R) rowT2_pass_kernel(RowTJob job) {
         if constexpr (BIG) {
             int lnx = ln;                                      // laundered: keeps the 64-bit table addresses out of the loop-invariant set
             asm volatile("" : "+v"(lnx));
-            mul_table<2 * R, 0, false, R>(v, job.trans + (long long)lb * 16 * N + grp * N, lnx);
+            mul_table<2 * R, 0, false, R>(v, frame_trans(job, p) + (long long)lb * 16 * N + grp * N, lnx);
         } else {
 #pragma unroll
             for (int j = 0; j < 2 * R; ++j) v[j] = cmulf(v[j], tv[j]);

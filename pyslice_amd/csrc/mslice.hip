@@ -82,6 +82,10 @@ struct msl_handle {
     int row_pchunk = 0;         // 0 = auto (MSL_ROW_PCHUNK)
     int row_variant = 1;        // 0: plain row kernel, 1: software-pipelined (MSL_ROW_VARIANT)
     int pitch = 0;              // row pitch (elements) of psi0/psi; > ny de-aliases the column pass's 128-byte segments
+    // frame batching (msl_config.frame_batch): FB frames share one launch of every slice-loop kernel -- image index =
+    // frame * P + probe, each frame with its own transmission stack.  Work buffers hold FB * P images (the probes are
+    // replicated once per frame of the batch), trans / transT hold FB stacks; cur_batch = stack the next potential goes to.
+    int FB = 1, cur_batch = 0;
     // device buffers
     float2* psi0 = nullptr;
     float2* psi = nullptr;
@@ -114,6 +118,8 @@ struct msl_handle {
     float* d_ff = nullptr;
     int ff_species_cap = 0;
     int n_species = 0;
+    int ff_species[104] = {0};     // species list the resident form-factor table was computed for (frame-invariant: computed once per run)
+    int ff_n = 0;
     double* d_xy = nullptr;
     // counters
     msl_counters ctr{};
@@ -304,6 +310,7 @@ struct LineArgs {
     long long m1_ls = 0, m2_ls = 0;
     int store_mode = STORE_C64; int shift_n = 0, shift_r = 0; float scale = 1.f; float sigma = 0.f;
     int win_n0 = 0, win_nn = 0, win_r0 = 0, win_nr = 0;      // win_nn > 0: store only the window of the shifted output
+    int group = 0; long long out_gs = 0, m_gs = 0;           // frame batching (LineJob)
 };
 
 int launch_lines(msl_handle* h, const FftPlan& pl, const LineArgs& a, int kind) {
@@ -324,6 +331,7 @@ int launch_lines(msl_handle* h, const FftPlan& pl, const LineArgs& a, int kind) 
     job.out_contiguous = a.out_contiguous < 0 ? a.contiguous_lines : a.out_contiguous;
     job.store_mode = a.store_mode; job.shift_n = a.shift_n; job.shift_r = a.shift_r;
     job.win_n0 = a.win_n0; job.win_nn = a.win_nn; job.win_r0 = a.win_r0; job.win_nr = a.win_nr;
+    job.group = a.group; job.out_gs = a.out_gs; job.m_gs = a.m_gs;
     job.n_stages = pl.n_stages; for (int i = 0; i < pl.n_stages; ++i) job.radix[i] = pl.radix[i];
     job.scale = a.scale; job.sigma = a.sigma;
     const int N = pl.M;         // sizing follows the transform length (M > N for Bluestein lines)
@@ -431,6 +439,7 @@ int launch_row_fast_r(msl_handle* h, const RowJob& job, int kind) {
         int pc = job.n_images;
         while (pc > 1 && xg * ((job.n_images + pc - 1) / pc) < slots) pc = (pc + 1) / 2;
         if (h->row_pchunk > 0) pc = std::min(h->row_pchunk, job.n_images);
+        if (job.t_group > 0) while (job.t_group % pc) --pc;          // a chunk of probes shares one t_k line: stay inside a frame
         j2.pchunk = pc;
         const long long items = xg * ((job.n_images + pc - 1) / pc);
         const int grid = (int)std::min<long long>(items, slots);
@@ -504,9 +513,9 @@ int fft2_inplace(msl_handle* h, float2* buf, int images, int dir, float scale, i
 // Exit-wave epilogue, second half: FFT along x of the y-transformed exit waves in psi, fftshift of both axes and
 // scatter into slot `slot` of the (P, T_local, wx, wy) result (calculators.py:284-290).  With a k-window only the
 // columns inside it are transformed and only the rows inside it are stored.
-int epilogue_x_pass(msl_handle* h, int slot) {
+int epilogue_x_pass(msl_handle* h, int slot, int groups = 1) {
     const msl_config& c = h->cfg;
-    const int P = c.n_probes;
+    const int P = c.n_probes * groups;               // image = frame-of-batch * n_probes + probe -> wf[probe][slot + frame]
     float2* dst = h->wf + (size_t)slot * h->wpix;
     const long long out_is = (long long)c.n_frames * h->wpix;
     const bool windowed = (h->wx != c.nx) || (h->wy != c.ny);
@@ -514,12 +523,14 @@ int epilogue_x_pass(msl_handle* h, int slot) {
     if (fast_ok) {
         ColJob k = col_job(h, h->psi, dst, P, h->pitch, h->wy);
         k.flags = COL_FWD | COL_SHIFT; k.out_image_stride = out_is;
+        if (groups > 1) { k.out_group = c.n_probes; k.out_group_stride = (long long)h->wpix; }
         if (windowed) { k.win_c0 = h->wy0; k.win_nc = h->wy; k.win_x0 = h->wx0; k.win_nx = h->wx; }
         return launch_col_fast(h, k, K_OTHER);
     }
     LineArgs k = col_args(h, h->psi, dst, P, h->pitch, h->wy);
     k.fft1 = +1;
     k.out_is = out_is;
+    if (groups > 1) { k.group = c.n_probes; k.out_gs = (long long)h->wpix; }
     k.shift_n = c.nx / 2; k.shift_r = c.ny / 2;
     if (windowed) { k.win_n0 = h->wx0; k.win_nn = h->wx; k.win_r0 = h->wy0; k.win_nr = h->wy; }
     return launch_lines(h, h->plan_x, k, K_OTHER);
@@ -528,9 +539,13 @@ int epilogue_x_pass(msl_handle* h, int slot) {
 // ---- one-pass-per-slice path ------------------------------------------------------------------------
 // psi0 (P, nx, pitch) -> psi0T (P, ny, pitchT): needed when the first pass of the slice loop runs along x
 int transpose_probes(msl_handle* h) {
-    if (!h->onepass || !h->need_psi0T) return MSL_OK;       // the first pass runs along y, on layout A
     const msl_config& c = h->cfg;
-    dim3 grid((c.ny + 31) / 32, (c.nx + 31) / 32, c.n_probes);
+    // frame batching: every frame of a batch starts from the same probes -- one copy per frame
+    const size_t group = (size_t)c.n_probes * c.nx * h->pitch;
+    for (int f = 1; f < h->FB; ++f)
+        HIPCHK(h, hipMemcpyAsync(h->psi0 + f * group, h->psi0, group * sizeof(float2), hipMemcpyDeviceToDevice, h->stream));
+    if (!h->onepass || !h->need_psi0T) return MSL_OK;       // the first pass runs along y, on layout A
+    dim3 grid((c.ny + 31) / 32, (c.nx + 31) / 32, c.n_probes * h->FB);
     hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, h->stream, h->psi0, h->psi0T, c.nx, c.ny, h->pitch, h->pitchT,
                        (long long)c.nx * h->pitch, (long long)c.ny * h->pitchT);
     HIPCHK(h, hipGetLastError());
@@ -554,7 +569,7 @@ int transpose_odd_slices(msl_handle* h) {
     for (int z0 = 0; z0 < count; z0 += 65535) {
         const int nzb = std::min(65535, count - z0);
         dim3 grid((c.ny + 31) / 32, (c.nx + 31) / 32, nzb);
-        const size_t off = (size_t)(first + 2 * z0) * npix;
+        const size_t off = (size_t)h->cur_batch * c.nz * npix + (size_t)(first + 2 * z0) * npix;
         hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, h->stream, h->trans + off, h->transT + off, c.nx, c.ny,
                            c.ny, c.nx, (long long)(2 * npix), (long long)(2 * npix));
     }
@@ -575,6 +590,7 @@ int launch_rowT_v(msl_handle* h, RowTJob job, int kind) {
     int pc = job.n_images;
     while (pc > 1 && lb * ((job.n_images + pc - 1) / pc) < slots) pc = (pc + 1) / 2;
     if (h->row_pchunk > 0) pc = std::min(h->row_pchunk, job.n_images);
+    if (job.t_group > 0) while (job.t_group % pc) --pc;              // a chunk of probes shares one t_k line: stay inside a frame
     job.pchunk = pc;
     const long long items = lb * ((job.n_images + pc - 1) / pc);
     const int grid = (int)std::min<long long>(items, slots);
@@ -601,6 +617,7 @@ int launch_rowTP_io(msl_handle* h, RowTJob job, int kind) {
     int pc = job.n_images;
     while (pc > 1 && lb * ((job.n_images + pc - 1) / pc) < slots) pc = (pc + 1) / 2;
     if (h->row_pchunk > 0) pc = std::min(h->row_pchunk, job.n_images);
+    if (job.t_group > 0) while (job.t_group % pc) --pc;              // a chunk of probes shares one t_k line: stay inside a frame
     job.pchunk = pc;
     const long long items = lb * ((job.n_images + pc - 1) / pc);
     const int grid = (int)std::min<long long>(items, slots);
@@ -626,6 +643,7 @@ int launch_rowT2_r(msl_handle* h, RowTJob job, int kind) {
     int pc = BIG ? 1 : job.n_images;
     while (pc > 1 && lb * ((job.n_images + pc - 1) / pc) < slots) pc = (pc + 1) / 2;
     if (!BIG && h->row_pchunk > 0) pc = std::min(h->row_pchunk, job.n_images);
+    if (job.t_group > 0) while (job.t_group % pc) --pc;              // a chunk of probes shares one t_k line: stay inside a frame
     job.pchunk = pc;
     const long long items = lb * ((job.n_images + pc - 1) / pc);
     const int grid = (int)std::min<long long>(items, slots);
@@ -647,6 +665,7 @@ int launch_rowT_dir(msl_handle* h, const msl_handle::OpDir& o, RowTJob job, int 
         a.out_es = job.out_pitch; a.out_ls = 1; a.out_is = job.out_image_stride;
         a.contiguous_lines = 0; a.out_contiguous = 1;
         a.m1_ls = pl.N;
+        if (job.t_group > 0) { a.group = job.t_group; a.m_gs = job.t_stride; a.out_gs = (long long)job.t_group * job.out_image_stride; }
         int n = 0;
         if (job.flags & P2_PRE_A) {
             a.fft[n] = +1; a.mkind[n] = MUL_VEC; a.mul[n] = job.pl; ++n;
@@ -672,9 +691,10 @@ int launch_rowT_dir(msl_handle* h, const msl_handle::OpDir& o, RowTJob job, int 
 // Slice loop when a grid length is 2 R^2: every pass transposes (there is no in-place kernel for those lengths).
 // Pass k runs along y for even k and along x for odd k; after an odd number of slices one transpose brings the
 // waves back to layout A, and the exit FFT is the stand-alone two-pass one.
-int slice_loop_onepass_b(msl_handle* h, int fused_slot) {
+int slice_loop_onepass_b(msl_handle* h, int fused_slot, int groups, int first_group) {
     const msl_config& c = h->cfg;
-    const int P = c.n_probes, nz = c.nz;
+    const int P = c.n_probes * groups, nz = c.nz;           // images of this run: frames of the batch x probes
+    const size_t toff = (size_t)first_group * c.nz * c.nx * c.ny;
     const size_t npix = (size_t)c.nx * c.ny;
     const long long isA = (long long)c.nx * h->pitch, isB = (long long)c.ny * h->pitchT;
     const bool fused = fused_slot >= 0;
@@ -685,14 +705,15 @@ int slice_loop_onepass_b(msl_handle* h, int fused_slot) {
         j.flags = (k > 0 ? P2_PRE_A : 0) | (k < nz - 1 ? P2_POST_A : 0);
         if (h->debug_flags_mask >= 0) j.flags &= h->debug_flags_mask;
         j.n_images = P;
+        if (groups > 1) { j.t_group = c.n_probes; j.t_stride = (long long)c.nz * npix; }
         if (!(k & 1)) {
             j.in = (k == 0) ? h->psi0 : h->psi; j.out = h->psiT;
-            j.trans = h->trans + (size_t)k * npix; j.pl = h->pyt;
+            j.trans = h->trans + toff + (size_t)k * npix; j.pl = h->pyt;
             j.in_image_stride = isA; j.out_image_stride = isB; j.in_pitch = h->pitch; j.out_pitch = h->pitchT; j.n_lines = c.nx;
             rc = launch_rowT_dir(h, h->opy, j, K_ROW);
         } else {
             j.in = h->psiT; j.out = h->psi;
-            j.trans = h->transT + (size_t)k * npix; j.pl = h->pxt;
+            j.trans = h->transT + toff + (size_t)k * npix; j.pl = h->pxt;
             j.in_image_stride = isB; j.out_image_stride = isA; j.in_pitch = h->pitchT; j.out_pitch = h->pitch; j.n_lines = c.ny;
             rc = launch_rowT_dir(h, h->opx, j, K_COL);
         }
@@ -714,12 +735,12 @@ int slice_loop_onepass_b(msl_handle* h, int fused_slot) {
             r.fft1 = +1;
             if ((rc = launch_lines(h, h->plan_y, r, K_OTHER))) return rc;
         }
-        if ((rc = epilogue_x_pass(h, fused_slot))) return rc;
+        if ((rc = epilogue_x_pass(h, fused_slot, groups))) return rc;
     }
     h->cur = nullptr;
     h->ctr.slice_steps += (uint64_t)P * nz;
-    h->ctr.frames += 1;
-    h->ctr.algorithmic_bytes += (uint64_t)P * nz * 16ull * npix + (uint64_t)nz * 8ull * npix + (fused ? (uint64_t)P * 16ull * npix : 0ull);
+    h->ctr.frames += groups;
+    h->ctr.algorithmic_bytes += (uint64_t)P * nz * 16ull * npix + (uint64_t)groups * nz * 8ull * npix + (fused ? (uint64_t)P * 16ull * npix : 0ull);
     return MSL_OK;
 }
 
@@ -733,6 +754,7 @@ int launch_row2_r(msl_handle* h, Row2Job job, int kind) {
     int pc = job.n_images;
     while (pc > 1 && xg * ((job.n_images + pc - 1) / pc) < slots) pc = (pc + 1) / 2;
     if (h->row_pchunk > 0) pc = std::min(h->row_pchunk, job.n_images);
+    if (job.t_group > 0) while (job.t_group % pc) --pc;              // a chunk of probes shares one t_k line: stay inside a frame
     job.pchunk = pc;
     const long long items = xg * ((job.n_images + pc - 1) / pc);
     const int grid = (int)std::min<long long>(items, slots);
@@ -743,10 +765,11 @@ int launch_row2_r(msl_handle* h, Row2Job job, int kind) {
 
 // Slice loop with one HBM pass per slice (see fft_pow2.h).  Pass k runs along y when its distance to the last
 // slice is even, else along x; all passes but the last write transposed, the last one is in place on layout A.
-int slice_loop_onepass(msl_handle* h, int fused_slot) {
-    if (h->scheme_b) return slice_loop_onepass_b(h, fused_slot);
+int slice_loop_onepass(msl_handle* h, int fused_slot, int groups, int first_group) {
+    if (h->scheme_b) return slice_loop_onepass_b(h, fused_slot, groups, first_group);
     const msl_config& c = h->cfg;
-    const int P = c.n_probes, nz = c.nz;
+    const int P = c.n_probes * groups, nz = c.nz;
+    const size_t toff = (size_t)first_group * c.nz * c.nx * c.ny;
     const size_t npix = (size_t)c.nx * c.ny;
     const long long isA = (long long)c.nx * h->pitch, isB = (long long)c.ny * h->pitchT;
     const bool fused = fused_slot >= 0;
@@ -760,8 +783,9 @@ int slice_loop_onepass(msl_handle* h, int fused_slot) {
         if (h->debug_flags_mask >= 0) flags &= h->debug_flags_mask;     // timing experiments only (MSL_DEBUG_FLAGS_MASK)
         if (last) {
             Row2Job j{};
-            j.psi = h->psi; j.trans = h->trans + (size_t)k * npix; j.py = h->pyt; j.tw = h->tw4_y;
+            j.psi = h->psi; j.trans = h->trans + toff + (size_t)k * npix; j.py = h->pyt; j.tw = h->tw4_y;
             j.image_stride = isA; j.pitch = h->pitch; j.nx = c.nx; j.n_images = P; j.flags = flags;
+            if (groups > 1) { j.t_group = c.n_probes; j.t_stride = (long long)c.nz * npix; }
             rc = h->Ry == 32 ? launch_row2_r<32>(h, j, K_ROW) : launch_row2_r<16>(h, j, K_ROW);
             if (rc) return rc;
             break;
@@ -769,28 +793,29 @@ int slice_loop_onepass(msl_handle* h, int fused_slot) {
         const bool along_y = !slice_is_transposed(h, k);
         RowTJob j{};
         j.flags = flags; j.n_images = P;
+        if (groups > 1) { j.t_group = c.n_probes; j.t_stride = (long long)c.nz * npix; }
         // 1024-point lines in both directions: paired-lines kernel, work buffers between two transposing passes in the
         // paired layout (the first pass reads, the last one writes the natural layout)
         const bool paired = h->rowT_paired && h->Rx == 32 && h->Ry == 32;
         const bool in_p = paired && k > 0, out_p = paired && k < nz - 2;
         if (along_y) {
             j.in = (k == 0) ? h->psi0 : h->psi; j.out = h->psiT;
-            j.trans = h->trans + (size_t)k * npix; j.pl = h->pyt; j.tw = h->tw4_y;
+            j.trans = h->trans + toff + (size_t)k * npix; j.pl = h->pyt; j.tw = h->tw4_y;
             j.in_image_stride = isA; j.out_image_stride = isB; j.in_pitch = h->pitch; j.out_pitch = h->pitchT; j.n_lines = c.nx;
             rc = paired ? launch_rowTP(h, j, in_p, out_p, K_ROW) : (h->Ry == 32 ? launch_rowT_r<32>(h, j, K_ROW) : launch_rowT_r<16>(h, j, K_ROW));
         } else {
             j.in = (k == 0) ? h->psi0T : h->psiT; j.out = h->psi;
-            j.trans = h->transT + (size_t)k * npix; j.pl = h->pxt; j.tw = h->tw4_x;
+            j.trans = h->transT + toff + (size_t)k * npix; j.pl = h->pxt; j.tw = h->tw4_x;
             j.in_image_stride = isB; j.out_image_stride = isA; j.in_pitch = h->pitchT; j.out_pitch = h->pitch; j.n_lines = c.ny;
             rc = paired ? launch_rowTP(h, j, in_p, out_p, K_COL) : (h->Rx == 32 ? launch_rowT_r<32>(h, j, K_COL) : launch_rowT_r<16>(h, j, K_COL));
         }
         if (rc) return rc;
     }
-    if (fused && (rc = epilogue_x_pass(h, fused_slot))) return rc;
+    if (fused && (rc = epilogue_x_pass(h, fused_slot, groups))) return rc;
     h->cur = nullptr;
     h->ctr.slice_steps += (uint64_t)P * nz;
-    h->ctr.frames += 1;
-    h->ctr.algorithmic_bytes += (uint64_t)P * nz * 16ull * npix + (uint64_t)nz * 8ull * npix + (fused ? (uint64_t)P * 16ull * npix : 0ull);
+    h->ctr.frames += groups;
+    h->ctr.algorithmic_bytes += (uint64_t)P * nz * 16ull * npix + (uint64_t)groups * nz * 8ull * npix + (fused ? (uint64_t)P * 16ull * npix : 0ull);
     return MSL_OK;
 }
 
@@ -811,11 +836,12 @@ int ensure_atoms(msl_handle* h, size_t n) {
 }
 
 // The slice loop (generic kernels).  fused_slot < 0: leave real-space exit waves in psi.
-int slice_loop(msl_handle* h, int fused_slot) {
-    if (h->onepass) return slice_loop_onepass(h, fused_slot);
+int slice_loop(msl_handle* h, int fused_slot, int groups, int first_group) {
+    if (h->onepass) return slice_loop_onepass(h, fused_slot, groups, first_group);
     const msl_config& c = h->cfg;
-    const int P = c.n_probes, nz = c.nz;
+    const int P = c.n_probes * groups, nz = c.nz;
     const size_t npix = (size_t)c.nx * c.ny;
+    const size_t toff = (size_t)first_group * c.nz * npix;
     HIPCHK(h, hipMemcpyAsync(h->psi, h->psi0, (size_t)P * c.nx * h->pitch * sizeof(float2), hipMemcpyDeviceToDevice, h->stream));
     int rc = begin_timed(h, 2 * nz + 2);
     if (rc) return rc;
@@ -824,13 +850,15 @@ int slice_loop(msl_handle* h, int fused_slot) {
         const bool last = (z == nz - 1);
         if (h->Ry) {
             RowJob r = row_job(h, h->psi, P, h->pitch);
-            r.do_ifft = z > 0; r.trans = h->trans + (size_t)z * npix;
+            r.do_ifft = z > 0; r.trans = h->trans + toff + (size_t)z * npix;
             r.do_fft = (!last || fused); r.py = last ? nullptr : h->pyt;
+            if (groups > 1) { r.t_group = c.n_probes; r.t_stride = (long long)c.nz * npix; }
             if ((rc = launch_row_fast(h, r, K_ROW))) return rc;
         } else {
             LineArgs r = row_args(h, h->psi, h->psi, P, h->pitch);
             r.fft1 = (z > 0) ? -1 : 0;
-            r.m1_kind = MUL_ARRAY; r.m1 = h->trans + (size_t)z * npix; r.m1_ls = c.ny;
+            r.m1_kind = MUL_ARRAY; r.m1 = h->trans + toff + (size_t)z * npix; r.m1_ls = c.ny;
+            if (groups > 1) { r.group = c.n_probes; r.m_gs = (long long)c.nz * npix; r.out_gs = (long long)c.n_probes * r.out_is; }
             if (!last) { r.fft2 = +1; r.m2_kind = MUL_VEC; r.m2 = h->pyt; }
             else if (fused) { r.fft2 = +1; }
             if ((rc = launch_lines(h, h->plan_y, r, K_ROW))) return rc;
@@ -849,12 +877,12 @@ int slice_loop(msl_handle* h, int fused_slot) {
     }
     if (fused) {
         // epilogue: fft along x, fftshift both axes, scatter into (P, T_local, nx, ny)
-        if ((rc = epilogue_x_pass(h, fused_slot))) return rc;
+        if ((rc = epilogue_x_pass(h, fused_slot, groups))) return rc;
     }
     h->cur = nullptr;
     h->ctr.slice_steps += (uint64_t)P * nz;
-    h->ctr.frames += 1;
-    h->ctr.algorithmic_bytes += (uint64_t)P * nz * 32ull * npix + (uint64_t)nz * 8ull * npix + (fused ? (uint64_t)P * 16ull * npix : 0ull);
+    h->ctr.frames += groups;
+    h->ctr.algorithmic_bytes += (uint64_t)P * nz * 32ull * npix + (uint64_t)groups * nz * 8ull * npix + (fused ? (uint64_t)P * 16ull * npix : 0ull);
     return MSL_OK;
 }
 
@@ -926,6 +954,7 @@ int msl_create(const msl_config* cfg, msl_handle** out) {
     msl_handle* h = new (std::nothrow) msl_handle();
     if (!h) return fail(nullptr, MSL_ERR_NOMEM, "msl_create: out of host memory");
     h->cfg = *cfg;
+    h->FB = (cfg->frame_batch > 1 && !cfg->keep_potential) ? cfg->frame_batch : 1;
     // k-window, centred on the DC pixel of the fftshifted spectrum (index n/2): [n/2 - w/2, n/2 - w/2 + w)
     h->wx = cfg->window_nx ? cfg->window_nx : cfg->nx;
     h->wy = cfg->window_ny ? cfg->window_ny : cfg->ny;
@@ -1000,15 +1029,16 @@ int msl_create(const msl_config* cfg, msl_handle** out) {
         h->onepass = want && (h->opx.R || h->opx.generic) && (h->opy.R || h->opy.generic) && !cfg->keep_potential;
         h->scheme_b = h->onepass && (h->opx.two || h->opy.two || h->opx.generic || h->opy.generic);
         if (h->pitch == cfg->ny && h->onepass) h->pitch = cfg->ny + 16;        // pad the work buffers of 2R^2 grids too
-        if ((rc = dalloc(h, &h->psi0, (size_t)cfg->nx * h->pitch * cfg->n_probes))) return bail(rc);
-        if ((rc = dalloc(h, &h->psi, (size_t)cfg->nx * h->pitch * cfg->n_probes))) return bail(rc);
+        const size_t images = (size_t)cfg->n_probes * h->FB;
+        if ((rc = dalloc(h, &h->psi0, (size_t)cfg->nx * h->pitch * images))) return bail(rc);
+        if ((rc = dalloc(h, &h->psi, (size_t)cfg->nx * h->pitch * images))) return bail(rc);
         if (h->onepass) {
             h->pitchT = cfg->nx + (h->pitch - cfg->ny);
-            if ((rc = dalloc(h, &h->psiT, (size_t)cfg->ny * h->pitchT * cfg->n_probes))) return bail(rc);
+            if ((rc = dalloc(h, &h->psiT, (size_t)cfg->ny * h->pitchT * images))) return bail(rc);
             // transposed probes: only when the first pass runs along x (alternating scheme with an even slice count)
             h->need_psi0T = !h->scheme_b && (cfg->nz % 2 == 0);
-            if (h->need_psi0T && (rc = dalloc(h, &h->psi0T, (size_t)cfg->ny * h->pitchT * cfg->n_probes))) return bail(rc);
-            if ((rc = dalloc(h, &h->transT, npix * cfg->nz))) return bail(rc);
+            if (h->need_psi0T && (rc = dalloc(h, &h->psi0T, (size_t)cfg->ny * h->pitchT * images))) return bail(rc);
+            if ((rc = dalloc(h, &h->transT, npix * cfg->nz * h->FB))) return bail(rc);
             { const char* ev = getenv("MSL_ROWT_VARIANT"); if (ev) h->rowT_variant = atoi(ev); }
             { const char* ev = getenv("MSL_ROWT_PAIRED"); if (ev) h->rowT_paired = atoi(ev); }
             { const char* ev = getenv("MSL_DEBUG_FLAGS_MASK"); if (ev) h->debug_flags_mask = atoi(ev); }
@@ -1016,7 +1046,7 @@ int msl_create(const msl_config* cfg, msl_handle** out) {
             (void)hipFuncSetAttribute((const void*)row_pass2_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
         }
     }
-    if ((rc = dalloc(h, &h->trans, npix * cfg->nz))) return bail(rc);
+    if ((rc = dalloc(h, &h->trans, npix * cfg->nz * h->FB))) return bail(rc);
     if (cfg->keep_potential && (rc = dalloc(h, &h->V, npix * cfg->nz))) return bail(rc);
     if (cfg->n_frames > 0) {
         if ((rc = dalloc(h, &h->wf, h->wpix * cfg->n_probes * cfg->n_frames))) return bail(rc);
@@ -1060,6 +1090,7 @@ int msl_set_kirkland(msl_handle* h, const double* abcd) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->have_kirkland = true;
     h->n_species = 0;
+    h->ff_n = 0;
     return MSL_OK;
 }
 
@@ -1102,11 +1133,12 @@ int msl_resize_probes(msl_handle* h, int32_t n_probes) {
     HIPCHK(h, hipSetDevice(h->cfg.device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     int rc;
-    if ((rc = dalloc(h, &h->psi0, (size_t)h->cfg.nx * h->pitch * n_probes))) return rc;
-    if ((rc = dalloc(h, &h->psi, (size_t)h->cfg.nx * h->pitch * n_probes))) return rc;
+    const size_t images = (size_t)n_probes * h->FB;
+    if ((rc = dalloc(h, &h->psi0, (size_t)h->cfg.nx * h->pitch * images))) return rc;
+    if ((rc = dalloc(h, &h->psi, (size_t)h->cfg.nx * h->pitch * images))) return rc;
     if (h->onepass) {
-        if ((rc = dalloc(h, &h->psiT, (size_t)h->cfg.ny * h->pitchT * n_probes))) return rc;
-        if (h->need_psi0T && (rc = dalloc(h, &h->psi0T, (size_t)h->cfg.ny * h->pitchT * n_probes))) return rc;
+        if ((rc = dalloc(h, &h->psiT, (size_t)h->cfg.ny * h->pitchT * images))) return rc;
+        if (h->need_psi0T && (rc = dalloc(h, &h->psi0T, (size_t)h->cfg.ny * h->pitchT * images))) return rc;
     }
     if ((rc = dalloc(h, &h->d_xy, (size_t)2 * n_probes))) return rc;
     h->cfg.n_probes = n_probes;
@@ -1186,6 +1218,8 @@ int msl_build_potential(msl_handle* h, const double* pos, const int32_t* Z, int6
     const msl_config& c = h->cfg;
     HIPCHK(h, hipSetDevice(c.device));
     const size_t npix = (size_t)c.nx * c.ny;
+    float2* const TR = h->trans + (size_t)h->cur_batch * c.nz * npix;                 // batch slot this frame's stack goes to
+    float2* const TRT = h->transT ? h->transT + (size_t)h->cur_batch * c.nz * npix : nullptr;
     // species present (sorted ascending, like np.unique)
     int z2s[104];
     for (int i = 0; i < 104; ++i) z2s[i] = -1;
@@ -1206,6 +1240,7 @@ int msl_build_potential(msl_handle* h, const double* pos, const int32_t* Z, int6
     if (nsp > h->ff_species_cap) {
         if ((rc = dalloc(h, &h->d_ff, npix * nsp))) return rc;
         h->ff_species_cap = nsp;
+        h->ff_n = 0;
     }
     const int nkeys = c.nz * std::max(nsp, 1);
     if (nkeys > h->keys_cap) {
@@ -1243,9 +1278,15 @@ int msl_build_potential(msl_handle* h, const double* pos, const int32_t* Z, int6
             st.used = true;
         }
         const double lx = c.nx * c.dx, ly = c.ny * c.dy;
-        long long tot = (long long)npix * nsp;
-        hipLaunchKernelGGL(formfactor_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, h->d_ff, h->d_abcd,
-                           h->d_species, nsp, c.nx, c.ny, 1.0 / lx, 1.0 / ly);
+        // f_Z(q^2) depends on the grid and the species only (potentials.py:283-293 recomputes it per frame): build the table
+        // when the species list changes, i.e. once per run
+        if (nsp != h->ff_n || memcmp(species, h->ff_species, nsp * sizeof(int)) != 0) {
+            long long tot = (long long)npix * nsp;
+            hipLaunchKernelGGL(formfactor_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, h->d_ff, h->d_abcd,
+                               h->d_species, nsp, c.nx, c.ny, 1.0 / lx, 1.0 / ly);
+            memcpy(h->ff_species, species, nsp * sizeof(int));
+            h->ff_n = nsp;
+        }
         hipLaunchKernelGGL(atom_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d_pos, h->d_Z,
                            (long long)n, h->d_z2s, h->d_lo, h->d_hi, c.nz, nsp, ax1, ax2, axs, 1.0 / lx, 1.0 / ly, h->d_key,
                            h->d_u1, h->d_u2, h->d_counts);
@@ -1268,43 +1309,43 @@ int msl_build_potential(msl_handle* h, const double* pos, const int32_t* Z, int6
             const bool use_mfma = hermitian && (c.ny % 32 == 0) && !getenv("MSL_NO_MFMA");
             if (use_mfma) {
                 const int ty32 = c.ny / 32, n_tiles = (c.nx / 2 / 32) * ty32;
-                hipLaunchKernelGGL(structure_factor_mfma_kernel, dim3((n_tiles + 3) / 4, c.nz), dim3(256), 0, h->stream, h->trans,
+                hipLaunchKernelGGL(structure_factor_mfma_kernel, dim3((n_tiles + 3) / 4, c.nz), dim3(256), 0, h->stream, TR,
                                    h->d_ex, h->d_ey, h->d_ff, h->d_start, nsp, c.nx, c.ny, ty32, n_tiles);
             } else {
-                hipLaunchKernelGGL(structure_factor_kernel, dim3(tiles_x * tiles_y, c.nz), dim3(256), 0, h->stream, h->trans, h->d_ex,
+                hipLaunchKernelGGL(structure_factor_kernel, dim3(tiles_x * tiles_y, c.nz), dim3(256), 0, h->stream, TR, h->d_ex,
                                    h->d_ey, h->d_ff, h->d_start, nsp, c.nx, c.ny, tiles_y);
             }
             if (hermitian) {
                 const int nb = c.ny + c.nx / 2 - 1;
-                hipLaunchKernelGGL(structure_factor_nyquist_kernel, dim3((nb + 127) / 128, c.nz), dim3(128), 0, h->stream, h->trans,
+                hipLaunchKernelGGL(structure_factor_nyquist_kernel, dim3((nb + 127) / 128, c.nz), dim3(128), 0, h->stream, TR,
                                    h->d_ex, h->d_ey, h->d_ff, h->d_start, nsp, c.nx, c.ny);
                 hipLaunchKernelGGL(structure_factor_mirror_kernel, dim3((c.ny + 255) / 256, c.nx / 2 - 1, c.nz), dim3(256), 0,
-                                   h->stream, h->trans, c.nx, c.ny);
+                                   h->stream, TR, c.nx, c.ny);
             }
             HIPCHK(h, hipGetLastError());
         }
     }
-    if (!recip_written) HIPCHK(h, hipMemsetAsync(h->trans, 0, npix * c.nz * sizeof(float2), h->stream));
+    if (!recip_written) HIPCHK(h, hipMemsetAsync(TR, 0, npix * c.nz * sizeof(float2), h->stream));
     h->n_species = nsp;
     // V_s = Re ifft2(R_s) / (dx^2 dy^2);  t_s = exp(i sigma V_s)  -- in place over the (nz,nx,ny) buffer
     const float vscale = (float)(1.0 / ((double)c.nx * c.ny) / (c.dx * c.dx * c.dy * c.dy));
     h->cur = nullptr;
     if (h->Ry) {
-        RowJob r = row_job(h, h->trans, c.nz, c.ny);
+        RowJob r = row_job(h, TR, c.nz, c.ny);
         r.do_ifft = 1;
         if ((rc = launch_row_fast(h, r, K_OTHER))) return rc;
     } else {
-        LineArgs r = row_args(h, h->trans, h->trans, c.nz, c.ny);
+        LineArgs r = row_args(h, TR, TR, c.nz, c.ny);
         r.fft1 = -1;
         if ((rc = launch_lines(h, h->plan_y, r, K_OTHER))) return rc;
     }
     if (h->Rx) {
-        ColJob k = col_job(h, h->trans, h->trans, c.nz, c.ny, c.ny);
+        ColJob k = col_job(h, TR, TR, c.nz, c.ny, c.ny);
         k.flags = COL_INV | COL_POTENTIAL; k.scale = vscale; k.sigma = (float)c.sigma; k.out_real = h->V;
-        if (h->onepass) { k.flags |= COL_TPOT; k.tparity = h->scheme_b ? 0 : ((c.nz - 1) & 1); k.out_t = h->transT; }
+        if (h->onepass) { k.flags |= COL_TPOT; k.tparity = h->scheme_b ? 0 : ((c.nz - 1) & 1); k.out_t = TRT; }
         if ((rc = launch_col_fast(h, k, K_OTHER))) return rc;
     } else {
-        LineArgs k = col_args(h, h->trans, h->trans, c.nz, c.ny, c.ny);
+        LineArgs k = col_args(h, TR, TR, c.nz, c.ny, c.ny);
         k.fft1 = -1;
         k.scale = vscale;
         k.store_mode = STORE_POTENTIAL; k.out_real = h->V; k.sigma = (float)c.sigma;
@@ -1332,8 +1373,8 @@ int msl_upload_potential(msl_handle* h, const float* V) {
     float* tmp = nullptr;
     if (!dst) { int rc = dalloc(h, &tmp, n); if (rc) return rc; dst = tmp; }
     HIPCHK(h, hipMemcpyAsync(dst, V, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(transmission_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->trans, dst, (long long)n,
-                       (float)c.sigma);
+    hipLaunchKernelGGL(transmission_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->trans + (size_t)h->cur_batch * n, dst,
+                       (long long)n, (float)c.sigma);
     HIPCHK(h, hipGetLastError());
     { int rc = transpose_odd_slices(h); if (rc) return rc; }
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1342,16 +1383,17 @@ int msl_upload_potential(msl_handle* h, const float* V) {
     return MSL_OK;
 }
 
-static int run_loop(msl_handle* h, int slot) {
+static int run_loop(msl_handle* h, int slot, int groups = 1) {
     if (!h) return fail(h, MSL_ERR_INVALID, "null handle");
+    const int first_group = groups > 1 ? 0 : h->cur_batch;
     if (!h->have_probes) return fail(h, MSL_ERR_STATE, "propagate: no probes (msl_set_probes / msl_upload_probes)");
     if (!h->have_potential) return fail(h, MSL_ERR_STATE, "propagate: no potential (msl_build_potential / msl_upload_potential)");
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    if (!h->cfg.launch_timing) return slice_loop(h, slot);         // queued; msl_synchronize / msl_download wait for it
+    if (!h->cfg.launch_timing) return slice_loop(h, slot, groups, first_group);         // queued; msl_synchronize / msl_download wait for it
     hipEvent_t e0, e1;
     HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
     HIPCHK(h, hipEventRecord(e0, h->stream));
-    int rc = slice_loop(h, slot);
+    int rc = slice_loop(h, slot, groups, first_group);
     if (rc) return rc;
     HIPCHK(h, hipEventRecord(e1, h->stream));
     HIPCHK(h, hipEventSynchronize(e1));
@@ -1373,6 +1415,25 @@ int msl_propagate_frame(msl_handle* h, int32_t slot) {
     if (!h->wf) return fail(h, MSL_ERR_STATE, "msl_propagate_frame: handle created with n_frames == 0");
     if (slot < 0 || slot >= h->cfg.n_frames) return fail(h, MSL_ERR_INVALID, "msl_propagate_frame: slot %d out of range [0,%d)", slot, h->cfg.n_frames);
     return run_loop(h, slot);
+}
+
+int msl_select_batch_slot(msl_handle* h, int32_t b) {
+    if (!h) return fail(h, MSL_ERR_INVALID, "null handle");
+    if (b < 0 || b >= h->FB) return fail(h, MSL_ERR_INVALID, "msl_select_batch_slot: slot %d out of range [0,%d)", b, h->FB);
+    h->cur_batch = b;
+    return MSL_OK;
+}
+
+int msl_frame_batch(const msl_handle* h) { return h ? h->FB : 0; }
+
+int msl_propagate_frames(msl_handle* h, int32_t first_slot, int32_t count) {
+    if (!h) return fail(h, MSL_ERR_INVALID, "null handle");
+    if (!h->wf) return fail(h, MSL_ERR_STATE, "msl_propagate_frames: handle created with n_frames == 0");
+    if (count < 1 || count > h->FB) return fail(h, MSL_ERR_INVALID, "msl_propagate_frames: count %d outside [1,%d] (msl_config.frame_batch)", count, h->FB);
+    if (first_slot < 0 || first_slot + count > h->cfg.n_frames)
+        return fail(h, MSL_ERR_INVALID, "msl_propagate_frames: slots [%d,%d) outside [0,%d)", first_slot, first_slot + count, h->cfg.n_frames);
+    if (count == 1) { const int saved = h->cur_batch; h->cur_batch = 0; int rc = run_loop(h, first_slot, 1); h->cur_batch = saved; return rc; }
+    return run_loop(h, first_slot, count);
 }
 
 int msl_tacaw(msl_handle* h, const void* d_src, void* d_dst, int64_t batch, int32_t T, int64_t npix) {
@@ -1461,7 +1522,7 @@ void* msl_device_ptr(msl_handle* h, msl_buffer what) {
         case MSL_BUF_PROBES: return h->psi0;
         case MSL_BUF_EXIT: return h->psi;
         case MSL_BUF_POTENTIAL: return h->V;
-        case MSL_BUF_TRANSMISSION: return h->trans;
+        case MSL_BUF_TRANSMISSION: return h->trans ? h->trans + (size_t)h->cur_batch * h->cfg.nz * h->cfg.nx * h->cfg.ny : nullptr;
         case MSL_BUF_WAVEFUNCTION: return h->wf;
         case MSL_BUF_INTENSITY: return h->intensity;
         case MSL_BUF_FORMFACTOR: return h->d_ff;
@@ -1612,7 +1673,7 @@ int msl_download(msl_handle* h, msl_buffer what, void* dst, size_t bytes, int64_
         for (int z0 = 0; z0 < count; z0 += 65535) {
             const int nzb = std::min(65535, count - z0);
             dim3 grid((h->cfg.nx + 31) / 32, (h->cfg.ny + 31) / 32, nzb);
-            const size_t off = (size_t)(first + 2 * z0) * npix;
+            const size_t off = (size_t)h->cur_batch * h->cfg.nz * npix + (size_t)(first + 2 * z0) * npix;
             hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, h->stream, h->transT + off, h->trans + off,
                                h->cfg.ny, h->cfg.nx, h->cfg.nx, h->cfg.ny, (long long)(2 * npix), (long long)(2 * npix));
         }

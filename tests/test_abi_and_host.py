@@ -32,7 +32,7 @@ def test_struct_layouts_match_header(lib):
     """ctypes mirrors of msl_config / msl_counters have the C sizes (guards silent ABI drift)."""
     import ctypes as C
     from pyslice_amd import _native
-    assert C.sizeof(_native.MslConfig) == 3 * 4 + 4 + 5 * 8 + 5 * 4 + 7 * 4     # 3 ints (+pad), 5 doubles, 5+7 ints
+    assert C.sizeof(_native.MslConfig) == 3 * 4 + 4 + 5 * 8 + 5 * 4 + 7 * 4     # 3 ints (+pad), 5 doubles, 5+7 ints (frame_batch took one reserved slot)
     assert C.sizeof(_native.MslCounters) == 12 * 8
 
 

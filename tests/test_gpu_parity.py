@@ -369,6 +369,41 @@ def test_paired_lines_kernel_matches_oracle(ps, orc, nz, monkeypatch):
     assert ref_residual(got, want) < RESID_TOL
 
 
+@pytest.mark.parametrize("nx,ny,nz,P,B", [(256, 256, 5, 1, 4), (256, 256, 4, 3, 2), (512, 512, 3, 1, 3), (512, 512, 4, 2, 4),
+                                          (1024, 1024, 3, 1, 2), (1024, 256, 4, 1, 3), (96, 80, 3, 2, 4), (45, 63, 2, 1, 5),
+                                          (501, 64, 2, 1, 2), (2048, 512, 2, 1, 2), (256, 256, 1, 1, 4)])
+def test_frame_batching_matches_oracle(ps, orc, nx, ny, nz, P, B):
+    """frame_batch = B: B MD frames share every slice-loop launch (image = frame x probe, one transmission stack per
+    frame).  5 frames, so the last batch is short; register kernels (256, 512, 1024, 2048 lines), the generic kernel and
+    Bluestein lines; against the oracle, and bit-identical to the unbatched run."""
+    from pyslice_amd.synthetic import synthetic_trajectory
+    tr = synthetic_trajectory(nx, nz, 5, ny=ny, density=0.05, seed=90 + nz)
+    lx, ly = tr.box_matrix[0, 0], tr.box_matrix[1, 1]
+    pp = [tuple(v) for v in np.random.default_rng(4).random((P, 2)) * [lx, ly]]
+    out = []
+    for fb in (B, 1):
+        calc = ps.MultisliceCalculator(progress=False, dtype="complex64", frame_batch=fb)
+        calc.setup(tr, aperture=30.0, voltage_eV=100e3, probe_positions=pp)
+        assert calc._engine.frame_batch == fb
+        out.append(npy(calc.run().wavefunction_data))
+    assert np.array_equal(out[0], out[1])
+    want = orc.run_frames(tr.box_matrix, tr.positions, tr.atom_types, 30.0, 100e3, pp)["wavefunction_data"]
+    assert rel_l2(out[0], want) < WAVE_TOL
+
+
+def test_frame_batching_default_for_single_probe_runs(ps, orc):
+    """the reference's default (probe_positions=None: one probe) batches frames automatically; results unchanged"""
+    from pyslice_amd.synthetic import synthetic_trajectory
+    tr = synthetic_trajectory(256, 6, 70, density=0.03, seed=12)
+    calc = ps.MultisliceCalculator(progress=False)
+    calc.setup(tr, aperture=30.0, voltage_eV=100e3)
+    assert calc._engine.frame_batch == 64
+    got = npy(calc.run().wavefunction_data)
+    idx = [0, 1, 63, 64, 69]
+    want = orc.run_frames(tr.box_matrix, tr.positions, tr.atom_types, 30.0, 100e3, None, frames=idx)["wavefunction_data"]
+    assert rel_l2(got[:, idx], want) < WAVE_TOL
+
+
 def test_calculator_oracle_parity_onepass_nonsquare(ps, orc):
     """256 x 1024 grid: the transposing passes alternate between the R=16 (x lines) and R=32 (y lines) kernels."""
     from pyslice_amd.synthetic import synthetic_trajectory
