@@ -66,7 +66,10 @@ typedef struct {
                                 * otherwise launch-bound.  Potentials are built into batch slots (msl_select_batch_slot) and run by
                                 * msl_propagate_frames.  Costs B x the work buffers and transmission stacks.  0 / 1 = off; ignored
                                 * (treated as 1) with keep_potential. */
-    int32_t reserved[3];
+    int32_t bin_nx, bin_ny;    /* detector binning: every stored pixel is the sum of bin_nx x bin_ny neighbouring pixels of the
+                                * fftshifted spectrum (of the k-window, when there is one; the window must be a multiple of the bin).  The
+                                * result, intensity and frame buffers then have shape (.., wx/bin_nx, wy/bin_ny).  0 / 1 = off. */
+    int32_t reserved[1];
 } msl_config;
 
 typedef enum {
@@ -174,9 +177,22 @@ int  msl_frame_batch(const msl_handle* h);
  * Replaces TACAWData.fft_from_wf_data (tacaw_data.py:89-104). */
 int  msl_tacaw(msl_handle* h, const void* d_src_c64, void* d_dst_f32, int64_t batch, int32_t T, int64_t npix);
 
+/* Streaming TACAW: the time -> frequency transform accumulated tile of frames by tile of frames, for n_bins
+ * chosen frequency bins, so that the handle holds a ring of frame slots (msl_config.n_frames = tile length) and the
+ * accumulators instead of every frame (the reference needs the whole (P,T,nx,ny) array: tacaw_data.py:94-96).
+ *   begin:  T_total = frames of the run, bins = n_bins unshifted FFT bin numbers u in [0,T_total) (NULL: all T_total);
+ *   push:   folds the frames in slots [first_slot, first_slot+count), whose time indices are t0, t0+1, ..;
+ *   finish: intensity[p,i,k] = | sum_t Psi[p,t,k] exp(-2 pi i bins[i] t / T) |^2 (0 for bin 0: mean subtraction) becomes the
+ *           handle's intensity buffer, shape (P, n_bins, K), ready for the reductions below; total_PK (host, P*K float64,
+ *           may be NULL) receives sum over ALL T_total bins of the intensity (Parseval: T sum|Psi|^2 - |sum Psi|^2), i.e.
+ *           TACAWData.diffraction() of the full transform without any of it being stored. */
+int  msl_tacaw_stream_begin(msl_handle* h, int32_t T_total, int32_t n_bins, const int32_t* bins);
+int  msl_tacaw_stream_push(msl_handle* h, int32_t first_slot, int32_t count, int32_t t0);
+int  msl_tacaw_stream_finish(msl_handle* h, double* total_PK);
+
 /* ---- consumers of the resident results: reductions that stream the array once on the device ----
  * The TACAW reductions take a (B,F,K) float32 intensity array: d_src == NULL selects the handle's own intensity buffer
- * (B=P, F=T, K=nx*ny, after msl_tacaw); otherwise a caller-held device pointer with the given shape.  Results are
+ * (B=P, F=T after msl_tacaw or n_bins after msl_tacaw_stream_finish, K=stored pixels); otherwise a caller-held device pointer with the given shape.  Results are
  * written to HOST memory; sums are accumulated in float64 like the reference's.
  *
  * msl_tacaw_spectrum: out[b*F+f] = sum_k w(k) I[b,f,k], w = 1 or mask[k] != 0 (mask: K host bytes or NULL).

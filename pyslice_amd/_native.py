@@ -25,6 +25,7 @@ EXPORTS = [
     "msl_reset_counters", "msl_fft2_host",
     "msl_tacaw_spectrum", "msl_tacaw_diffraction", "msl_tacaw_dispersion", "msl_adf",
     "msl_select_batch_slot", "msl_propagate_frames", "msl_frame_batch",
+    "msl_tacaw_stream_begin", "msl_tacaw_stream_push", "msl_tacaw_stream_finish",
 ]
 
 
@@ -35,7 +36,7 @@ class MslConfig(C.Structure):
                 ("n_probes", C.c_int32), ("n_frames", C.c_int32), ("device", C.c_int32),
                 ("keep_potential", C.c_int32), ("fft_path", C.c_int32),
                 ("window_nx", C.c_int32), ("window_ny", C.c_int32), ("launch_timing", C.c_int32),
-                ("frame_batch", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("frame_batch", C.c_int32), ("bin_nx", C.c_int32), ("bin_ny", C.c_int32), ("reserved", C.c_int32 * 1)]
 
 
 class MslCounters(C.Structure):
@@ -94,6 +95,9 @@ def load():
         "msl_select_batch_slot": (C.c_int, [vp, i32]),
         "msl_propagate_frames": (C.c_int, [vp, i32, i32]),
         "msl_frame_batch": (C.c_int, [vp]),
+        "msl_tacaw_stream_begin": (C.c_int, [vp, i32, i32, vp]),
+        "msl_tacaw_stream_push": (C.c_int, [vp, i32, i32, i32]),
+        "msl_tacaw_stream_finish": (C.c_int, [vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -121,7 +125,7 @@ class Engine:
     """One libmslice handle: one HIP device, one stream, all device buffers of one grid."""
 
     def __init__(self, nx, ny, nz, dx, dy, dz, wavelength, sigma, n_probes=1, n_frames=0, device=0,
-                 keep_potential=False, fft_path=0, window=None, launch_timing=False, frame_batch=1):
+                 keep_potential=False, fft_path=0, window=None, launch_timing=False, frame_batch=1, k_bin=None):
         self._lib = load()
         self._h = C.c_void_p()
         cfg = MslConfig(nx=int(nx), ny=int(ny), nz=int(nz), dx=float(dx), dy=float(dy), dz=float(dz),
@@ -129,7 +133,7 @@ class Engine:
                         n_frames=int(n_frames), device=int(device), keep_potential=int(bool(keep_potential)),
                         fft_path=int(fft_path), window_nx=int(window[0]) if window else 0,
                         window_ny=int(window[1]) if window else 0, launch_timing=int(bool(launch_timing)),
-                        frame_batch=int(frame_batch))
+                        frame_batch=int(frame_batch), bin_nx=int(k_bin[0]) if k_bin else 0, bin_ny=int(k_bin[1]) if k_bin else 0)
         rc = self._lib.msl_create(C.byref(cfg), C.byref(self._h))
         if rc != MSL_OK:
             msg = (self._lib.msl_last_error(None) or b"msl_create failed").decode()
@@ -138,9 +142,13 @@ class Engine:
         self.nx, self.ny, self.nz = int(nx), int(ny), int(nz)
         self.n_probes, self.n_frames, self.device = int(n_probes), int(n_frames), int(device)
         self.keep_potential = bool(keep_potential)
-        # stored shape of one exit-wave spectrum: the k-window, or the whole grid
+        # stored shape of one exit-wave spectrum: the k-window, or the whole grid, divided by the detector bin
         self.wx = int(window[0]) if window and window[0] else self.nx
         self.wy = int(window[1]) if window and window[1] else self.ny
+        if k_bin:
+            self.wx //= max(1, int(k_bin[0]))
+            self.wy //= max(1, int(k_bin[1]))
+        self.intensity_F = 0               # frequency bins of the resident intensity buffer
         self.frame_batch = int(self._lib.msl_frame_batch(self._h))      # frames that share one sequence of launches
 
     # -- lifetime
@@ -236,6 +244,25 @@ class Engine:
     def tacaw(self, src_ptr=None, dst_ptr=None, batch=0, T=0, npix=0):
         self._chk(self._lib.msl_tacaw(self._h, C.c_void_p(src_ptr) if src_ptr else None,
                                       C.c_void_p(dst_ptr) if dst_ptr else None, int(batch), int(T), int(npix)))
+        if not src_ptr:
+            self.intensity_F = self.n_frames
+
+    # -- streaming TACAW: accumulate the time->frequency transform for chosen bins, tile of frames by tile of frames
+    def tacaw_stream_begin(self, T_total, bins=None):
+        b = None if bins is None else np.ascontiguousarray(bins, dtype=np.int32).reshape(-1)
+        self._chk(self._lib.msl_tacaw_stream_begin(self._h, int(T_total), 0 if b is None else b.size, _ptr(b) if b is not None else None))
+        self._stream_F = int(T_total) if b is None else int(b.size)
+
+    def tacaw_stream_push(self, first_slot, count, t0):
+        self._chk(self._lib.msl_tacaw_stream_push(self._h, int(first_slot), int(count), int(t0)))
+
+    def tacaw_stream_finish(self, want_total=True):
+        """-> (P, wx, wy) float64: sum over ALL frequency bins of the intensity (or None); the selected bins become the
+        resident intensity buffer (P, n_bins, wx, wy)"""
+        tot = np.empty((self.n_probes, self.wx, self.wy), dtype=np.float64) if want_total else None
+        self._chk(self._lib.msl_tacaw_stream_finish(self._h, _ptr(tot) if tot is not None else None))
+        self.intensity_F = self._stream_F
+        return tot
 
     # -- reductions over resident results; src = (device pointer, B, F, K) or None for the handle's own buffer
     @staticmethod
@@ -246,7 +273,7 @@ class Engine:
         return C.c_void_p(int(ptr)), int(B), int(F), int(K)
 
     def _bfk(self, src):
-        return (self.n_probes, self.n_frames, self.wx * self.wy) if src is None else tuple(int(v) for v in src[1:])
+        return (self.n_probes, self.intensity_F, self.wx * self.wy) if src is None else tuple(int(v) for v in src[1:])
 
     def tacaw_spectrum(self, mask=None, src=None):
         """(B,F) float64: sum over k of the (masked) intensity."""
@@ -332,7 +359,7 @@ class Engine:
 
     def intensity(self, first=0, count=0):
         n = count if count else self.n_probes
-        return self.download(BUF_INTENSITY, np.float32, (n, self.n_frames, self.wx, self.wy), first, count)
+        return self.download(BUF_INTENSITY, np.float32, (n, self.intensity_F, self.wx, self.wy), first, count)
 
     def form_factors(self, n_species):
         return self.download(BUF_FORMFACTOR, np.float32, (n_species, self.nx, self.ny))

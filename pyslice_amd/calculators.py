@@ -36,7 +36,7 @@ logger = logging.getLogger(__name__)
 class MultisliceCalculator:
 
     def __init__(self, device=None, force_cpu=False, *, output="host", dtype="complex128", progress=True,
-                 gather="rank0", cache=False, k_window=None, frame_batch=None):
+                 gather="rank0", cache=False, k_window=None, frame_batch=None, k_bin=None, stream_tile=None):
         """
         device / force_cpu: as the reference (calculators.py:41).  There is no CPU path here, so
         force_cpu=True raises.  Keyword-only extras (not in the reference):
@@ -72,6 +72,18 @@ class MultisliceCalculator:
                 raise ValueError("the frame cache stores full (P,nx,ny,1,1) frames: cache=True cannot be combined with k_window")
             k_window = (int(k_window[0]), int(k_window[1]))
         self._k_window = k_window
+        if k_bin is not None:
+            if len(k_bin) != 2 or int(k_bin[0]) < 1 or int(k_bin[1]) < 1:
+                raise ValueError("k_bin must be two positive pixel counts (bx, by)")
+            if cache:
+                raise ValueError("the frame cache stores full (P,nx,ny,1,1) frames: cache=True cannot be combined with k_bin")
+            k_bin = (int(k_bin[0]), int(k_bin[1]))
+        self._k_bin = k_bin
+        if stream_tile is not None and int(stream_tile) < 1:
+            raise ValueError("stream_tile must be a positive frame count")
+        if stream_tile is not None and cache:
+            raise ValueError("stream_tile cannot be combined with cache=True")
+        self._stream_tile = None if stream_tile is None else int(stream_tile)
         if frame_batch is not None and int(frame_batch) < 1:
             raise ValueError("frame_batch must be a positive frame count")
         self._frame_batch = None if frame_batch is None else int(frame_batch)
@@ -157,10 +169,20 @@ class MultisliceCalculator:
             # about 64 images per launch, at most 16 GB for the two orientations of the batch's transmission stacks
             batch = max(1, min(-(-64 // self.n_probes), int(16e9 // (16.0 * n_slices * nx * ny))))
         batch = 1 if self._cache else max(1, min(batch, len(self._frames)))
+        slots = max(1, len(self._frames))
+        if self._stream_tile is not None:
+            if self._world > 1:
+                raise NotImplementedError("streaming TACAW runs in one process (shard probes over processes instead)")
+            slots = max(1, min(self._stream_tile, slots))
+            batch = min(batch, slots)
+        if self._k_bin is not None:
+            wx, wy = self._k_window if self._k_window is not None else (nx, ny)
+            if wx % self._k_bin[0] or wy % self._k_bin[1]:
+                raise ValueError(f"the stored spectrum {wx} x {wy} is not a multiple of k_bin {self._k_bin}")
         self._engine = _native.Engine(nx, ny, n_slices, self.dx, self.dy, dz, wavelength(voltage_eV),
                                       interaction_sigma(voltage_eV), n_probes=self.n_probes,
-                                      n_frames=max(1, len(self._frames)), device=_device_index(dev),
-                                      window=self._k_window, frame_batch=batch)
+                                      n_frames=slots, device=_device_index(dev),
+                                      window=self._k_window, frame_batch=batch, k_bin=self._k_bin)
         self._engine.set_kirkland(loadKirkland())
         lo, hi = slice_edges(slice_coords)
         self._engine.set_slices(lo, hi)
@@ -171,6 +193,8 @@ class MultisliceCalculator:
         """reference calculators.py:163-250: all frames, then pack WFData."""
         if self._engine is None:
             raise RuntimeError("call setup() before run()")
+        if self._stream_tile is not None:
+            raise RuntimeError("stream_tile is set: the device holds a ring of frames only -- call run_streaming_tacaw()")
         eng = self._engine
         t0 = time.time()
         frames = self._frames
@@ -217,11 +241,7 @@ class MultisliceCalculator:
         logger.info(f"Simulation completed in {self.elapsed:.2f}s ({self.frames_computed} computed, {self.frames_cached} cached)")
 
         # reference calculators.py:218-221 (quirk Q2: `sampling`, not dx; torch default float32)
-        kxs = np.fft.fftshift(np.fft.fftfreq(self.nx, self.sampling)).astype(np.float32)
-        kys = np.fft.fftshift(np.fft.fftfreq(self.ny, self.sampling)).astype(np.float32)
-        if self._k_window is not None:          # the window is centred on the DC pixel (index n//2 after the shift)
-            x0, y0 = self.nx // 2 - eng.wx // 2, self.ny // 2 - eng.wy // 2
-            kxs, kys = kxs[x0:x0 + eng.wx], kys[y0:y0 + eng.wy]
+        kxs, kys = self._k_axes()
         time_array = np.arange(self.n_frames) * self.trajectory.timestep
         layer_array = np.array([0])
 
@@ -236,6 +256,82 @@ class MultisliceCalculator:
         if self._world > 1 and self._gather == "none":
             wf._frame_shard = (self.n_frames, len(frames))      # lets TACAWData do the all-to-all itself
         return wf
+
+    def _k_axes(self):
+        """kxs, kys of the stored spectra: reference calculators.py:218-219 (quirk Q2), cropped to the k-window (centred on
+        the DC pixel, index n//2 after the shift) and averaged over every detector bin"""
+        kxs = np.fft.fftshift(np.fft.fftfreq(self.nx, self.sampling)).astype(np.float32)
+        kys = np.fft.fftshift(np.fft.fftfreq(self.ny, self.sampling)).astype(np.float32)
+        if self._k_window is not None:
+            wx, wy = self._k_window
+            x0, y0 = self.nx // 2 - wx // 2, self.ny // 2 - wy // 2
+            kxs, kys = kxs[x0:x0 + wx], kys[y0:y0 + wy]
+        if self._k_bin is not None:
+            kxs = kxs.reshape(-1, self._k_bin[0]).mean(axis=1).astype(np.float32)
+            kys = kys.reshape(-1, self._k_bin[1]).mean(axis=1).astype(np.float32)
+        return kxs, kys
+
+    def run_streaming_tacaw(self, freq_window=None, bins=None):
+        """Streaming TACAW (needs stream_tile): all frames are propagated through a ring of `stream_tile` frame slots and
+        folded, tile by tile, into the time->frequency transform of the selected bins.
+
+        freq_window = (lo, hi): keep the bins of TACAWData.frequencies (fftshifted, reference tacaw_data.py:84-85) with
+        lo <= f <= hi;  bins = explicit indices into that fftshifted axis;  neither: all T bins.
+        Returns a TACAWData whose `frequencies` / `intensity` hold the selected bins only ((P,F,wx,wy), device-resident
+        for the reductions), plus `total_diffraction` (P,wx,wy): the sum over ALL T bins (Parseval), i.e. what
+        TACAWData.diffraction() of the full transform returns, without the transform being stored."""
+        from .tacaw_data import TACAWData
+        if self._engine is None:
+            raise RuntimeError("call setup() before run_streaming_tacaw()")
+        if self._stream_tile is None:
+            raise RuntimeError("run_streaming_tacaw() needs MultisliceCalculator(stream_tile=Tt)")
+        eng, T = self._engine, self.n_frames
+        if T < 2:
+            raise ValueError("TACAW needs at least 2 frames")
+        time_array = np.arange(T) * self.trajectory.timestep
+        freqs = np.fft.fftshift(np.fft.fftfreq(T, d=time_array[1] - time_array[0]))
+        if bins is not None:
+            sel = np.asarray(bins, dtype=np.int64).reshape(-1)
+            if sel.size == 0 or sel.min() < 0 or sel.max() >= T:
+                raise ValueError(f"bins must be indices into the {T} fftshifted frequencies")
+        elif freq_window is not None:
+            sel = np.nonzero((freqs >= freq_window[0]) & (freqs <= freq_window[1]))[0]
+            if sel.size == 0:
+                raise ValueError(f"no frequency bin inside {freq_window}")
+        else:
+            sel = np.arange(T)
+        unshifted = (sel + (T + 1) // 2) % T              # fftshifted index s holds FFT bin (s + ceil(T/2)) mod T
+        t0 = time.time()
+        eng.tacaw_stream_begin(T, unshifted)
+        ring, B = eng.n_frames, eng.frame_batch
+        for tile0 in range(0, T, ring):
+            tile = list(range(tile0, min(T, tile0 + ring)))
+            for s0 in range(0, len(tile), B):
+                chunk = tile[s0:s0 + B]
+                if B > 1:
+                    for b, frame_idx in enumerate(chunk):
+                        eng.select_batch_slot(b)
+                        eng.build_potential(self.trajectory.positions[frame_idx], self._Z, self.slice_axis)
+                    eng.propagate_frames(s0, len(chunk))
+                else:
+                    eng.build_potential(self.trajectory.positions[chunk[0]], self._Z, self.slice_axis)
+                    eng.propagate_frame(s0)
+            eng.tacaw_stream_push(0, len(tile), tile0)
+        total = eng.tacaw_stream_finish(True)
+        self.elapsed = time.time() - t0
+        kxs, kys = self._k_axes()
+        tac = TACAWData.__new__(TACAWData)
+        tac.__dict__.update(dict(probe_positions=self.probe_positions, time=time_array, kxs=_as_tensor(kxs), kys=_as_tensor(kys),
+                                 layer=np.array([0]), wavefunction_data=None, probe=self.base_probe,
+                                 frequencies=freqs[sel], frequency_bins=sel, total_diffraction=total,
+                                 _engine=eng, _intensity_src=(eng, None), _output=self._output))
+        if self._output == "device":
+            ptr = eng.device_ptr(_native.BUF_INTENSITY)
+            tac.intensity = torch.as_tensor(_native.DeviceArray(ptr, (eng.n_probes, eng.intensity_F, eng.wx, eng.wy), "<f4", owner=eng),
+                                            device=f"cuda:{eng.device}")
+        else:
+            tac.intensity = _as_tensor(eng.intensity().astype(np.float64))
+        return tac
 
     # ------------------------------------------------------------------------------------------
     def _collect(self):

@@ -16,6 +16,7 @@
 #include "fft_pow2.h"
 #include "potential.h"
 #include "reduce.h"
+#include "stream.h"
 
 using namespace msl;
 
@@ -59,7 +60,13 @@ struct msl_handle {
     // one-pass-per-slice path (transposing passes): second work buffer in (P, ny, nx+pad) layout, transposed
     // probes and the transposed transmission slices
     int wx = 0, wy = 0, wx0 = 0, wy0 = 0;   // k-window of the stored exit-wave spectra (fftshifted coordinates)
-    size_t wpix = 0;
+    size_t wpix = 0;               // stored pixels per exit-wave spectrum: the (binned) k-window or the whole grid
+    int bx = 1, by = 1;            // detector binning: stored pixel = sum of bx x by neighbouring pixels of the window
+    float2* bin_stage = nullptr;   // binning: full-resolution window of the frames of one launch sequence, (FB*P, wx, wy)
+    // streaming TACAW
+    float2* st_acc = nullptr; double2* st_s1 = nullptr; double* st_s2 = nullptr; float2* st_tw = nullptr; int* st_bins = nullptr;
+    int st_T = 0, st_F = 0; bool st_open = false;
+    int64_t intensity_F = 0;       // frequency bins of the resident intensity buffer (T after msl_tacaw, n_bins after a stream)
     char* scratch = nullptr;       // reductions: partial sums / masks / index lists
     size_t scratch_bytes = 0;
     bool onepass = false;
@@ -513,27 +520,43 @@ int fft2_inplace(msl_handle* h, float2* buf, int images, int dir, float scale, i
 // Exit-wave epilogue, second half: FFT along x of the y-transformed exit waves in psi, fftshift of both axes and
 // scatter into slot `slot` of the (P, T_local, wx, wy) result (calculators.py:284-290).  With a k-window only the
 // columns inside it are transformed and only the rows inside it are stored.
+// staged full-resolution windows of `groups` frames x P probes -> binned frame slots slot .. slot+groups-1
+int bin_frames(msl_handle* h, int slot, int groups) {
+    const msl_config& c = h->cfg;
+    const long long total = (long long)h->wpix * c.n_probes * groups;
+    hipLaunchKernelGGL(bin_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, h->bin_stage, h->wf, c.n_probes, groups,
+                       c.n_frames, slot, h->wx, h->wy, h->bx, h->by);
+    HIPCHK(h, hipGetLastError());
+    return mark_launch(h, K_OTHER);
+}
+
 int epilogue_x_pass(msl_handle* h, int slot, int groups = 1) {
     const msl_config& c = h->cfg;
     const int P = c.n_probes * groups;               // image = frame-of-batch * n_probes + probe -> wf[probe][slot + frame]
-    float2* dst = h->wf + (size_t)slot * h->wpix;
-    const long long out_is = (long long)c.n_frames * h->wpix;
+    const bool binned = h->bin_stage != nullptr;
+    // binning: the full-resolution window of every image goes to the staging buffer (image-major), bin_kernel sums it
+    // into the frame slots -- 16 B/pixel/(probe, frame) extra against 16 B/pixel/slice-step of the loop
+    float2* dst = binned ? h->bin_stage : h->wf + (size_t)slot * h->wpix;
+    const long long out_is = binned ? (long long)h->wx * h->wy : (long long)c.n_frames * h->wpix;
+    const int og = binned ? 1 : groups;               // staged images stay image-major; bin_kernel regroups them by frame
     const bool windowed = (h->wx != c.nx) || (h->wy != c.ny);
     const bool fast_ok = h->Rx && (!windowed || (c.ny % 32 == 0 && h->wy % 32 == 0));
     if (fast_ok) {
         ColJob k = col_job(h, h->psi, dst, P, h->pitch, h->wy);
         k.flags = COL_FWD | COL_SHIFT; k.out_image_stride = out_is;
-        if (groups > 1) { k.out_group = c.n_probes; k.out_group_stride = (long long)h->wpix; }
+        if (og > 1) { k.out_group = c.n_probes; k.out_group_stride = (long long)h->wpix; }
         if (windowed) { k.win_c0 = h->wy0; k.win_nc = h->wy; k.win_x0 = h->wx0; k.win_nx = h->wx; }
-        return launch_col_fast(h, k, K_OTHER);
+        int rc = launch_col_fast(h, k, K_OTHER);
+        return (rc || !binned) ? rc : bin_frames(h, slot, groups);
     }
     LineArgs k = col_args(h, h->psi, dst, P, h->pitch, h->wy);
     k.fft1 = +1;
     k.out_is = out_is;
-    if (groups > 1) { k.group = c.n_probes; k.out_gs = (long long)h->wpix; }
+    if (og > 1) { k.group = c.n_probes; k.out_gs = (long long)h->wpix; }
     k.shift_n = c.nx / 2; k.shift_r = c.ny / 2;
     if (windowed) { k.win_n0 = h->wx0; k.win_nn = h->wx; k.win_r0 = h->wy0; k.win_nr = h->wy; }
-    return launch_lines(h, h->plan_x, k, K_OTHER);
+    int rc = launch_lines(h, h->plan_x, k, K_OTHER);
+    return (rc || !binned) ? rc : bin_frames(h, slot, groups);
 }
 
 // ---- one-pass-per-slice path ------------------------------------------------------------------------
@@ -960,7 +983,13 @@ int msl_create(const msl_config* cfg, msl_handle** out) {
     h->wy = cfg->window_ny ? cfg->window_ny : cfg->ny;
     h->wx0 = cfg->nx / 2 - h->wx / 2;
     h->wy0 = cfg->ny / 2 - h->wy / 2;
-    h->wpix = (size_t)h->wx * h->wy;
+    h->bx = cfg->bin_nx > 1 ? cfg->bin_nx : 1;
+    h->by = cfg->bin_ny > 1 ? cfg->bin_ny : 1;
+    if (h->wx % h->bx || h->wy % h->by) {
+        const int rc_ = fail(nullptr, MSL_ERR_INVALID, "msl_create: stored spectrum %d x %d is not a multiple of the bin %d x %d", h->wx, h->wy, h->bx, h->by);
+        delete h; return rc_;
+    }
+    h->wpix = (size_t)(h->wx / h->bx) * (h->wy / h->by);
     auto bail = [&](int rc) { g_create_error = h->err; msl_destroy(h); return rc; };
     if (hipSetDevice(cfg->device) != hipSuccess) return bail(fail(h, MSL_ERR_HIP, "hipSetDevice(%d) failed", cfg->device));
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(h, MSL_ERR_HIP, "hipStreamCreate failed"));
@@ -1049,6 +1078,7 @@ int msl_create(const msl_config* cfg, msl_handle** out) {
     if ((rc = dalloc(h, &h->trans, npix * cfg->nz * h->FB))) return bail(rc);
     if (cfg->keep_potential && (rc = dalloc(h, &h->V, npix * cfg->nz))) return bail(rc);
     if (cfg->n_frames > 0) {
+        if ((h->bx > 1 || h->by > 1) && (rc = dalloc(h, &h->bin_stage, (size_t)h->wx * h->wy * cfg->n_probes * h->FB))) return bail(rc);
         if ((rc = dalloc(h, &h->wf, h->wpix * cfg->n_probes * cfg->n_frames))) return bail(rc);
         if (hipMemsetAsync(h->wf, 0, h->wpix * cfg->n_probes * cfg->n_frames * sizeof(float2), h->stream) != hipSuccess)
             return bail(fail(h, MSL_ERR_HIP, "memset failed"));
@@ -1075,7 +1105,7 @@ int msl_destroy(msl_handle* h) {
     void* bufs[] = {h->psi0, h->psi, h->trans, h->V, h->wf, h->intensity, h->pxt, h->pyt, h->d_abcd, h->d_lo, h->d_hi,
                     h->d_pos, h->d_Z, h->d_key, h->d_order, h->d_u1, h->d_u2, h->d_ex, h->d_ey, h->d_counts, h->d_start,
                     h->d_z2s, h->d_species, h->d_ff, h->d_xy, h->plan_x.tw, h->plan_y.tw, h->plan_t.tw, h->tw4_x, h->tw4_y,
-                    h->scratch, h->psiT, h->psi0T, h->transT, h->opx.tw2, h->opx.ptab, h->opy.tw2, h->opy.ptab,
+                    h->scratch, h->psiT, h->psi0T, h->transT, h->bin_stage, h->st_acc, h->st_s1, h->st_s2, h->st_tw, h->st_bins, h->opx.tw2, h->opx.ptab, h->opy.tw2, h->opy.ptab,
                     (h->opx.two ? h->opx.tw : nullptr), (h->opy.two ? h->opy.tw : nullptr), h->plan_x.chirp, h->plan_x.bfilt, h->plan_y.chirp, h->plan_y.bfilt, h->plan_t.chirp, h->plan_t.bfilt};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1451,6 +1481,7 @@ int msl_tacaw(msl_handle* h, const void* d_src, void* d_dst, int64_t batch, int3
             if (rc) return rc;
             h->intensity_elems = need;
         }
+        h->intensity_F = T;
         dst = h->intensity;
     } else if (!dst) {
         return fail(h, MSL_ERR_INVALID, "msl_tacaw: src given without dst");
@@ -1501,6 +1532,88 @@ int msl_tacaw(msl_handle* h, const void* d_src, void* d_dst, int64_t batch, int3
     return MSL_OK;
 }
 
+static int ensure_scratch(msl_handle* h, size_t bytes);
+
+int msl_tacaw_stream_begin(msl_handle* h, int32_t T_total, int32_t n_bins, const int32_t* bins) {
+    if (!h) return fail(h, MSL_ERR_INVALID, "null handle");
+    if (!h->wf) return fail(h, MSL_ERR_STATE, "msl_tacaw_stream_begin: handle created with n_frames == 0 (no frame ring)");
+    if (T_total < 2) return fail(h, MSL_ERR_INVALID, "msl_tacaw_stream_begin: needs at least 2 frames (got %d)", T_total);
+    if (!bins) n_bins = T_total;
+    if (n_bins < 1 || n_bins > T_total) return fail(h, MSL_ERR_INVALID, "msl_tacaw_stream_begin: %d bins of %d", n_bins, T_total);
+    std::vector<int> b(n_bins);
+    for (int i = 0; i < n_bins; ++i) {
+        b[i] = bins ? bins[i] : i;
+        if (b[i] < 0 || b[i] >= T_total) return fail(h, MSL_ERR_INVALID, "msl_tacaw_stream_begin: bin %d outside [0,%d)", b[i], T_total);
+    }
+    const msl_config& c = h->cfg;
+    HIPCHK(h, hipSetDevice(c.device));
+    const size_t PK = (size_t)c.n_probes * h->wpix;
+    int rc;
+    if ((rc = dalloc(h, &h->st_acc, PK * n_bins))) return rc;
+    if ((rc = dalloc(h, &h->st_s1, PK))) return rc;
+    if ((rc = dalloc(h, &h->st_s2, PK))) return rc;
+    if ((rc = dalloc(h, &h->st_tw, (size_t)T_total))) return rc;
+    if ((rc = dalloc(h, &h->st_bins, (size_t)n_bins))) return rc;
+    std::vector<float2> tw(T_total);
+    for (int m = 0; m < T_total; ++m) { const double a = -2.0 * M_PI * m / T_total; tw[m] = make_float2((float)cos(a), (float)sin(a)); }
+    HIPCHK(h, hipMemcpyAsync(h->st_tw, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->st_bins, b.data(), b.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->st_acc, 0, PK * n_bins * sizeof(float2), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->st_s1, 0, PK * sizeof(double2), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->st_s2, 0, PK * sizeof(double), h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));            // the host vectors go out of scope
+    h->st_T = T_total; h->st_F = n_bins; h->st_open = true;
+    return MSL_OK;
+}
+
+int msl_tacaw_stream_push(msl_handle* h, int32_t first_slot, int32_t count, int32_t t0) {
+    if (!h) return fail(h, MSL_ERR_INVALID, "null handle");
+    if (!h->st_open) return fail(h, MSL_ERR_STATE, "msl_tacaw_stream_push: no open stream (msl_tacaw_stream_begin)");
+    const msl_config& c = h->cfg;
+    if (count < 1 || first_slot < 0 || first_slot + count > c.n_frames)
+        return fail(h, MSL_ERR_INVALID, "msl_tacaw_stream_push: slots [%d,%d) outside the ring of %d", first_slot, first_slot + count, c.n_frames);
+    if (t0 < 0 || t0 + count > h->st_T) return fail(h, MSL_ERR_INVALID, "msl_tacaw_stream_push: times [%d,%d) outside [0,%d)", t0, t0 + count, h->st_T);
+    HIPCHK(h, hipSetDevice(c.device));
+    FoldJob j{};
+    j.wf = h->wf; j.acc = h->st_acc; j.s1 = h->st_s1; j.s2 = h->st_s2; j.tw = h->st_tw; j.bins = h->st_bins;
+    j.K = (long long)h->wpix; j.ring = c.n_frames; j.first_slot = first_slot; j.count = count; j.t0 = t0; j.T = h->st_T; j.F = h->st_F;
+    const dim3 grid((unsigned)((h->wpix + 255) / 256), c.n_probes);
+    for (int f0 = 0; f0 < h->st_F; f0 += MSL_FOLD_FCH) {
+        j.f0 = f0;
+        hipLaunchKernelGGL(tacaw_fold_kernel, grid, dim3(256), 0, h->stream, j);
+    }
+    HIPCHK(h, hipGetLastError());
+    return MSL_OK;
+}
+
+int msl_tacaw_stream_finish(msl_handle* h, double* total_PK) {
+    if (!h) return fail(h, MSL_ERR_INVALID, "null handle");
+    if (!h->st_open) return fail(h, MSL_ERR_STATE, "msl_tacaw_stream_finish: no open stream");
+    const msl_config& c = h->cfg;
+    HIPCHK(h, hipSetDevice(c.device));
+    const size_t PK = (size_t)c.n_probes * h->wpix, need = PK * h->st_F;
+    int rc;
+    if (h->intensity_elems != need) {
+        if ((rc = dalloc(h, &h->intensity, need))) return rc;
+        h->intensity_elems = need;
+    }
+    h->intensity_F = h->st_F;
+    hipLaunchKernelGGL(tacaw_stream_finish_kernel, dim3((unsigned)((need + 255) / 256)), dim3(256), 0, h->stream, h->st_acc, h->intensity,
+                       h->st_bins, (long long)h->st_F, (long long)h->wpix, (long long)need);
+    HIPCHK(h, hipGetLastError());
+    if (total_PK) {
+        if ((rc = ensure_scratch(h, PK * sizeof(double)))) return rc;
+        hipLaunchKernelGGL(tacaw_stream_total_kernel, dim3((unsigned)((PK + 255) / 256)), dim3(256), 0, h->stream, h->st_s1, h->st_s2,
+                           (double)h->st_T, (long long)PK, (double*)h->scratch);
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipMemcpyAsync(total_PK, h->scratch, PK * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    (void)hipFree(h->st_acc); h->st_acc = nullptr;           // the accumulators are the big part: give them back
+    h->st_open = false;
+    return MSL_OK;
+}
+
 size_t msl_buffer_bytes(const msl_handle* h, msl_buffer what) {
     if (!h) return 0;
     const msl_config& c = h->cfg;
@@ -1543,7 +1656,7 @@ static int intensity_source(msl_handle* h, const char* who, const void** src, in
     if (!h) return fail(h, MSL_ERR_INVALID, "null handle");
     if (!*src) {
         if (!h->intensity || h->intensity_elems == 0) return fail(h, MSL_ERR_STATE, "%s: no intensity (call msl_tacaw)", who);
-        *src = h->intensity; *B = h->cfg.n_probes; *F = h->cfg.n_frames; *K = (int64_t)h->wpix;
+        *src = h->intensity; *B = h->cfg.n_probes; *F = h->intensity_F; *K = (int64_t)h->wpix;
     }
     if (*B < 1 || *F < 1 || *K < 1) return fail(h, MSL_ERR_INVALID, "%s: bad shape (%lld,%lld,%lld)", who, (long long)*B, (long long)*F, (long long)*K);
     if (*B * *F > 0x7fffffffLL) return fail(h, MSL_ERR_UNSUPPORTED, "%s: more than 2^31 rows", who);

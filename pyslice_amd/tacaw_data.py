@@ -55,7 +55,7 @@ class TACAWData(WFData):
             self._intensity_src = (eng, None)          # reductions read the library's own buffer
             if self.__dict__.get("_output") == "device":
                 ptr = eng.device_ptr(_native.BUF_INTENSITY)
-                shape = (eng.n_probes, eng.n_frames, eng.wx, eng.wy)
+                shape = (eng.n_probes, eng.intensity_F, eng.wx, eng.wy)
                 self.intensity = torch.as_tensor(_native.DeviceArray(ptr, shape, "<f4", owner=eng), device=f"cuda:{eng.device}")
             else:
                 self.intensity = _as_tensor(eng.intensity().astype(np.float64))
@@ -108,7 +108,7 @@ class TACAWData(WFData):
         d = self.__dict__
         eng, dev = d.get("_intensity_src", (None, None))
         if dev is None and eng is not None:
-            return eng, None, (eng.n_probes, eng.n_frames, eng.wx * eng.wy), eng.device_ptr(_native.BUF_INTENSITY)
+            return eng, None, (eng.n_probes, eng.intensity_F, eng.wx * eng.wy), eng.device_ptr(_native.BUF_INTENSITY)
         if dev is None:
             # intensity assembled elsewhere: stage a float32 copy on the device once
             if not TORCH_AVAILABLE or not torch.cuda.is_available():

@@ -613,6 +613,103 @@ def test_many_probes_per_launch(ps, orc, nx, ny, nz, P):
     assert fmp.case(nx, ny, nz, P) < WAVE_TOL
 
 
+@pytest.mark.parametrize("nx,ny,nz,window,kbin,fb", [(256, 256, 3, None, (4, 4), 1), (256, 256, 4, (64, 96), (2, 8), 2),
+                                                     (96, 80, 3, None, (3, 5), 1), (512, 512, 3, (128, 128), (4, 2), 3),
+                                                     (1024, 256, 2, (256, 64), (16, 1), 1), (45, 63, 2, (15, 21), (5, 7), 2)])
+def test_k_bin_is_a_block_sum_of_the_full_spectrum(ps, orc, nx, ny, nz, window, kbin, fb):
+    """k_bin=(bx,by): every stored pixel is the (coherent) sum of bx x by neighbouring pixels of the fftshifted spectrum --
+    the oracle's full array, cropped to the window, .reshape(.., wx/bx, bx, wy/by, by).sum().  Register and generic exit
+    FFTs, with and without a k-window, with frame batching."""
+    from pyslice_amd.synthetic import synthetic_trajectory
+    tr = synthetic_trajectory(nx, nz, 3, ny=ny, density=0.05, seed=5 + nz)
+    lx, ly = tr.box_matrix[0, 0], tr.box_matrix[1, 1]
+    pp = [tuple(v) for v in np.random.default_rng(2).random((2, 2)) * [lx, ly]]
+    calc = ps.MultisliceCalculator(progress=False, k_window=window, k_bin=kbin, frame_batch=fb)
+    calc.setup(tr, aperture=30.0, voltage_eV=100e3, probe_positions=pp)
+    wf = calc.run()
+    got = npy(wf.wavefunction_data)[..., 0]
+    full = orc.run_frames(tr.box_matrix, tr.positions, tr.atom_types, 30.0, 100e3, pp)["wavefunction_data"][..., 0]
+    wx, wy = window if window else (nx, ny)
+    x0, y0 = nx // 2 - wx // 2, ny // 2 - wy // 2
+    win = full[:, :, x0:x0 + wx, y0:y0 + wy]
+    want = win.reshape(2, 3, wx // kbin[0], kbin[0], wy // kbin[1], kbin[1]).sum(axis=(3, 5))
+    assert got.shape == want.shape
+    assert rel_l2(got, want) < WAVE_TOL
+    kx, ky, _ = orc.wf_axes(nx, ny, 0.1, 3, tr.timestep)
+    assert np.allclose(npy(wf.kxs), kx[x0:x0 + wx].reshape(-1, kbin[0]).mean(axis=1), rtol=1e-6, atol=1e-7)
+    assert np.allclose(npy(wf.kys), ky[y0:y0 + wy].reshape(-1, kbin[1]).mean(axis=1), rtol=1e-6, atol=1e-7)
+    # TACAW on the binned spectra = the oracle's time FFT of the binned array (three frames only: the intensity is the small
+    # difference of nearly equal spectra, so the fp32 error of the spectra is amplified -- 1e-3 here)
+    f, inten = orc.tacaw(want[..., None], wf.time)
+    assert rel_l2(npy(ps.TACAWData(wf).intensity), inten) < 1e-3
+
+
+def test_k_bin_argument_errors(ps):
+    from pyslice_amd.synthetic import synthetic_trajectory
+    with pytest.raises(ValueError):
+        ps.MultisliceCalculator(progress=False, k_bin=(0, 2))
+    with pytest.raises(ValueError):
+        ps.MultisliceCalculator(progress=False, k_bin=(2, 2), cache=True)
+    calc = ps.MultisliceCalculator(progress=False, k_bin=(3, 3))
+    with pytest.raises(ValueError, match="multiple"):
+        calc.setup(synthetic_trajectory(64, 2, 1, seed=1), aperture=30.0, voltage_eV=100e3)
+
+
+@pytest.mark.parametrize("n,T,tile,P,fb,kbin", [(64, 40, 16, 2, 1, None), (64, 21, 8, 1, 4, (2, 2)), (96, 12, 12, 2, 1, None), (256, 9, 4, 3, 2, (4, 4))])
+def test_streaming_tacaw_matches_the_full_transform(ps, orc, n, T, tile, P, fb, kbin):
+    """stream_tile = Tt: the device holds a ring of Tt frames; run_streaming_tacaw() folds tile after tile into the
+    time->frequency transform.  All bins: the oracle's intensity (tacaw_data.py:89-104); a frequency window: the same bins
+    of it; total_diffraction: the oracle's sum over all frequencies, from the Parseval accumulators."""
+    from pyslice_amd.synthetic import synthetic_trajectory
+    tr = synthetic_trajectory(n, 3, T, density=0.08, seed=31 + T)
+    lx, ly = tr.box_matrix[0, 0], tr.box_matrix[1, 1]
+    pp = [tuple(v) for v in np.random.default_rng(6).random((P, 2)) * [lx, ly]]
+    full = orc.run_frames(tr.box_matrix, tr.positions, tr.atom_types, 30.0, 100e3, pp)["wavefunction_data"]
+    if kbin:
+        full = full[..., 0].reshape(P, T, n // kbin[0], kbin[0], n // kbin[1], kbin[1]).sum(axis=(3, 5))[..., None]
+    f, inten = orc.tacaw(full, np.arange(T) * tr.timestep)
+    calc = ps.MultisliceCalculator(progress=False, stream_tile=tile, frame_batch=fb, k_bin=kbin)
+    calc.setup(tr, aperture=30.0, voltage_eV=100e3, probe_positions=pp)
+    assert calc._engine.n_frames == min(tile, T)
+    with pytest.raises(RuntimeError):
+        calc.run()
+    tac = calc.run_streaming_tacaw()
+    assert np.allclose(tac.frequencies, f)
+    got = npy(tac.intensity)
+    assert got.shape == inten.shape
+    assert rel_l2(got, inten) < TACAW_TOL
+    assert got[:, T // 2].max() == 0.0                                   # the DC bin (mean subtraction)
+    assert rel_l2(tac.total_diffraction, inten.sum(axis=1)) < TACAW_TOL
+    assert rel_l2(tac.spectrum(0), inten[0].sum(axis=(1, 2))) < TACAW_TOL
+    # a frequency window keeps those bins only; the frequency-integrated pattern still covers every bin
+    lo, hi = 0.0, 0.4 * f.max()
+    sel = np.nonzero((f >= lo) & (f <= hi))[0]
+    calc.setup(tr, aperture=30.0, voltage_eV=100e3, probe_positions=pp)
+    tw = calc.run_streaming_tacaw(freq_window=(lo, hi))
+    assert np.array_equal(tw.frequency_bins, sel) and np.allclose(tw.frequencies, f[sel])
+    assert rel_l2(npy(tw.intensity), inten[:, sel]) < TACAW_TOL
+    assert rel_l2(tw.total_diffraction, inten.sum(axis=1)) < TACAW_TOL
+    assert rel_l2(tw.diffraction(P - 1), inten[P - 1][sel].sum(axis=0)) < TACAW_TOL
+
+
+def test_streaming_tacaw_c5_grid_window_and_bin(ps, orc):
+    """BASELINE C5's grid (2048^2) with the k-window and bin DESIGN picks for it (window 512 x 512, bin 4 x 4), a shallow stack
+    so that the oracle stays affordable: streamed TACAW of 6 frames against the oracle's transform of its own binned window."""
+    from pyslice_amd.synthetic import synthetic_trajectory
+    n, T = 2048, 6
+    tr = synthetic_trajectory(n, 2, T, density=0.01, seed=77)
+    pp = [(101.0, 99.0), (60.0, 140.0)]
+    calc = ps.MultisliceCalculator(progress=False, stream_tile=4, k_window=(512, 512), k_bin=(4, 4))
+    calc.setup(tr, aperture=30.0, voltage_eV=100e3, probe_positions=pp)
+    tac = calc.run_streaming_tacaw()
+    full = orc.run_frames(tr.box_matrix, tr.positions, tr.atom_types, 30.0, 100e3, pp)["wavefunction_data"][..., 0]
+    win = full[:, :, n // 2 - 256:n // 2 + 256, n // 2 - 256:n // 2 + 256].reshape(2, T, 128, 4, 128, 4).sum(axis=(3, 5))
+    f, inten = orc.tacaw(win[..., None], np.arange(T) * tr.timestep)
+    assert npy(tac.intensity).shape == (2, T, 128, 128)
+    assert rel_l2(npy(tac.intensity), inten) < TACAW_TOL
+    assert rel_l2(tac.total_diffraction, inten.sum(axis=1)) < TACAW_TOL
+
+
 def test_k_window_argument_errors(ps):
     from pyslice_amd.synthetic import synthetic_trajectory
     tr = synthetic_trajectory(32, 2, 1, density=0.05, seed=1)
