@@ -227,6 +227,8 @@ def run(a):
         else:
             tacaw_T = n_local
     fb = a.frame_batch if a.frame_batch > 0 else max(1, min(-(-64 // P), int(16e9 // (16.0 * nz * npix))))
+    if a.frame_batch <= 0 and fb >= 16:
+        fb -= fb % 16
     fb = max(1, min(fb, a.steps))
     eng = _native.Engine(n, n, nz, xs[1] - xs[0], ys[1] - ys[0], zs[1] - zs[0] if nz > 1 else 0.5, wavelength(100e3),
                          interaction_sigma(100e3), n_probes=P, n_frames=slots, device=local_rank,

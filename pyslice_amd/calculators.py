@@ -168,6 +168,8 @@ class MultisliceCalculator:
         if batch is None:
             # about 64 images per launch, at most 16 GB for the two orientations of the batch's transmission stacks
             batch = max(1, min(-(-64 // self.n_probes), int(16e9 // (16.0 * n_slices * nx * ny))))
+            if batch >= 16:
+                batch -= batch % 16           # whole rounds of work items over the CUs (16-line tiles, 256 CUs x 2 workgroups)
         batch = 1 if self._cache else max(1, min(batch, len(self._frames)))
         slots = max(1, len(self._frames))
         if self._stream_tile is not None:

@@ -158,13 +158,20 @@ struct RowJob {
     // frame batching: images [g*t_group, (g+1)*t_group) belong to frame g of the batch, whose transmission stack starts
     // t_stride elements after the previous frame's (t_group == 0: one frame, every image uses `trans`)
     int t_group;
+    unsigned t_magic;       // floor(2^32 / t_group) + 1
     long long t_stride;
 };
 
-// transmission stack of the frame that image p belongs to
+// transmission stack of the frame that image p belongs to: job.trans + frame_off(job, p).  p is wave-uniform and the
+// frame number p / t_group is computed in scalar registers only -- a multiply-high by t_magic = floor(2^32 / t_group) + 1,
+// exact while p * t_group < 2^32 -- because these kernels run within a few VGPRs of the 256 that two waves per SIMD allow:
+// a vector temporary here pushed rowT2_pass_kernel<16> into the AGPRs and halved its occupancy (81 -> 117 us per pass).
 template <typename Job>
-__device__ __forceinline__ const float2* frame_trans(const Job& job, int p) {
-    return job.t_group > 0 ? job.trans + (long long)(p / job.t_group) * job.t_stride : job.trans;
+__device__ __forceinline__ long long frame_off(const Job& job, int p) {
+    if (job.t_group <= 0) return 0;
+    const unsigned up = (unsigned)__builtin_amdgcn_readfirstlane(p);
+    const unsigned f = job.t_group == 1 ? up : __umulhi(up, job.t_magic);        // (the magic number of 1 does not fit 32 bits)
+    return (long long)f * job.t_stride;
 }
 
 // Row pass.  Workgroup = 256 threads = 256/R lines per iteration, persistent over line groups.
@@ -200,7 +207,7 @@ __global__ void __launch_bounds__(256, R == 32 ? 3 : 4) row_pass_kernel(RowJob j
         for (int j = 0; j < R; ++j) v[j] = row[j * R + ln];
         if (job.do_ifft) fourstep_split<R, true>(v, scratch, tw, ln);
         if (job.trans) {
-            const float2* trow = frame_trans(job, p) + (long long)x * N;
+            const float2* trow = job.trans + frame_off(job, p) + (long long)x * N;
             mul_table<R, 0, false>(v, trow, ln);
         }
         if (job.do_fft) {
@@ -259,7 +266,7 @@ __global__ void __launch_bounds__(256, 2) row_pass_pf_kernel(RowJob job) {
         float2* cur_row = row_of(item, k);
         if (k == 0 && job.trans) {          // new x-group: its transmission rows first (L2), before the next HBM loads
             const int x = (int)(item / pchunks) * G + grp;
-            const float2* trow = frame_trans(job, (int)(item % pchunks) * PC) + (long long)x * N;
+            const float2* trow = job.trans + frame_off(job, (int)(item % pchunks) * PC) + (long long)x * N;
 #pragma unroll
             for (int j = 0; j < R; ++j) tv[j] = trow[j * R + ln];
         }
@@ -470,6 +477,7 @@ struct Row2Job {
     long long image_stride;
     int pitch, nx, n_images, flags, pchunk;
     int t_group;            // frame batching, see RowJob
+    unsigned t_magic;
     long long t_stride;
 };
 
@@ -512,7 +520,7 @@ __global__ void __launch_bounds__(256, 2) row_pass2_kernel(Row2Job job) {
         float2* cur_row = row_of(item, k);
         if (k == 0) {
             const int x = (int)(item / pchunks) * G + grp;
-            const float2* trow = frame_trans(job, (int)(item % pchunks) * PC) + (long long)x * N;
+            const float2* trow = job.trans + frame_off(job, (int)(item % pchunks) * PC) + (long long)x * N;
 #pragma unroll
             for (int j = 0; j < R; ++j) tv[j] = trow[j * R + ln];
         }
@@ -557,6 +565,7 @@ struct RowTJob {
     long long in_image_stride, out_image_stride;
     int in_pitch, out_pitch, n_lines, n_images, flags, pchunk;
     int t_group;            // frame batching, see RowJob
+    unsigned t_magic;
     long long t_stride;
 #ifdef MSL_STAMPS
     unsigned* stamps;       // tools/rowt_timeline.hip: per wave, cycles spent in each of MSL_NSTAMP phases of the iteration
@@ -632,7 +641,7 @@ __global__ void __launch_bounds__(LINES * R) rowT_pass_kernel(RowTJob job) {
         const int p = pc * PC + k;
         const int cur_lb = lb;
         if (k == 0) {
-            const float2* trow = frame_trans(job, pc * PC) + (long long)(lb * LINES + grp) * N;
+            const float2* trow = job.trans + frame_off(job, pc * PC) + (long long)(lb * LINES + grp) * N;
 #pragma unroll
             for (int j = 0; j < R; ++j) tv[j] = trow[j * R + ln];
         }
@@ -829,7 +838,7 @@ __global__ void __launch_bounds__(8 * R, 2) rowTP_pass_kernel(RowTJob job) {
         const int p = pc * PC + k;
         const int cur_lb = lb;
         if (k == 0) {
-            const float2* trow = frame_trans(job, pc * PC) + (long long)(lb * LINES + grp) * N;
+            const float2* trow = job.trans + frame_off(job, pc * PC) + (long long)(lb * LINES + grp) * N;
 #pragma unroll
             for (int j = 0; j < R; ++j) tv[j] = trow[j * R + ln];
         }
@@ -956,7 +965,7 @@ __device__ __forceinline__ void line2_transform(float2 (&v)[2 * R], float* scrat
 // rowT_pass_kernel, full-line tile.  R = 32 (N = 2048): a line is 64 complex per lane, so neither fits; t_k comes from
 // L2 per line and the transposed store goes through the tile in two position halves (set 0, set 1).
 template <int R>
-__global__ void __launch_bounds__(16 * R) rowT2_pass_kernel(RowTJob job) {
+__global__ void __launch_bounds__(16 * R, 2) rowT2_pass_kernel(RowTJob job) {      // two waves per SIMD: at most 256 VGPRs + AGPRs
     constexpr int N2 = R * R, N = 2 * N2, NT = 16 * R;
     constexpr bool BIG = (R == 32);
     constexpr int CPOS = BIG ? N2 : N;                 // positions per store chunk
@@ -1014,7 +1023,6 @@ __global__ void __launch_bounds__(16 * R) rowT2_pass_kernel(RowTJob job) {
     int item = blockIdx.x;
     int lb = item / pchunks, pc = item % pchunks, k = 0;
     const int in_off = grp * job.in_pitch + ln;
-    const int t_off = grp * N + ln;
     auto block_base = [&](int lbb, int pcc, int kk) {
         return job.in + ((long long)(pcc * PC + kk) * job.in_image_stride + (long long)lbb * 16 * job.in_pitch);
     };
@@ -1029,8 +1037,11 @@ __global__ void __launch_bounds__(16 * R) rowT2_pass_kernel(RowTJob job) {
         float2 v[2 * R];
         if constexpr (BIG) {
             const float2* r = block_base(lb, pc, k);
+            int ioff = tid;                             // re-derived every iteration (register limit, see below)
+            asm volatile("" : "+v"(ioff));
+            ioff = (ioff / R) * job.in_pitch + (ioff % R);
 #pragma unroll
-            for (int j = 0; j < 2 * R; ++j) v[j] = r[in_off + j * R];
+            for (int j = 0; j < 2 * R; ++j) v[j] = r[ioff + j * R];
         } else {
 #pragma unroll
             for (int j = 0; j < 2 * R; ++j) v[j] = vn[j];
@@ -1038,9 +1049,12 @@ __global__ void __launch_bounds__(16 * R) rowT2_pass_kernel(RowTJob job) {
         const int p = pc * PC + k;
         const int cur_lb = lb;
         if (!BIG && k == 0) {
-            const float2* trow = frame_trans(job, pc * PC) + (long long)lb * 16 * N;
+            const float2* trow = job.trans + frame_off(job, pc * PC) + (long long)lb * 16 * N;
+            int toff = tid;                               // re-derived here (one chunk of probes in PC): not worth a register across the loop
+            asm volatile("" : "+v"(toff));
+            toff = (toff / R) * N + (toff % R);
 #pragma unroll
-            for (int j = 0; j < 2 * R; ++j) tv[j] = trow[t_off + j * R];
+            for (int j = 0; j < 2 * R; ++j) tv[j] = trow[toff + j * R];
         }
         int nitem = item, nlb = lb, npc = pc, nk = k + 1;
         if (nk >= min(PC, job.n_images - pc * PC)) {
@@ -1049,8 +1063,11 @@ __global__ void __launch_bounds__(16 * R) rowT2_pass_kernel(RowTJob job) {
         }
         if (!BIG && nitem < n_items) {                  // (a mid-iteration prefetch as in rowT_pass_kernel measured 3% slower here)
             const float2* r = block_base(nlb, npc, nk);
+            int ioff = tid;                             // re-derived from the thread index every iteration: the kernel sits at
+            asm volatile("" : "+v"(ioff));              // its register limit and would otherwise spill this offset
+            ioff = (ioff / R) * job.in_pitch + (ioff % R);
 #pragma unroll
-            for (int j = 0; j < 2 * R; ++j) vn[j] = r[in_off + j * R];
+            for (int j = 0; j < 2 * R; ++j) vn[j] = r[ioff + j * R];
         }
         if (job.flags & P2_PRE_A) {
             line2_transform<R, false>(v, scratch, tw, tw2, ln);
@@ -1058,9 +1075,11 @@ __global__ void __launch_bounds__(16 * R) rowT2_pass_kernel(RowTJob job) {
             line2_transform<R, true>(v, scratch, tw, tw2, ln);
         }
         if constexpr (BIG) {
-            int lnx = ln;                                      // laundered: keeps the 64-bit table addresses out of the loop-invariant set
+            // uniform 64-bit base (scalar registers) + one 32-bit per-thread offset, laundered so that the table addresses
+            // stay out of the loop-invariant set
+            int lnx = grp * N + ln;
             asm volatile("" : "+v"(lnx));
-            mul_table<2 * R, 0, false, R>(v, frame_trans(job, p) + (long long)lb * 16 * N + grp * N, lnx);
+            mul_table<2 * R, 0, false, R, 4>(v, job.trans + frame_off(job, p) + (long long)lb * 16 * N, lnx);
         } else {
 #pragma unroll
             for (int j = 0; j < 2 * R; ++j) v[j] = cmulf(v[j], tv[j]);

@@ -728,7 +728,7 @@ int slice_loop_onepass_b(msl_handle* h, int fused_slot, int groups, int first_gr
         j.flags = (k > 0 ? P2_PRE_A : 0) | (k < nz - 1 ? P2_POST_A : 0);
         if (h->debug_flags_mask >= 0) j.flags &= h->debug_flags_mask;
         j.n_images = P;
-        if (groups > 1) { j.t_group = c.n_probes; j.t_stride = (long long)c.nz * npix; }
+        if (groups > 1) { j.t_group = c.n_probes; j.t_magic = (unsigned)((1ull << 32) / (unsigned)c.n_probes + 1); j.t_stride = (long long)c.nz * npix; }
         if (!(k & 1)) {
             j.in = (k == 0) ? h->psi0 : h->psi; j.out = h->psiT;
             j.trans = h->trans + toff + (size_t)k * npix; j.pl = h->pyt;
@@ -808,7 +808,7 @@ int slice_loop_onepass(msl_handle* h, int fused_slot, int groups, int first_grou
             Row2Job j{};
             j.psi = h->psi; j.trans = h->trans + toff + (size_t)k * npix; j.py = h->pyt; j.tw = h->tw4_y;
             j.image_stride = isA; j.pitch = h->pitch; j.nx = c.nx; j.n_images = P; j.flags = flags;
-            if (groups > 1) { j.t_group = c.n_probes; j.t_stride = (long long)c.nz * npix; }
+            if (groups > 1) { j.t_group = c.n_probes; j.t_magic = (unsigned)((1ull << 32) / (unsigned)c.n_probes + 1); j.t_stride = (long long)c.nz * npix; }
             rc = h->Ry == 32 ? launch_row2_r<32>(h, j, K_ROW) : launch_row2_r<16>(h, j, K_ROW);
             if (rc) return rc;
             break;
@@ -816,7 +816,7 @@ int slice_loop_onepass(msl_handle* h, int fused_slot, int groups, int first_grou
         const bool along_y = !slice_is_transposed(h, k);
         RowTJob j{};
         j.flags = flags; j.n_images = P;
-        if (groups > 1) { j.t_group = c.n_probes; j.t_stride = (long long)c.nz * npix; }
+        if (groups > 1) { j.t_group = c.n_probes; j.t_magic = (unsigned)((1ull << 32) / (unsigned)c.n_probes + 1); j.t_stride = (long long)c.nz * npix; }
         // 1024-point lines in both directions: paired-lines kernel, work buffers between two transposing passes in the
         // paired layout (the first pass reads, the last one writes the natural layout)
         const bool paired = h->rowT_paired && h->Rx == 32 && h->Ry == 32;
@@ -875,7 +875,7 @@ int slice_loop(msl_handle* h, int fused_slot, int groups, int first_group) {
             RowJob r = row_job(h, h->psi, P, h->pitch);
             r.do_ifft = z > 0; r.trans = h->trans + toff + (size_t)z * npix;
             r.do_fft = (!last || fused); r.py = last ? nullptr : h->pyt;
-            if (groups > 1) { r.t_group = c.n_probes; r.t_stride = (long long)c.nz * npix; }
+            if (groups > 1) { r.t_group = c.n_probes; r.t_magic = (unsigned)((1ull << 32) / (unsigned)c.n_probes + 1); r.t_stride = (long long)c.nz * npix; }
             if ((rc = launch_row_fast(h, r, K_ROW))) return rc;
         } else {
             LineArgs r = row_args(h, h->psi, h->psi, P, h->pitch);
