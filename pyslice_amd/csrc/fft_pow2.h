@@ -1079,7 +1079,7 @@ __global__ void __launch_bounds__(16 * R, 2) rowT2_pass_kernel(RowTJob job) {   
             // stay out of the loop-invariant set
             int lnx = grp * N + ln;
             asm volatile("" : "+v"(lnx));
-            mul_table<2 * R, 0, false, R, 4>(v, job.trans + frame_off(job, p) + (long long)lb * 16 * N, lnx);
+            mul_table<2 * R, 0, false, R>(v, job.trans + frame_off(job, p) + (long long)lb * 16 * N, lnx);
         } else {
 #pragma unroll
             for (int j = 0; j < 2 * R; ++j) v[j] = cmulf(v[j], tv[j]);
