@@ -583,7 +583,7 @@ struct RowTJob {
 #endif
 
 template <int R, int LINES, bool C64>
-__global__ void __launch_bounds__(LINES * R) rowT_pass_kernel(RowTJob job) {
+__global__ void __launch_bounds__(LINES * R, (R == 16) ? 3 : 2) rowT_pass_kernel(RowTJob job) {
     constexpr int N = R * R;
 #ifdef MSL_STAMPS
     constexpr int TCH = 8;                              // the diagnostic build needs the registers for its counters
