@@ -567,6 +567,10 @@ struct RowTJob {
     int t_group;            // frame batching, see RowJob
     unsigned t_magic;
     long long t_stride;
+    // rowTB_pass_kernel (lines of any length N <= R^2/2 by Bluestein's chirp-z on the register FFTs of length M = R^2):
+    const float2* bf;       // (M/2 + 1) filter FFT_M(conj chirp, wrapped) / M -- an even sequence, first half stored
+    const float2* bw;       // (M/2) chirp w[n] = exp(-i pi n^2 / N), zero for n >= N
+    int n_line;             // N
 #ifdef MSL_STAMPS
     unsigned* stamps;       // tools/rowt_timeline.hip: per wave, cycles spent in each of MSL_NSTAMP phases of the iteration
 #endif
@@ -905,6 +909,162 @@ __global__ void __launch_bounds__(8 * R, 2) rowTP_pass_kernel(RowTJob job) {
                 const int e = e0 + (NT / 4) * it;
                 const float2 a = tile[(2 * q4) * CS + e], b = tile[(2 * q4 + 1) * CS + e];
                 *reinterpret_cast<float4*>(dst + (off0 + it * ostep)) = make_float4(a.x, a.y, b.x, b.y);
+            }
+        }
+        lds_barrier();
+        item = nitem; lb = nlb; pc = npc; k = nk;
+    }
+}
+
+// ---- lines of ANY length N <= R^2/2: Bluestein's chirp-z transform on the register FFTs -------------------------------------
+// The reference's grids are n = int(L/sampling) + 1 points (potentials.py:123-125; its own probe test uses 501 x 491,
+// src/unittests/00_probe.py:7-8), almost never a power of two.  The generic LDS Stockham kernel (fft_generic.h) serves them at
+// 0.1 of the roofline: every radix stage is a round trip of the whole tile through the LDS between two barriers.  Here a line of
+// N points is embedded, zero-padded, in the M = R^2 point register layout of the power-of-two kernels (element n = reg R + lane)
+// and every N-point DFT is the chirp-z convolution
+//     fft_N(x)[k] = w[k] . IFFT_M( FFT_M(pad(x w)) . Bf )[k],     w[n] = exp(-i pi n^2 / N),   Bf = FFT_M(conj w, wrapped) / M
+// (M >= 2N - 1), the inverse the same with conjugated chirp and filter (Bf is even, so FFT/IFFT order is immaterial).  One pass
+// A . t_k . A,  A = ifft_N P fft_N,  is 8 register FFTs of length M and 11 table multiplies per line -- twice the work of a line
+// of the 1024-point kernel, which is the price of ANY length: a 501 x 491 grid runs at the speed of a 1024 x 1024 one instead of
+// 3.5 x slower.  Inside A the chirps cancel (w P conj w = P); entries beyond N, which hold wrapped-around convolution terms, are
+// zeroed by the zero padding of the P and chirp tables.  Everything else -- prefetch of the next line, t_k in registers across
+// a chunk of probes, 16-line tile, 128-byte transposed segments -- is rowT_pass_kernel's.  The number of lines need not be a
+// multiple of 16: the last tile re-reads the last line and its surplus columns land in the row padding of the output
+// (pitch >= n_lines rounded up to 16), which no pass reads.
+template <int R>
+__global__ void __launch_bounds__(16 * R, (R == 32) ? 2 : 4) rowTB_pass_kernel(RowTJob job) {
+    constexpr int M = R * R, H = R / 2, NH = M / 2, LINES = 16, NT = LINES * R, TCH = 8;
+    constexpr int CS = R * (R + 1) + 1;
+    constexpr int TPS = LINES / 2, POS_PER_IT = NT / TPS, NIT = NH / POS_PER_IT;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float2* tw = reinterpret_cast<float2*>(smem_raw);         // M: four-step twiddles
+    float2* bf = tw + M;                                      // NH + 2: filter, first half
+    float2* bp = bf + NH + 2;                                 // NH: Fresnel factor (1/N folded in), zero beyond N
+    float2* bw = bp + NH;                                     // NH: chirp, zero beyond N
+    float2* tile = bw + NH;                                   // LINES * CS
+    const int tid = threadIdx.x;
+    const int N = job.n_line;
+    for (int i = tid; i < M; i += NT) tw[i] = job.tw[i];
+    for (int i = tid; i <= NH; i += NT) bf[i] = job.bf[i];
+    for (int i = tid; i < NH; i += NT) { bp[i] = job.pl[i]; bw[i] = job.bw[i]; }
+    __syncthreads();
+    const int grp = tid / R, ln = tid % R;
+    const int q = tid % TPS, r0 = tid / TPS;
+    float2* myrow = tile + grp * CS;
+    const float2* fa = bf + ln;                               // Bf[j R + ln],                      j <  R/2
+    const float2* fb = bf - ln;                               // Bf[M - (j R + ln)] = bf[(R - j) R - ln],  j >= R/2
+    auto mul_filter = [&](float2 (&vv)[R], auto conj_c) {
+        constexpr bool CONJ = decltype(conj_c)::value;
+#pragma unroll
+        for (int c = 0; c < R; c += TCH) {
+            float2 w[TCH];
+#pragma unroll
+            for (int j = 0; j < TCH; ++j) w[j] = (c + j < H) ? fa[(c + j) * R] : fb[(R - (c + j)) * R];
+#pragma unroll
+            for (int j = 0; j < TCH; ++j) vv[c + j] = CONJ ? cmulf_conj(vv[c + j], w[j]) : cmulf(vv[c + j], w[j]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // v[j] *= tab[j R + ln] (conjugated when CONJ) for the R/2 registers that can hold line elements; the rest is padding: zero
+    auto mul_half = [&](float2 (&vv)[R], const float2* tab, auto conj_c) {
+        constexpr bool CONJ = decltype(conj_c)::value;
+#pragma unroll
+        for (int c = 0; c < H; c += TCH) {
+            float2 w[TCH];
+#pragma unroll
+            for (int j = 0; j < TCH; ++j) w[j] = tab[(c + j) * R + ln];
+#pragma unroll
+            for (int j = 0; j < TCH; ++j) vv[c + j] = CONJ ? cmulf_conj(vv[c + j], w[j]) : cmulf(vv[c + j], w[j]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int j = H; j < R; ++j) vv[j] = make_float2(0.f, 0.f);
+    };
+    const int lblocks = (job.n_lines + LINES - 1) / LINES;
+    const int PC = job.pchunk;
+    const int pchunks = (job.n_images + PC - 1) / PC;
+    const int n_items = lblocks * pchunks;
+    const int step_lb = (int)gridDim.x / pchunks, step_pc = (int)gridDim.x % pchunks;
+    auto line_ptr = [&](int lbb, int pcc, int kk) {
+        const int L = min(lbb * LINES + grp, job.n_lines - 1);
+        return job.in + (long long)(pcc * PC + kk) * job.in_image_stride + (long long)L * job.in_pitch;
+    };
+    int item = blockIdx.x;
+    int lb = item / pchunks, pc = item - lb * pchunks, k = 0;
+    float2 vn[H];
+    if (item < n_items) {
+        const float2* r = line_ptr(lb, pc, 0);
+#pragma unroll
+        for (int j = 0; j < H; ++j) vn[j] = (j * R + ln < N) ? r[j * R + ln] : make_float2(0.f, 0.f);
+    }
+    float2 tv[H];
+    while (item < n_items) {
+        float2 v[R];
+#pragma unroll
+        for (int j = 0; j < H; ++j) v[j] = vn[j];
+#pragma unroll
+        for (int j = H; j < R; ++j) v[j] = make_float2(0.f, 0.f);
+        const int p = pc * PC + k;
+        const int cur_lb = lb;
+        if (k == 0) {
+            const float2* trow = job.trans + frame_off(job, pc * PC) + (long long)min(lb * LINES + grp, job.n_lines - 1) * N;
+#pragma unroll
+            for (int j = 0; j < H; ++j) tv[j] = (j * R + ln < N) ? trow[j * R + ln] : make_float2(0.f, 0.f);
+        }
+        int nitem = item, nlb = lb, npc = pc, nk = k + 1;
+        if (nk >= min(PC, job.n_images - pc * PC)) {
+            nk = 0; nitem = item + (int)gridDim.x; nlb = lb + step_lb; npc = pc + step_pc;
+            if (npc >= pchunks) { npc -= pchunks; ++nlb; }
+        }
+        auto prefetch_part = [&](auto lo_c, auto hi_c) {
+            constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
+            __builtin_amdgcn_sched_barrier(0);
+            if (nitem < n_items) {
+                const float2* r = line_ptr(nlb, npc, nk);
+#pragma unroll
+                for (int j = LO; j < HI; ++j) vn[j] = (j * R + ln < N) ? r[j * R + ln] : make_float2(0.f, 0.f);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        float* scr = reinterpret_cast<float*>(myrow);
+        // A = ifft_N . P . fft_N on the zero-padded line
+        auto a_first = [&]() {
+            mul_half(v, bw, std::false_type{});
+            fourstep_split<R, false, TCH>(v, scr, tw, ln);
+            mul_filter(v, std::false_type{});
+            fourstep_split<R, true, TCH>(v, scr, tw, ln);
+        };
+        auto a_second = [&]() {
+            mul_half(v, bp, std::false_type{});
+            fourstep_split<R, false, TCH>(v, scr, tw, ln);
+            mul_filter(v, std::true_type{});
+            fourstep_split<R, true, TCH>(v, scr, tw, ln);
+            mul_half(v, bw, std::true_type{});
+        };
+        if (job.flags & P2_PRE_A) a_first();
+        prefetch_part(MSL_IC(0), MSL_IC(H / 4));
+        if (job.flags & P2_PRE_A) a_second();
+        prefetch_part(MSL_IC(H / 4), MSL_IC(H / 2));
+#pragma unroll
+        for (int j = 0; j < H; ++j) v[j] = cmulf(v[j], tv[j]);
+        if (job.flags & P2_POST_A) a_first();
+        prefetch_part(MSL_IC(H / 2), MSL_IC(3 * H / 4));
+        if (job.flags & P2_POST_A) a_second();
+        prefetch_part(MSL_IC(3 * H / 4), MSL_IC(H));
+        wave_lds_fence();
+#pragma unroll
+        for (int j = 0; j < H; ++j) myrow[j * R + ln] = v[j];
+        lds_barrier();
+        float2* dst = job.out + (long long)p * job.out_image_stride + cur_lb * LINES;
+        int off0 = 2 * q + r0 * job.out_pitch;
+        asm volatile("" : "+v"(off0));
+        const int ostep = POS_PER_IT * job.out_pitch;
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int pos = r0 + POS_PER_IT * i;
+            if (pos < N) {
+                const float2 a = tile[(2 * q) * CS + pos], b = tile[(2 * q + 1) * CS + pos];
+                *reinterpret_cast<float4*>(dst + (off0 + i * ostep)) = make_float4(a.x, a.y, b.x, b.y);
             }
         }
         lds_barrier();

@@ -72,7 +72,9 @@ struct msl_handle {
     bool onepass = false;
     bool scheme_b = false;         // a direction of 2R^2 points: every pass transposes, first pass along y, final transpose if nz is odd
     // one-pass kernel per direction: R^2 register kernel, 2 R^2 (two) register kernel with its tables, or the generic LDS kernel
-    struct OpDir { int R = 0; bool two = false; bool generic = false; float2* tw = nullptr; float2* tw2 = nullptr; float2* ptab = nullptr; } opx, opy;
+    // (breg: any length <= R^2/2 by Bluestein's chirp-z on the R^2 register FFTs, with its filter bf and chirp bw)
+    struct OpDir { int R = 0; bool two = false; bool generic = false; bool breg = false; float2* tw = nullptr; float2* tw2 = nullptr;
+                   float2* ptab = nullptr; float2* bf = nullptr; float2* bw = nullptr; } opx, opy;
     float2* psiT = nullptr;
     float2* psi0T = nullptr;
     bool need_psi0T = false;
@@ -415,6 +417,23 @@ LineArgs col_args(const msl_handle* h, const float2* in, float2* out, int images
     return a;
 }
 
+// Probes per work item of the chunked kernels (a work item = 16 lines x a chunk of probes that share the t_k lines in
+// registers; the grid is `slots` persistent workgroups).  The time of a launch is (rounds of work items over the slots) x
+// (iterations per item): take the chunk that minimises it, the larger one on ties (fewer t_k loads).  Halving until every slot
+// has an item, as round 1 did, wastes up to half a launch when the item count lands just above a multiple of the slots
+// (300 lines x 64 probes: 304 items of 4 probes = 8 iteration times, 247 items of 5 probes = 5).
+int choose_pchunk(long long line_blocks, int n_images, long long slots, int t_group) {
+    int best = 1;
+    long long best_cost = -1;
+    for (int pc = 1; pc <= n_images; ++pc) {
+        if (t_group > 0 && t_group % pc) continue;            // frame batching: a chunk stays inside one frame
+        const long long items = line_blocks * ((n_images + pc - 1) / pc);
+        const long long cost = ((items + slots - 1) / slots) * pc;
+        if (best_cost < 0 || cost <= best_cost) { best = pc; best_cost = cost; }
+    }
+    return best;
+}
+
 // ---- four-step fast path ------------------------------------------------------------------------
 int fast_radix(int n) { return n == 1024 ? 32 : (n == 256 ? 16 : 0); }
 
@@ -610,10 +629,8 @@ int launch_rowT_v(msl_handle* h, RowTJob job, int kind) {
     const int per_cu = std::max(1, std::min(cap, (int)((size_t)h->lds_limit / lds)));
     const long long slots = (long long)h->n_cus * per_cu;
     const long long lb = job.n_lines / LINES;
-    int pc = job.n_images;
-    while (pc > 1 && lb * ((job.n_images + pc - 1) / pc) < slots) pc = (pc + 1) / 2;
-    if (h->row_pchunk > 0) pc = std::min(h->row_pchunk, job.n_images);
-    if (job.t_group > 0) while (job.t_group % pc) --pc;              // a chunk of probes shares one t_k line: stay inside a frame
+    int pc = choose_pchunk(lb, job.n_images, slots, job.t_group);
+    if (h->row_pchunk > 0) { pc = std::min(h->row_pchunk, job.n_images); if (job.t_group > 0) while (job.t_group % pc) --pc; }
     job.pchunk = pc;
     const long long items = lb * ((job.n_images + pc - 1) / pc);
     const int grid = (int)std::min<long long>(items, slots);
@@ -637,10 +654,8 @@ int launch_rowTP_io(msl_handle* h, RowTJob job, int kind) {
     const int per_cu = std::max(1, std::min(2, (int)((size_t)h->lds_limit / lds)));
     const long long slots = (long long)h->n_cus * per_cu;
     const long long lb = job.n_lines / LINES;
-    int pc = job.n_images;
-    while (pc > 1 && lb * ((job.n_images + pc - 1) / pc) < slots) pc = (pc + 1) / 2;
-    if (h->row_pchunk > 0) pc = std::min(h->row_pchunk, job.n_images);
-    if (job.t_group > 0) while (job.t_group % pc) --pc;              // a chunk of probes shares one t_k line: stay inside a frame
+    int pc = choose_pchunk(lb, job.n_images, slots, job.t_group);
+    if (h->row_pchunk > 0) { pc = std::min(h->row_pchunk, job.n_images); if (job.t_group > 0) while (job.t_group % pc) --pc; }
     job.pchunk = pc;
     const long long items = lb * ((job.n_images + pc - 1) / pc);
     const int grid = (int)std::min<long long>(items, slots);
@@ -663,15 +678,32 @@ int launch_rowT2_r(msl_handle* h, RowTJob job, int kind) {
     const int per_cu = std::max(1, std::min(2, (int)((size_t)h->lds_limit / lds)));
     const long long slots = (long long)h->n_cus * per_cu;
     const long long lb = job.n_lines / 16;
-    int pc = BIG ? 1 : job.n_images;
-    while (pc > 1 && lb * ((job.n_images + pc - 1) / pc) < slots) pc = (pc + 1) / 2;
-    if (!BIG && h->row_pchunk > 0) pc = std::min(h->row_pchunk, job.n_images);
-    if (job.t_group > 0) while (job.t_group % pc) --pc;              // a chunk of probes shares one t_k line: stay inside a frame
+    int pc = BIG ? 1 : choose_pchunk(lb, job.n_images, slots, job.t_group);
+    if (!BIG && h->row_pchunk > 0) { pc = std::min(h->row_pchunk, job.n_images); if (job.t_group > 0) while (job.t_group % pc) --pc; }
     job.pchunk = pc;
     const long long items = lb * ((job.n_images + pc - 1) / pc);
     const int grid = (int)std::min<long long>(items, slots);
     (void)hipFuncSetAttribute((const void*)rowT2_pass_kernel<R>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
     hipLaunchKernelGGL(rowT2_pass_kernel<R>, dim3(grid), dim3(16 * R), lds, h->stream, job);
+    HIPCHK(h, hipGetLastError());
+    return mark_launch(h, kind);
+}
+
+// lines of any length <= R^2/2: Bluestein on the register FFTs
+template <int R>
+int launch_rowTB_r(msl_handle* h, RowTJob job, int kind) {
+    constexpr int M = R * R, NH = M / 2, CS = R * (R + 1) + 1;
+    const size_t lds = ((size_t)M + NH + 2 + NH + NH + (size_t)16 * CS) * 8;
+    const int per_cu = std::max(1, std::min(R == 16 ? 4 : 1, (int)((size_t)h->lds_limit / lds)));
+    const long long slots = (long long)h->n_cus * per_cu;
+    const long long lb = (job.n_lines + 15) / 16;
+    int pc = choose_pchunk(lb, job.n_images, slots, job.t_group);
+    if (h->row_pchunk > 0) { pc = std::min(h->row_pchunk, job.n_images); if (job.t_group > 0) while (job.t_group % pc) --pc; }
+    job.pchunk = pc;
+    const long long items = lb * ((job.n_images + pc - 1) / pc);
+    const int grid = (int)std::min<long long>(items, slots);
+    (void)hipFuncSetAttribute((const void*)rowTB_pass_kernel<R>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
+    hipLaunchKernelGGL(rowTB_pass_kernel<R>, dim3(grid), dim3(16 * R), lds, h->stream, job);
     HIPCHK(h, hipGetLastError());
     return mark_launch(h, kind);
 }
@@ -704,6 +736,11 @@ int launch_rowT_dir(msl_handle* h, const msl_handle::OpDir& o, RowTJob job, int 
         return launch_lines(h, pl, a, kind);
     }
     job.tw = o.tw;
+    if (o.breg) {
+        job.pl = o.ptab; job.bf = o.bf; job.bw = o.bw;
+        job.n_line = (&o == &h->opx) ? h->cfg.nx : h->cfg.ny;
+        return o.R == 32 ? launch_rowTB_r<32>(h, job, kind) : launch_rowTB_r<16>(h, job, kind);
+    }
     if (o.two) {
         job.tw2 = o.tw2; job.pl = o.ptab;
         return o.R == 32 ? launch_rowT2_r<32>(h, job, kind) : launch_rowT2_r<16>(h, job, kind);
@@ -774,10 +811,8 @@ int launch_row2_r(msl_handle* h, Row2Job job, int kind) {
     const int per_cu = std::max(1, std::min(2, (int)((size_t)h->lds_limit / lds)));
     const long long slots = (long long)h->n_cus * per_cu;
     const long long xg = job.nx / G;
-    int pc = job.n_images;
-    while (pc > 1 && xg * ((job.n_images + pc - 1) / pc) < slots) pc = (pc + 1) / 2;
-    if (h->row_pchunk > 0) pc = std::min(h->row_pchunk, job.n_images);
-    if (job.t_group > 0) while (job.t_group % pc) --pc;              // a chunk of probes shares one t_k line: stay inside a frame
+    int pc = choose_pchunk(xg, job.n_images, slots, job.t_group);
+    if (h->row_pchunk > 0) { pc = std::min(h->row_pchunk, job.n_images); if (job.t_group > 0) while (job.t_group % pc) --pc; }
     job.pchunk = pc;
     const long long items = xg * ((job.n_images + pc - 1) / pc);
     const int grid = (int)std::min<long long>(items, slots);
@@ -946,6 +981,22 @@ int fill_propagator(msl_handle* h) {
     };
     if (h->opx.two && (rc = fill_split(h->opx.ptab, c.nx, c.dx))) return rc;
     if (h->opy.two && (rc = fill_split(h->opy.ptab, c.ny, c.dy))) return rc;
+    // zero-padded copies for the chirp-z kernels: R^2/2 entries, P[m] for m < n
+    auto fill_padded = [&](const msl_handle::OpDir& o, int n, double d) -> int {
+        const int NH = o.R * o.R / 2;
+        std::vector<float2> v(NH, make_float2(0.f, 0.f));
+        for (int m = 0; m < n; ++m) {
+            const int f = (m < (n + 1) / 2) ? m : m - n;
+            const double k = f * (1.0 / (n * d));
+            const double ph = -M_PI * c.wavelength * c.dz * k * k;
+            v[m] = make_float2((float)(cos(ph) / n), (float)(sin(ph) / n));
+        }
+        HIPCHK(h, hipMemcpyAsync(o.ptab, v.data(), NH * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        return MSL_OK;
+    };
+    if (h->opx.breg && (rc = fill_padded(h->opx, c.nx, c.dx))) return rc;
+    if (h->opy.breg && (rc = fill_padded(h->opy, c.ny, c.dy))) return rc;
     return MSL_OK;
 }
 
@@ -1034,7 +1085,36 @@ int msl_create(const msl_config* cfg, msl_handle** out) {
             const bool lines_ok = (n_other % 16 == 0);
             if (Rfast && lines_ok) { o.R = Rfast; o.two = false; o.tw = tw4; return MSL_OK; }
             const int R2 = (n == 512) ? 16 : (n == 2048 ? 32 : 0);
-            if (!R2 || !lines_ok || !want || getenv("MSL_NO_TWO")) {
+            const bool two_ok = R2 && lines_ok && want && !getenv("MSL_NO_TWO");
+            // chirp-z on the register FFTs of length M = R^2 >= 2n - 1.  A line costs the same whatever n is, so against the
+            // generic Stockham kernel (cost ~ n log n) it wins for n <= 128 (M = 256) and from n ~ 270 up (M = 1024), and everywhere
+            // the generic kernel would need its own, LDS-resident Bluestein transform (a prime factor above 13)
+            const bool smooth = ((&o == &h->opx) ? h->plan_x : h->plan_y).M == n;
+            if (!two_ok && want && n >= 33 && n <= 512 && (n <= 128 || n >= 272 || !smooth) && !getenv("MSL_NO_BLUESTEIN_REG")) {
+                const int Rb = (n <= 128) ? 16 : 32, M = Rb * Rb, NH = M / 2;
+                o.R = Rb; o.breg = true;
+                int r = make_tw4(h, &o.tw, Rb);
+                if (r) return r;
+                std::vector<float2> bw(NH, make_float2(0.f, 0.f)), bf(NH + 2, make_float2(0.f, 0.f));
+                std::vector<double> cr(M, 0.0), ci(M, 0.0);
+                for (int i = 0; i < n; ++i) {
+                    const long long q = ((long long)i * i) % (2LL * n);
+                    const double a = -M_PI * (double)q / (double)n;              // w[i] = exp(-i pi i^2 / n)
+                    bw[i] = make_float2((float)cos(a), (float)sin(a));
+                    cr[i] = cos(a); ci[i] = -sin(a);                              // conj chirp, wrapped to negative lags
+                    if (i) { cr[M - i] = cr[i]; ci[M - i] = ci[i]; }
+                }
+                host_fft_pow2(cr, ci);
+                for (int j = 0; j <= NH; ++j) bf[j] = make_float2((float)(cr[j] / M), (float)(ci[j] / M));
+                if ((r = dalloc(h, &o.bw, (size_t)NH))) return r;
+                if ((r = dalloc(h, &o.bf, (size_t)NH + 2))) return r;
+                if ((r = dalloc(h, &o.ptab, (size_t)NH))) return r;
+                if (hipMemcpy(o.bw, bw.data(), NH * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess ||
+                    hipMemcpy(o.bf, bf.data(), (NH + 2) * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess)
+                    return fail(h, MSL_ERR_HIP, "chirp table upload failed");
+                return MSL_OK;
+            }
+            if (!two_ok) {
                 // generic LDS kernel with a transposing store: tiles of >= 8 lines keep the stores at 64 bytes or more
                 const int M = (&o == &h->opx) ? h->plan_x.M : h->plan_y.M;
                 o.generic = want && M <= 1024 && !getenv("MSL_NO_GENERIC_ONEPASS");
@@ -1056,13 +1136,15 @@ int msl_create(const msl_config* cfg, msl_handle** out) {
         if ((rc = setup_dir(h->opx, cfg->nx, cfg->ny, h->Rx, h->tw4_x))) return bail(rc);
         if ((rc = setup_dir(h->opy, cfg->ny, cfg->nx, h->Ry, h->tw4_y))) return bail(rc);
         h->onepass = want && (h->opx.R || h->opx.generic) && (h->opy.R || h->opy.generic) && !cfg->keep_potential;
-        h->scheme_b = h->onepass && (h->opx.two || h->opy.two || h->opx.generic || h->opy.generic);
+        h->scheme_b = h->onepass && (h->opx.two || h->opy.two || h->opx.generic || h->opy.generic || h->opx.breg || h->opy.breg);
         if (h->pitch == cfg->ny && h->onepass) h->pitch = cfg->ny + 16;        // pad the work buffers of 2R^2 grids too
+        if (h->onepass && (h->pitch & 1)) ++h->pitch;                          // even pitches: the transposed stores write two lines (16 bytes) at a time
         const size_t images = (size_t)cfg->n_probes * h->FB;
         if ((rc = dalloc(h, &h->psi0, (size_t)cfg->nx * h->pitch * images))) return bail(rc);
         if ((rc = dalloc(h, &h->psi, (size_t)cfg->nx * h->pitch * images))) return bail(rc);
         if (h->onepass) {
-            h->pitchT = cfg->nx + (h->pitch - cfg->ny);
+            h->pitchT = cfg->nx + 16 + (cfg->nx & 1);
+            if (h->pitch - cfg->ny > 16 && !(cfg->nx & 1)) h->pitchT = cfg->nx + (h->pitch - cfg->ny);
             if ((rc = dalloc(h, &h->psiT, (size_t)cfg->ny * h->pitchT * images))) return bail(rc);
             // transposed probes: only when the first pass runs along x (alternating scheme with an even slice count)
             h->need_psi0T = !h->scheme_b && (cfg->nz % 2 == 0);
@@ -1106,7 +1188,8 @@ int msl_destroy(msl_handle* h) {
                     h->d_pos, h->d_Z, h->d_key, h->d_order, h->d_u1, h->d_u2, h->d_ex, h->d_ey, h->d_counts, h->d_start,
                     h->d_z2s, h->d_species, h->d_ff, h->d_xy, h->plan_x.tw, h->plan_y.tw, h->plan_t.tw, h->tw4_x, h->tw4_y,
                     h->scratch, h->psiT, h->psi0T, h->transT, h->bin_stage, h->st_acc, h->st_s1, h->st_s2, h->st_tw, h->st_bins, h->opx.tw2, h->opx.ptab, h->opy.tw2, h->opy.ptab,
-                    (h->opx.two ? h->opx.tw : nullptr), (h->opy.two ? h->opy.tw : nullptr), h->plan_x.chirp, h->plan_x.bfilt, h->plan_y.chirp, h->plan_y.bfilt, h->plan_t.chirp, h->plan_t.bfilt};
+                    ((h->opx.two || h->opx.breg) ? h->opx.tw : nullptr), ((h->opy.two || h->opy.breg) ? h->opy.tw : nullptr),
+                    h->opx.bf, h->opx.bw, h->opy.bf, h->opy.bw, h->plan_x.chirp, h->plan_x.bfilt, h->plan_y.chirp, h->plan_y.bfilt, h->plan_t.chirp, h->plan_t.bfilt};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;

@@ -710,6 +710,44 @@ def test_streaming_tacaw_c5_grid_window_and_bin(ps, orc):
     assert rel_l2(tac.total_diffraction, inten.sum(axis=1)) < TACAW_TOL
 
 
+@pytest.mark.parametrize("nx,ny,nz,P", [(501, 491, 5, 3), (500, 500, 4, 2), (33, 128, 3, 2), (129, 272, 4, 2), (100, 400, 3, 3),
+                                        (512, 300, 4, 2), (349, 1024, 3, 1), (271, 257, 2, 2), (491, 501, 1, 2), (360, 448, 2, 70)])
+def test_any_length_register_kernel_matches_oracle(ps, orc, nx, ny, nz, P):
+    """Lines of any length up to 512 run as Bluestein chirp-z transforms on the register FFTs (rowTB_pass_kernel: M = 256 for
+    n <= 128, M = 1024 for 272 <= n <= 512 and for every non-smooth n in between): the reference's own 501 x 491 grid
+    (src/unittests/00_probe.py:7-8) in both orientations, the boundaries of the length ranges, line counts that are not
+    multiples of 16, mixes with the power-of-two and generic kernels, many probes, odd and even depths."""
+    from pyslice_amd.synthetic import synthetic_trajectory
+    tr = synthetic_trajectory(nx, nz, 2, ny=ny, density=0.04, seed=nx + ny)
+    lx, ly = tr.box_matrix[0, 0], tr.box_matrix[1, 1]
+    pp = [tuple(v) for v in np.random.default_rng(9).random((P, 2)) * [lx, ly]]
+    calc = ps.MultisliceCalculator(progress=False, dtype="complex64")
+    calc.setup(tr, aperture=30.0, voltage_eV=100e3, probe_positions=pp)
+    got = npy(calc.run().wavefunction_data)
+    chk = list(range(P)) if P <= 3 else [0, P // 2, P - 1]
+    want = orc.run_frames(tr.box_matrix, tr.positions, tr.atom_types, 30.0, 100e3, [pp[i] for i in chk])["wavefunction_data"]
+    assert rel_l2(got[chk], want) < WAVE_TOL
+    assert ref_residual(got[chk], want) < RESID_TOL
+
+
+def test_any_length_register_kernel_deep_stack_and_generic_cross_check(ps, orc, monkeypatch):
+    """501 x 491, 100 slices: error growth of the chirp-z passes (8 length-1024 FFTs per line and pass) stays inside the
+    contract, and the generic LDS kernels (MSL_NO_BLUESTEIN_REG) give the same exit waves."""
+    from pyslice_amd.synthetic import synthetic_trajectory
+    tr = synthetic_trajectory(501, 100, 1, ny=491, density=0.03, seed=3)
+    pp = [(20.0, 30.0)]
+    outs = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("MSL_NO_BLUESTEIN_REG", "1")
+        calc = ps.MultisliceCalculator(progress=False)
+        calc.setup(tr, aperture=30.0, voltage_eV=100e3, probe_positions=pp)
+        outs.append(npy(calc.run().wavefunction_data))
+    want = orc.run_frames(tr.box_matrix, tr.positions, tr.atom_types, 30.0, 100e3, pp)["wavefunction_data"]
+    assert rel_l2(outs[0], want) < WAVE_TOL and rel_l2(outs[1], want) < WAVE_TOL
+    assert rel_l2(outs[0], outs[1]) < 5e-5
+
+
 def test_k_window_argument_errors(ps):
     from pyslice_amd.synthetic import synthetic_trajectory
     tr = synthetic_trajectory(32, 2, 1, density=0.05, seed=1)
