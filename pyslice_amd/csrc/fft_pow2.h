@@ -916,6 +916,163 @@ __global__ void __launch_bounds__(8 * R, 2) rowTP_pass_kernel(RowTJob job) {
     }
 }
 
+// ---- 1024-point lines, THREE workgroups per CU ------------------------------------------------------------------------------
+// The ablations of tools/rowt_timeline.hip put the floor of the transposing pass at the VALU pipe (175 us per 1024^2 x 64
+// pass at two waves per SIMD, pipe saturated) with LDS and memory time added on top almost in full, because two waves per SIMD
+// leave nothing to issue while one of them waits.  This variant trades registers for occupancy: 8-line tiles in the
+// paired-lines layout (see rowTP_pass_kernel), stored in TWO position halves so that a tile row is 4.2 KB (just the transpose
+// scratch), t_k re-read from L2 per probe instead of held in 64 registers, and only the first half of the next line prefetched
+// into registers (the second half is loaded straight into the registers of the line being retired, after they have gone to the
+// tile).  46 KB of LDS and <= 168 VGPRs per 256-thread workgroup: three independent workgroups = three waves per SIMD.
+template <bool IN_P, bool OUT_P>
+__global__ void __launch_bounds__(256, 3) rowT3_pass_kernel(RowTJob job) {
+    constexpr int R = 32, N = R * R, LINES = 8, NT = LINES * R, TCH = 8, H = R / 2;
+    constexpr int RS = R * (R + 1) / 2 + 1;           // tile row in float2: the transpose scratch (R(R+1) floats), >= N/2 positions, odd
+    constexpr int NH = N / 2 + 2;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float2* tw = reinterpret_cast<float2*>(smem_raw);
+    float2* plh = tw + N;
+    float2* tile = plh + NH;                          // LINES * RS
+    const int tid = threadIdx.x;
+    for (int i = tid; i < N; i += NT) tw[i] = job.tw[i];
+    for (int i = tid; i <= N / 2; i += NT) plh[i] = job.pl[i];
+    __syncthreads();
+    const int grp = tid / R, ln = tid % R;
+    float2* myrow = tile + grp * RS;
+    const float2* pa = plh + ln;
+    const float2* pb = plh - ln;
+    auto mul_p = [&](float2 (&vv)[R]) {
+#pragma unroll
+        for (int c = 0; c < R; c += TCH) {
+            float2 w[TCH];
+#pragma unroll
+            for (int j = 0; j < TCH; ++j) w[j] = (c + j < R / 2) ? pa[(c + j) * R] : pb[(R - (c + j)) * R];
+#pragma unroll
+            for (int j = 0; j < TCH; ++j) vv[c + j] = cmulf(vv[c + j], w[j]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    const int lblocks = job.n_lines / LINES;
+    const int PC = job.pchunk;
+    const int pchunks = (job.n_images + PC - 1) / PC;
+    const int n_items = lblocks * pchunks;
+        constexpr int ES = IN_P ? 2 : 1;
+    auto line_ptr = [&](int lbb, int pcc, int kk) {
+        int lnx = tid;                                // per-thread part re-derived (register limit)
+        asm volatile("" : "+v"(lnx));
+        const int L = lbb * LINES + lnx / R;
+        const long long off = IN_P ? (long long)(L >> 1) * (2 * job.in_pitch) + (L & 1) : (long long)L * job.in_pitch;
+        return job.in + (long long)(pcc * PC + kk) * job.in_image_stride + off + (lnx % R) * ES;
+    };
+    // Workgroups are dealt round-robin over the 8 XCDs: give every XCD a contiguous eighth of the items (line-block major),
+    // so that the t_k lines a workgroup re-reads per probe stay in ITS L2 (1 MB of the 8 MB slice per XCD)
+    // (with a grid that is a multiple of 8 a workgroup's items are an arithmetic sequence again: the cursor stays incremental)
+    const bool xmap = (n_items % 8 == 0) && (gridDim.x % 8 == 0);
+    const int istep = xmap ? (int)gridDim.x / 8 : (int)gridDim.x;
+    const int step_lb = istep / pchunks, step_pc = istep % pchunks;
+    int vitem = blockIdx.x;
+    int item = xmap ? (int)(blockIdx.x & 7) * (n_items >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    int lb = item / pchunks, pc = item - lb * pchunks, k = 0;
+    float2 vn[H];
+    float2 v[R];
+    if (vitem < n_items) {
+        const float2* r = line_ptr(lb, pc, 0);
+#pragma unroll
+        for (int j = 0; j < H; ++j) vn[j] = r[j * R * ES];
+#pragma unroll
+        for (int j = H; j < R; ++j) v[j] = r[j * R * ES];
+    }
+    while (vitem < n_items) {
+#pragma unroll
+        for (int j = 0; j < H; ++j) v[j] = vn[j];
+        const int p = pc * PC + k;
+        const int cur_lb = lb;
+        int nvitem = vitem, nitem = item, nlb = lb, npc = pc, nk = k + 1;
+        if (nk >= min(PC, job.n_images - pc * PC)) {
+            nk = 0; nvitem = vitem + (int)gridDim.x; nitem = nvitem < n_items ? item + istep : n_items;
+            nlb = lb + step_lb; npc = pc + step_pc;
+            if (npc >= pchunks) { npc -= pchunks; ++nlb; }
+        }
+        auto prefetch_part = [&](auto lo_c, auto hi_c) {
+            constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
+            __builtin_amdgcn_sched_barrier(0);
+            if (nitem < n_items) {
+                const float2* r = line_ptr(nlb, npc, nk);
+#pragma unroll
+                for (int j = LO; j < HI; ++j) vn[j] = r[j * R * ES];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        float* scr = reinterpret_cast<float*>(myrow);
+        if (job.flags & P2_PRE_A) fourstep_split<R, false, TCH>(v, scr, tw, ln);
+        prefetch_part(MSL_IC(0), MSL_IC(4));
+        if (job.flags & P2_PRE_A) {
+            mul_p(v);
+            fourstep_split<R, true, TCH>(v, scr, tw, ln);
+        }
+        prefetch_part(MSL_IC(4), MSL_IC(8));
+        {
+            int lnx = tid;
+            asm volatile("" : "+v"(lnx));
+            lnx = (lnx / R) * N + (lnx % R);
+            mul_table<R, 0, false, R, TCH>(v, job.trans + frame_off(job, p) + (long long)cur_lb * LINES * N, lnx);
+        }
+        if (job.flags & P2_POST_A) fourstep_split<R, false, TCH>(v, scr, tw, ln);
+        prefetch_part(MSL_IC(8), MSL_IC(12));
+        if (job.flags & P2_POST_A) {
+            mul_p(v);
+            fourstep_split<R, true, TCH>(v, scr, tw, ln);
+        }
+        prefetch_part(MSL_IC(12), MSL_IC(16));
+        // transposed store in two position halves: registers [0, R/2) = positions [0, N/2), then the rest
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+            wave_lds_fence();
+#pragma unroll
+            for (int j = 0; j < H; ++j) myrow[j * R + ln] = v[ph * H + j];
+            if (ph == 1) {
+                // the line has left the registers: the second half of the NEXT line goes straight into them
+                __builtin_amdgcn_sched_barrier(0);
+                if (nitem < n_items) {
+                    const float2* r = line_ptr(nlb, npc, nk);
+#pragma unroll
+                    for (int j = H; j < R; ++j) v[j] = r[j * R * ES];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            lds_barrier();
+            if constexpr (OUT_P) {
+                const int i = tid & 7, oct = tid >> 3, q = oct & 3, hh = oct >> 2;
+                const int mm0 = (hh & 3) + 4 * q + 16 * (hh >> 2);
+                const float2* src = tile + i * RS + 2 * mm0;
+                float2* dst = job.out + (long long)p * job.out_image_stride + 2 * (cur_lb * LINES + i);
+                int off0 = (ph * (N / 4) + mm0) * 2 * job.out_pitch;
+                asm volatile("" : "+v"(off0));
+                const int ostep = 32 * 2 * job.out_pitch;
+#pragma unroll
+                for (int it = 0; it < N / 4 / 32; ++it) {
+                    const float2 a = src[it * 64], b = src[it * 64 + 1];
+                    *reinterpret_cast<float4*>(dst + (off0 + it * ostep)) = make_float4(a.x, a.y, b.x, b.y);
+                }
+            } else {
+                const int q4 = tid & 3, e0 = tid >> 2;
+                float2* dst = job.out + (long long)p * job.out_image_stride + cur_lb * LINES + 2 * q4;
+                int off0 = (ph * (N / 2) + e0) * job.out_pitch;
+                asm volatile("" : "+v"(off0));
+                const int ostep = (NT / 4) * job.out_pitch;
+#pragma unroll
+                for (int it = 0; it < N / 2 / (NT / 4); ++it) {
+                    const int e = e0 + (NT / 4) * it;
+                    const float2 a = tile[(2 * q4) * RS + e], b = tile[(2 * q4 + 1) * RS + e];
+                    *reinterpret_cast<float4*>(dst + (off0 + it * ostep)) = make_float4(a.x, a.y, b.x, b.y);
+                }
+            }
+            lds_barrier();
+        }
+        vitem = nvitem; item = nitem; lb = nlb; pc = npc; k = nk;
+    }
+}
+
 // ---- lines of ANY length N <= R^2/2: Bluestein's chirp-z transform on the register FFTs -------------------------------------
 // The reference's grids are n = int(L/sampling) + 1 points (potentials.py:123-125; its own probe test uses 501 x 491,
 // src/unittests/00_probe.py:7-8), almost never a power of two.  The generic LDS Stockham kernel (fft_generic.h) serves them at
@@ -1272,6 +1429,104 @@ __global__ void __launch_bounds__(16 * R, 2) rowT2_pass_kernel(RowTJob job) {   
         lds_barrier();
         if constexpr (BIG) { stage_p(); lds_barrier(); }       // the store phase overwrote the parked propagator
         item = nitem; lb = nlb; pc = npc; k = nk;
+    }
+}
+
+// ---- stand-alone inverse FFT passes for lines of 2 R^2 points: the potential build on 512 / 2048 grids -------------------------
+// V_s = Re ifft2(R_s) / (dx^2 dy^2), t_s = exp(i sigma V_s) (potentials.py:336-342, multislice.py:282) went through the generic LDS
+// kernel on these grids (two passes at 2.6 TB/s plus a transposition of every second slice; 0.35 of 0.73 ms per frame at 512^2 x
+// 100, which a single probe cannot amortise).  Two passes of this kernel instead: the line is loaded in the split order the
+// register transform wants -- slot k of set b is X[2k + b], i.e. one 16-byte load per lane and register -- inverse-transformed
+// (line2_transform) and stored transposed through the 16-line tile; the second pass applies the potential epilogue and writes a
+// slice either transposed back (natural orientation) or as rows (the orientation the passes along x read).
+struct IfftT2Job {
+    const float2* in;           // (n_images, n_lines, in_pitch): lines in natural frequency order
+    float2* out_t;              // transposed store: out_t[img][pos][line]
+    float2* out_rows;           // row store (potential epilogue only): out_rows[img][line][pos]
+    const float2* tw;
+    const float2* tw2;
+    long long in_is, out_t_is, out_rows_is;
+    int in_pitch, out_t_pitch, out_rows_pitch, n_lines, n_images;
+    int potential;              // 1: V = Re(.) * scale, out = exp(i sigma V)
+    int rows_parity;            // potential: images with (img & 1) == rows_parity are stored as rows, the others transposed; -1: none
+    float scale, sigma_over_pi;
+};
+
+template <int R>
+__global__ void __launch_bounds__(16 * R, 2) ifftT2_kernel(IfftT2Job job) {
+    constexpr int N2 = R * R, N = 2 * N2, NT = 16 * R;
+    constexpr bool BIG = (R == 32);
+    constexpr int CPOS = BIG ? N2 : N;
+    constexpr int NCHUNK = N / CPOS;
+    constexpr int CS = CPOS + 1;
+    constexpr int POS_PER_IT = NT / 8;
+    constexpr int NIT = CPOS / POS_PER_IT;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float2* tw = reinterpret_cast<float2*>(smem_raw);
+    float2* tw2 = tw + N2;
+    float2* tile = tw2 + N2;                                     // 16 * CS, also the transpose scratch
+    const int tid = threadIdx.x;
+    for (int i = tid; i < N2; i += NT) { tw[i] = job.tw[i]; tw2[i] = job.tw2[i]; }
+    __syncthreads();
+    const int grp = tid / R, ln = tid % R;
+    const int q = tid & 7, r0 = tid >> 3;
+    float* scratch = reinterpret_cast<float*>(tile + grp * CS);
+    const int lblocks = job.n_lines / 16;
+    const int n_items = lblocks * job.n_images;
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int img = item / lblocks, lb = item - img * lblocks;
+        const float2* src = job.in + (long long)img * job.in_is + (long long)(lb * 16 + grp) * job.in_pitch;
+        int lnv = ln;                                       // laundered: keeps dozens of per-lane LDS / global addresses from being
+        asm volatile("" : "+v"(lnv));                       // hoisted out of the loop into registers the transform needs
+        float2 v[2 * R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const float4 x = *reinterpret_cast<const float4*>(src + 2 * (j * R + lnv));
+            v[j] = make_float2(x.x, x.y); v[R + j] = make_float2(x.z, x.w);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        float* scr = scratch;
+        asm volatile("" : "+v"(scr));
+        line2_transform<R, true>(v, scr, tw, tw2, lnv);
+        // exp(i sigma V) through sincospi: its range reduction is exact, where sincosf carries a slow path with a private
+        // array (scratch); sigma / pi is formed in double on the host.
+        auto trans_of = [&](float2 x) {
+            float sn, cs;
+            sincospif(job.sigma_over_pi * (x.x * job.scale), &sn, &cs);
+            return make_float2(cs, sn);
+        };
+        if (job.potential) {
+#pragma unroll
+            for (int j = 0; j < 2 * R; ++j) {
+                if (j % 4 == 0) __builtin_amdgcn_sched_barrier(0);          // four evaluations in flight, not all of them
+                v[j] = trans_of(v[j]);
+            }
+        }
+        if (job.potential && (img & 1) == job.rows_parity) {       // workgroup-uniform
+            float2* dst = job.out_rows + (long long)img * job.out_rows_is + (long long)(lb * 16 + grp) * job.out_rows_pitch;
+#pragma unroll
+            for (int j = 0; j < 2 * R; ++j) dst[(j / R) * N2 + (j % R) * R + lnv] = v[j];
+            continue;
+        }
+        float2* dst = job.out_t + (long long)img * job.out_t_is + lb * 16;
+        int off0 = 2 * q + r0 * job.out_t_pitch;
+        asm volatile("" : "+v"(off0));
+        const int ostep = POS_PER_IT * job.out_t_pitch;
+#pragma unroll
+        for (int c = 0; c < NCHUNK; ++c) {
+            lds_barrier();                             // the tile (and, for c == 0, every group's scratch use) is free
+            float2* myrow = reinterpret_cast<float2*>(scr);
+#pragma unroll
+            for (int j = 0; j < CPOS / R; ++j) myrow[j * R + lnv] = v[c * (CPOS / R) + j];
+            lds_barrier();
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) {
+                const int pos = r0 + POS_PER_IT * i;
+                const float2 a = tile[(2 * q) * CS + pos], b = tile[(2 * q + 1) * CS + pos];
+                *reinterpret_cast<float4*>(dst + (off0 + (c * NIT + i) * ostep)) = make_float4(a.x, a.y, b.x, b.y);
+            }
+        }
+        lds_barrier();
     }
 }
 

@@ -664,7 +664,31 @@ int launch_rowTP_io(msl_handle* h, RowTJob job, int kind) {
     HIPCHK(h, hipGetLastError());
     return mark_launch(h, kind);
 }
+// 1024-point lines, three 256-thread workgroups per CU (paired-lines layout, two-phase store, t_k from L2)
+template <bool IN_P, bool OUT_P>
+int launch_rowT3_io(msl_handle* h, RowTJob job, int kind) {
+    constexpr int R = 32, N = R * R, RS = R * (R + 1) / 2 + 1, LINES = 8;
+    const size_t lds = ((size_t)N + N / 2 + 2 + (size_t)LINES * RS) * 8;
+    const int per_cu = std::max(1, std::min(3, (int)((size_t)h->lds_limit / lds)));
+    const long long slots = (long long)h->n_cus * per_cu;
+    const long long lb = job.n_lines / LINES;
+    // no t_k reuse across probes here: one probe per work item chunk would do, but items are dealt line block major so that
+    // neighbouring workgroups share the t_k lines in L2; keep the chunk rule (it balances the rounds)
+    int pc = choose_pchunk(lb, job.n_images, slots, job.t_group);
+    if (h->row_pchunk > 0) { pc = std::min(h->row_pchunk, job.n_images); if (job.t_group > 0) while (job.t_group % pc) --pc; }
+    job.pchunk = pc;
+    const long long items = lb * ((job.n_images + pc - 1) / pc);
+    const int grid = (int)std::min<long long>(items, slots);
+    (void)hipFuncSetAttribute((const void*)rowT3_pass_kernel<IN_P, OUT_P>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
+    hipLaunchKernelGGL((rowT3_pass_kernel<IN_P, OUT_P>), dim3(grid), dim3(LINES * R), lds, h->stream, job);
+    HIPCHK(h, hipGetLastError());
+    return mark_launch(h, kind);
+}
 int launch_rowTP(msl_handle* h, const RowTJob& job, bool in_p, bool out_p, int kind) {
+    if (h->rowT_paired == 3) {
+        if (in_p) return out_p ? launch_rowT3_io<true, true>(h, job, kind) : launch_rowT3_io<true, false>(h, job, kind);
+        return out_p ? launch_rowT3_io<false, true>(h, job, kind) : launch_rowT3_io<false, false>(h, job, kind);
+    }
     if (in_p) return out_p ? launch_rowTP_io<true, true>(h, job, kind) : launch_rowTP_io<true, false>(h, job, kind);
     return out_p ? launch_rowTP_io<false, true>(h, job, kind) : launch_rowTP_io<false, false>(h, job, kind);
 }
@@ -1443,7 +1467,39 @@ int msl_build_potential(msl_handle* h, const double* pos, const int32_t* Z, int6
     // V_s = Re ifft2(R_s) / (dx^2 dy^2);  t_s = exp(i sigma V_s)  -- in place over the (nz,nx,ny) buffer
     const float vscale = (float)(1.0 / ((double)c.nx * c.ny) / (c.dx * c.dx * c.dy * c.dy));
     h->cur = nullptr;
-    if (h->Ry) {
+    // (512-point lines only: with 64 complex values per lane the 2048-point instantiation spills and is slower than the generic kernel)
+    const bool ifft_t2 = h->onepass && h->opx.two && h->opy.two && h->opx.R == 16 && h->opy.R == 16 && !h->V && !getenv("MSL_NO_IFFT_T2");
+    if (ifft_t2) {
+        // 512 / 2048 grids: two transposing inverse-FFT passes on the register kernels (TR -> TRT along y, TRT -> TR / TRT along
+        // x with the potential epilogue; slices a pass along x reads stay in TRT as rows)
+        auto pass = [&](int R, const IfftT2Job& j) -> int {
+            const int N2 = R * R, N = 2 * N2;
+            const size_t lds = (R == 32) ? ((size_t)2 * N2 + (size_t)16 * (N2 + 1)) * 8 : ((size_t)2 * N2 + (size_t)16 * (N + 1)) * 8;
+            const int per_cu = std::max(1, std::min(2, (int)((size_t)h->lds_limit / lds)));
+            const long long items = (long long)(j.n_lines / 16) * j.n_images;
+            const int grid = (int)std::min<long long>(items, (long long)h->n_cus * per_cu);
+            if (R == 32) {
+                (void)hipFuncSetAttribute((const void*)ifftT2_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
+                hipLaunchKernelGGL(ifftT2_kernel<32>, dim3(grid), dim3(512), lds, h->stream, j);
+            } else {
+                (void)hipFuncSetAttribute((const void*)ifftT2_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
+                hipLaunchKernelGGL(ifftT2_kernel<16>, dim3(grid), dim3(256), lds, h->stream, j);
+            }
+            HIPCHK(h, hipGetLastError());
+            return mark_launch(h, K_OTHER);
+        };
+        IfftT2Job a{};
+        a.in = TR; a.out_t = TRT; a.out_rows = nullptr; a.tw = h->opy.tw; a.tw2 = h->opy.tw2;
+        a.in_is = a.out_t_is = (long long)npix; a.in_pitch = c.ny; a.out_t_pitch = c.nx; a.n_lines = c.nx; a.n_images = c.nz;
+        a.potential = 0; a.rows_parity = -1;
+        if ((rc = pass(h->opy.R, a))) return rc;
+        IfftT2Job b{};
+        b.in = TRT; b.out_t = TR; b.out_rows = TRT; b.tw = h->opx.tw; b.tw2 = h->opx.tw2;
+        b.in_is = b.out_t_is = b.out_rows_is = (long long)npix; b.in_pitch = c.nx; b.out_t_pitch = c.ny; b.out_rows_pitch = c.nx;
+        b.n_lines = c.ny; b.n_images = c.nz; b.potential = 1; b.rows_parity = 1;      // scheme b: slice s is read along x iff s is odd
+        b.scale = vscale; b.sigma_over_pi = (float)(c.sigma / M_PI);
+        if ((rc = pass(h->opx.R, b))) return rc;
+    } else if (h->Ry) {
         RowJob r = row_job(h, TR, c.nz, c.ny);
         r.do_ifft = 1;
         if ((rc = launch_row_fast(h, r, K_OTHER))) return rc;
@@ -1452,7 +1508,9 @@ int msl_build_potential(msl_handle* h, const double* pos, const int32_t* Z, int6
         r.fft1 = -1;
         if ((rc = launch_lines(h, h->plan_y, r, K_OTHER))) return rc;
     }
-    if (h->Rx) {
+    if (ifft_t2) {
+        // (both passes done above)
+    } else if (h->Rx) {
         ColJob k = col_job(h, TR, TR, c.nz, c.ny, c.ny);
         k.flags = COL_INV | COL_POTENTIAL; k.scale = vscale; k.sigma = (float)c.sigma; k.out_real = h->V;
         if (h->onepass) { k.flags |= COL_TPOT; k.tparity = h->scheme_b ? 0 : ((c.nz - 1) & 1); k.out_t = TRT; }

@@ -351,13 +351,14 @@ def test_calculator_oracle_parity_onepass(ps, orc, n, nz, P):
     assert rel_l2(t, np.exp(1j * orc.interaction_sigma(100e3) * np.moveaxis(V, 2, 0))) < 1e-4
 
 
+@pytest.mark.parametrize("mode", ["1", "3"])
 @pytest.mark.parametrize("nz", [2, 3, 6, 7])
-def test_paired_lines_kernel_matches_oracle(ps, orc, nz, monkeypatch):
+def test_paired_lines_kernel_matches_oracle(ps, orc, nz, mode, monkeypatch):
     """MSL_ROWT_PAIRED=1: the 1024 x 1024 slice loop on 8-line tiles with the work buffers between two transposing passes
     in the paired-lines layout (two workgroups per CU).  nz = 2: one transposing pass, natural in and out; nz = 3: natural ->
     paired -> natural; deeper stacks run paired -> paired passes; even / odd depths start along different axes."""
     from pyslice_amd.synthetic import synthetic_trajectory
-    monkeypatch.setenv("MSL_ROWT_PAIRED", "1")
+    monkeypatch.setenv("MSL_ROWT_PAIRED", mode)        # 1: two workgroups per CU; 3: three (two-phase store, t_k from L2)
     tr = synthetic_trajectory(1024, nz, 1, density=0.02, seed=70 + nz)
     lx, ly = tr.box_matrix[0, 0], tr.box_matrix[1, 1]
     pp = [tuple(v) for v in np.random.default_rng(8).random((3, 2)) * [lx, ly]]
