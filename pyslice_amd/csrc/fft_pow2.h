@@ -467,7 +467,7 @@ __global__ void __launch_bounds__(16 * R) col_pass_kernel(ColJob job) {
 // read + write of psi per slice instead of two: 16 B/pixel/slice-step.  Same arithmetic as the
 // reference up to fp32 rounding order.
 // =================================================================================================
-enum { P2_PRE_A = 1, P2_POST_A = 2, P2_POST_F = 4 };
+enum { P2_PRE_A = 1, P2_POST_A = 2, P2_POST_F = 4, P2_IN_PAIRED = 8, P2_OUT_PAIRED = 16 };
 
 struct Row2Job {
     float2* psi;
@@ -1222,6 +1222,248 @@ __global__ void __launch_bounds__(16 * R, (R == 32) ? 2 : 4) rowTB_pass_kernel(R
             if (pos < N) {
                 const float2 a = tile[(2 * q) * CS + pos], b = tile[(2 * q + 1) * CS + pos];
                 *reinterpret_cast<float4*>(dst + (off0 + i * ostep)) = make_float4(a.x, a.y, b.x, b.y);
+            }
+        }
+        lds_barrier();
+        item = nitem; lb = nlb; pc = npc; k = nk;
+    }
+}
+
+// ---- 2048-point register FFT, one wave per line; lines of any length 513..1024 by chirp-z on it ------------------------------
+// A line of M = 2048 points in ONE wave: 64 lanes x 32 registers, element index = reg * 64 + lam(lane), where
+//     lam(L) = 32 (L & 1) + (L >> 1)
+// spreads the logical positions over the physical lanes so that the two lanes that share a 64-point sub-transform are
+// neighbours.  Forward transform (k = k1 + 32 k2):
+//     32-point register FFT over reg (n1 -> k1)  ->  x W_2048^(k1 n2)  ->  LDS transpose: lane (k1, h) gets A[k1; n2 = m + 32 h]
+//     in register m  ->  the 64-point DFT over n2 as ONE radix-2 step across the lane pair (h = 0: a = x_own + x_partner,
+//     h = 1: d = (x_partner - x_own) W_64^m; the partner's value comes through DPP quad_perm, no LDS)  ->  32-point register FFT
+//     (h = 0 holds k2 = 2q, h = 1 holds k2 = 2q + 1: element k = 64 q + (32 h + k1) = reg * 64 + lam(lane): the input layout).
+// The inverse runs the mirror image with conjugated twiddles.  Against the 2 R^2 layout of rowT2_pass_kernel<32> (64 complex
+// per lane) a lane holds 32 complex, which leaves registers for the prefetch of the next line and for t_k.
+__device__ __forceinline__ int lam64(int L) { return 32 * (L & 1) + (L >> 1); }
+__device__ __forceinline__ float dpp_swap_pair(float x) {          // value of the neighbouring lane (L ^ 1)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true));
+}
+constexpr int W2K_PITCH = 97;               // floats per k1 row of the transpose scratch: n2 < 32 at [0,32), n2 >= 32 at [48,80); 97 = 1 mod 32
+
+// tw: LDS table T[k1 * 64 + n2] = exp(-2 pi i k1 n2 / 2048); w64: LDS table [h * 32 + m] = (h ? exp(-2 pi i m / 64) : 1);
+// scr: this wave's scratch of 32 * W2K_PITCH floats; L = lane, la = lam64(L), sgn = (L & 1) ? -1 : +1
+template <bool INV, int CH = 8>
+__device__ __forceinline__ void fft2048_wave(float2 (&v)[32], float* scr, const float2* tw, const float2* w64, int L, int la, float sgn) {
+    constexpr int R = 32;
+    const int col = (la & 31) + 48 * (la >> 5);                     // this lane's column n2 = la in a k1 row
+    const int rowbase = (L >> 1) * W2K_PITCH + 48 * (L & 1);        // lane (k1, h): row k1, columns m + 32 h
+    auto pair_step = [&](bool twiddle_first) {
+#pragma unroll
+        for (int c = 0; c < R; c += CH) {
+            float2 w[CH];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) w[j] = w64[(L & 1) * R + c + j];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                float2 x = v[c + j];
+                if (twiddle_first) x = cmulf_conj(x, w[j]);                    // inverse: d' = d~ conj(W_64^m) on the odd lane
+                const float2 r = make_float2(fmaf(sgn, x.x, dpp_swap_pair(x.x)), fmaf(sgn, x.y, dpp_swap_pair(x.y)));
+                v[c + j] = twiddle_first ? r : cmulf(r, w[j]);                 // forward: d = (..) W_64^m on the odd lane
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    if constexpr (!INV) {
+        fft_regs<R, false>(v);
+        mul_table<R, 1, false, 64, CH>(v, tw, la);
+#pragma unroll
+        for (int k1 = 0; k1 < R; ++k1) scr[k1 * W2K_PITCH + col] = v[k1].x;
+        wave_lds_fence();
+#pragma unroll
+        for (int m = 0; m < R; ++m) v[m].x = scr[rowbase + m];
+        wave_lds_fence();
+#pragma unroll
+        for (int k1 = 0; k1 < R; ++k1) scr[k1 * W2K_PITCH + col] = v[k1].y;
+        wave_lds_fence();
+#pragma unroll
+        for (int m = 0; m < R; ++m) v[m].y = scr[rowbase + m];
+        wave_lds_fence();
+        pair_step(false);
+        fft_regs<R, false>(v);
+    } else {
+        fft_regs<R, true>(v);
+        pair_step(true);
+#pragma unroll
+        for (int m = 0; m < R; ++m) scr[rowbase + m] = v[m].x;
+        wave_lds_fence();
+#pragma unroll
+        for (int k1 = 0; k1 < R; ++k1) v[k1].x = scr[k1 * W2K_PITCH + col];
+        wave_lds_fence();
+#pragma unroll
+        for (int m = 0; m < R; ++m) scr[rowbase + m] = v[m].y;
+        wave_lds_fence();
+#pragma unroll
+        for (int k1 = 0; k1 < R; ++k1) v[k1].y = scr[k1 * W2K_PITCH + col];
+        wave_lds_fence();
+        mul_table<R, 1, true, 64, CH>(v, tw, la);
+        fft_regs<R, true>(v);
+    }
+}
+
+// Transposing pass A . t_k . A for lines of any length 513 <= N <= 1024: rowTB_pass_kernel's chirp-z scheme on fft2048_wave.
+// One wave per line, 8 lines per workgroup; between two of these passes the work buffers are in the paired-lines layout (see
+// rowTP_pass_kernel), so that a transposed 128-byte segment is two positions of the tile's eight lines.
+template <bool IN_P, bool OUT_P>
+__global__ void __launch_bounds__(512, 2) rowTB2_pass_kernel(RowTJob job) {
+    constexpr int R = 32, M = 2048, H = 16, NH = M / 2, LINES = 8, NT = 512, TCH = 8;
+    constexpr int RS = (R * W2K_PITCH) / 2 + 1;        // tile row in float2 (1553: the transpose scratch; >= NH positions; = 17 mod 32)
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float2* tw = reinterpret_cast<float2*>(smem_raw);         // 2048
+    float2* w64 = tw + M;                                     // 64
+    float2* bf = w64 + 64;                                    // NH + 2
+    float2* bp = bf + NH + 2;                                 // NH
+    float2* bw = bp + NH;                                     // NH
+    float2* tile = bw + NH;                                   // LINES * RS
+    const int tid = threadIdx.x;
+    const int N = job.n_line;
+    for (int i = tid; i < M; i += NT) tw[i] = job.tw[i];
+    if (tid < 64) w64[tid] = job.tw2[tid];
+    for (int i = tid; i <= NH; i += NT) bf[i] = job.bf[i];
+    for (int i = tid; i < NH; i += NT) { bp[i] = job.pl[i]; bw[i] = job.bw[i]; }
+    __syncthreads();
+    const int wv = tid >> 6, L = tid & 63, la = lam64(L);
+    const float sgn = (L & 1) ? -1.f : 1.f;
+    float2* myrow = tile + wv * RS;
+    float* scr = reinterpret_cast<float*>(myrow);
+    const float2* fa = bf + la;                               // Bf[64 j + la],              j < 16
+    const float2* fb = bf - la;                               // Bf[M - (64 j + la)] = bf[64 (32 - j) - la],  j >= 16
+    auto mul_filter = [&](float2 (&vv)[R], auto conj_c) {
+        constexpr bool CONJ = decltype(conj_c)::value;
+#pragma unroll
+        for (int c = 0; c < R; c += TCH) {
+            float2 w[TCH];
+#pragma unroll
+            for (int j = 0; j < TCH; ++j) w[j] = (c + j < H) ? fa[(c + j) * 64] : fb[(R - (c + j)) * 64];
+#pragma unroll
+            for (int j = 0; j < TCH; ++j) vv[c + j] = CONJ ? cmulf_conj(vv[c + j], w[j]) : cmulf(vv[c + j], w[j]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto mul_half = [&](float2 (&vv)[R], const float2* tab, auto conj_c) {
+        constexpr bool CONJ = decltype(conj_c)::value;
+#pragma unroll
+        for (int c = 0; c < H; c += TCH) {
+            float2 w[TCH];
+#pragma unroll
+            for (int j = 0; j < TCH; ++j) w[j] = tab[(c + j) * 64 + la];
+#pragma unroll
+            for (int j = 0; j < TCH; ++j) vv[c + j] = CONJ ? cmulf_conj(vv[c + j], w[j]) : cmulf(vv[c + j], w[j]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int j = H; j < R; ++j) vv[j] = make_float2(0.f, 0.f);
+    };
+    const int lblocks = (job.n_lines + LINES - 1) / LINES;
+    const int PC = job.pchunk;
+    const int pchunks = (job.n_images + PC - 1) / PC;
+    const int n_items = lblocks * pchunks;
+    const int step_lb = (int)gridDim.x / pchunks, step_pc = (int)gridDim.x % pchunks;
+    constexpr int ES = IN_P ? 2 : 1;
+    auto line_ptr = [&](int lbb, int pcc, int kk) {
+        const int Lc = min(lbb * LINES + wv, job.n_lines - 1);
+        const long long off = IN_P ? (long long)(Lc >> 1) * (2 * job.in_pitch) + (Lc & 1) : (long long)Lc * job.in_pitch;
+        return job.in + (long long)(pcc * PC + kk) * job.in_image_stride + off;
+    };
+    int item = blockIdx.x;
+    int lb = item / pchunks, pc = item - lb * pchunks, k = 0;
+    float2 vn[H];
+    if (item < n_items) {
+        const float2* r = line_ptr(lb, pc, 0);
+#pragma unroll
+        for (int j = 0; j < H; ++j) vn[j] = (j * 64 + la < N) ? r[(j * 64 + la) * ES] : make_float2(0.f, 0.f);
+    }
+    float2 tv[H];
+    while (item < n_items) {
+        float2 v[R];
+#pragma unroll
+        for (int j = 0; j < H; ++j) v[j] = vn[j];
+#pragma unroll
+        for (int j = H; j < R; ++j) v[j] = make_float2(0.f, 0.f);
+        const int p = pc * PC + k;
+        const int cur_lb = lb;
+        if (k == 0) {
+            const float2* trow = job.trans + frame_off(job, pc * PC) + (long long)min(lb * LINES + wv, job.n_lines - 1) * N;
+#pragma unroll
+            for (int j = 0; j < H; ++j) tv[j] = (j * 64 + la < N) ? trow[j * 64 + la] : make_float2(0.f, 0.f);
+        }
+        int nitem = item, nlb = lb, npc = pc, nk = k + 1;
+        if (nk >= min(PC, job.n_images - pc * PC)) {
+            nk = 0; nitem = item + (int)gridDim.x; nlb = lb + step_lb; npc = pc + step_pc;
+            if (npc >= pchunks) { npc -= pchunks; ++nlb; }
+        }
+        auto prefetch_part = [&](auto lo_c, auto hi_c) {
+            constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
+            __builtin_amdgcn_sched_barrier(0);
+            if (nitem < n_items) {
+                const float2* r = line_ptr(nlb, npc, nk);
+#pragma unroll
+                for (int j = LO; j < HI; ++j) vn[j] = (j * 64 + la < N) ? r[(j * 64 + la) * ES] : make_float2(0.f, 0.f);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto a_first = [&]() {
+            mul_half(v, bw, std::false_type{});
+            fft2048_wave<false, TCH>(v, scr, tw, w64, L, la, sgn);
+            mul_filter(v, std::false_type{});
+            fft2048_wave<true, TCH>(v, scr, tw, w64, L, la, sgn);
+        };
+        auto a_second = [&]() {
+            mul_half(v, bp, std::false_type{});
+            fft2048_wave<false, TCH>(v, scr, tw, w64, L, la, sgn);
+            mul_filter(v, std::true_type{});
+            fft2048_wave<true, TCH>(v, scr, tw, w64, L, la, sgn);
+            mul_half(v, bw, std::true_type{});
+        };
+        if (job.flags & P2_PRE_A) a_first();
+        prefetch_part(MSL_IC(0), MSL_IC(4));
+        if (job.flags & P2_PRE_A) a_second();
+        prefetch_part(MSL_IC(4), MSL_IC(8));
+#pragma unroll
+        for (int j = 0; j < H; ++j) v[j] = cmulf(v[j], tv[j]);
+        if (job.flags & P2_POST_A) a_first();
+        prefetch_part(MSL_IC(8), MSL_IC(12));
+        if (job.flags & P2_POST_A) a_second();
+        prefetch_part(MSL_IC(12), MSL_IC(16));
+        wave_lds_fence();
+#pragma unroll
+        for (int j = 0; j < H; ++j) myrow[j * 64 + la] = v[j];
+        lds_barrier();
+        if constexpr (OUT_P) {
+            // segment = positions (2 mm, 2 mm + 1) of the tile's 8 lines; thread = (line i, pair mm); the four octets of a
+            // half-wave take pairs 4 apart so that, with the tile row pitch = 17 mod 32, their LDS reads fall into different banks
+            const int i = tid & 7, oct = tid >> 3, q = oct & 3, hh = oct >> 2;
+            const int mm0 = (hh & 3) + 4 * q + 16 * (hh >> 2);             // 0 .. 63
+            const float2* src = tile + i * RS + 2 * mm0;
+            float2* dst = job.out + (long long)p * job.out_image_stride + 2 * (cur_lb * LINES + i);
+            int off0 = mm0 * 2 * job.out_pitch;
+            asm volatile("" : "+v"(off0));
+            const int ostep = 64 * 2 * job.out_pitch;
+#pragma unroll
+            for (int it = 0; it < NH / 2 / 64; ++it) {
+                if (2 * (mm0 + 64 * it) < N) {
+                    const float2 a = src[it * 128], b = src[it * 128 + 1];
+                    *reinterpret_cast<float4*>(dst + (off0 + it * ostep)) = make_float4(a.x, a.y, b.x, b.y);
+                }
+            }
+        } else {
+            const int q4 = tid & 3, e0 = tid >> 2;                         // natural output: 8 lines = 64-byte segments
+            float2* dst = job.out + (long long)p * job.out_image_stride + cur_lb * LINES + 2 * q4;
+            int off0 = e0 * job.out_pitch;
+            asm volatile("" : "+v"(off0));
+            const int ostep = (NT / 4) * job.out_pitch;
+#pragma unroll
+            for (int it = 0; it < NH / (NT / 4); ++it) {
+                const int e = e0 + (NT / 4) * it;
+                if (e < N) {
+                    const float2 a = tile[(2 * q4) * RS + e], b = tile[(2 * q4 + 1) * RS + e];
+                    *reinterpret_cast<float4*>(dst + (off0 + it * ostep)) = make_float4(a.x, a.y, b.x, b.y);
+                }
             }
         }
         lds_barrier();

@@ -73,7 +73,8 @@ struct msl_handle {
     bool scheme_b = false;         // a direction of 2R^2 points: every pass transposes, first pass along y, final transpose if nz is odd
     // one-pass kernel per direction: R^2 register kernel, 2 R^2 (two) register kernel with its tables, or the generic LDS kernel
     // (breg: any length <= R^2/2 by Bluestein's chirp-z on the R^2 register FFTs, with its filter bf and chirp bw)
-    struct OpDir { int R = 0; bool two = false; bool generic = false; bool breg = false; float2* tw = nullptr; float2* tw2 = nullptr;
+    // (breg2: lengths 513..1024 by the same scheme on the wave-per-line 2048-point FFT; tw = T[k1*64+n2], tw2 = W_64 table)
+    struct OpDir { int R = 0; bool two = false; bool generic = false; bool breg = false; bool breg2 = false; float2* tw = nullptr; float2* tw2 = nullptr;
                    float2* ptab = nullptr; float2* bf = nullptr; float2* bw = nullptr; } opx, opy;
     float2* psiT = nullptr;
     float2* psi0T = nullptr;
@@ -732,6 +733,24 @@ int launch_rowTB_r(msl_handle* h, RowTJob job, int kind) {
     return mark_launch(h, kind);
 }
 
+// lines of 513..1024 points: Bluestein on the wave-per-line 2048-point register FFT
+template <bool IN_P, bool OUT_P>
+int launch_rowTB2_io(msl_handle* h, RowTJob job, int kind) {
+    constexpr int M = 2048, NH = M / 2, RS = (32 * W2K_PITCH) / 2 + 1;
+    const size_t lds = ((size_t)M + 64 + NH + 2 + NH + NH + (size_t)8 * RS) * 8;
+    const long long slots = h->n_cus;
+    const long long lb = (job.n_lines + 7) / 8;
+    int pc = choose_pchunk(lb, job.n_images, slots, job.t_group);
+    if (h->row_pchunk > 0) { pc = std::min(h->row_pchunk, job.n_images); if (job.t_group > 0) while (job.t_group % pc) --pc; }
+    job.pchunk = pc;
+    const long long items = lb * ((job.n_images + pc - 1) / pc);
+    const int grid = (int)std::min<long long>(items, slots);
+    (void)hipFuncSetAttribute((const void*)rowTB2_pass_kernel<IN_P, OUT_P>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
+    hipLaunchKernelGGL((rowTB2_pass_kernel<IN_P, OUT_P>), dim3(grid), dim3(512), lds, h->stream, job);
+    HIPCHK(h, hipGetLastError());
+    return mark_launch(h, kind);
+}
+
 // one transposing pass along direction `o`: register kernels for R^2 and 2 R^2 points, else the generic LDS kernel
 // running the same program (fft, x P, ifft, x t, fft, x P, ifft) with a transposing store
 int launch_rowT_dir(msl_handle* h, const msl_handle::OpDir& o, RowTJob job, int kind) {
@@ -760,9 +779,10 @@ int launch_rowT_dir(msl_handle* h, const msl_handle::OpDir& o, RowTJob job, int 
         return launch_lines(h, pl, a, kind);
     }
     job.tw = o.tw;
-    if (o.breg) {
+    if (o.breg || o.breg2) {
         job.pl = o.ptab; job.bf = o.bf; job.bw = o.bw;
         job.n_line = (&o == &h->opx) ? h->cfg.nx : h->cfg.ny;
+        if (o.breg2) { job.tw2 = o.tw2; return launch_rowTB2_io<false, false>(h, job, kind); }
         return o.R == 32 ? launch_rowTB_r<32>(h, job, kind) : launch_rowTB_r<16>(h, job, kind);
     }
     if (o.two) {
@@ -1007,7 +1027,7 @@ int fill_propagator(msl_handle* h) {
     if (h->opy.two && (rc = fill_split(h->opy.ptab, c.ny, c.dy))) return rc;
     // zero-padded copies for the chirp-z kernels: R^2/2 entries, P[m] for m < n
     auto fill_padded = [&](const msl_handle::OpDir& o, int n, double d) -> int {
-        const int NH = o.R * o.R / 2;
+        const int NH = o.breg2 ? 1024 : o.R * o.R / 2;
         std::vector<float2> v(NH, make_float2(0.f, 0.f));
         for (int m = 0; m < n; ++m) {
             const int f = (m < (n + 1) / 2) ? m : m - n;
@@ -1019,8 +1039,8 @@ int fill_propagator(msl_handle* h) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
         return MSL_OK;
     };
-    if (h->opx.breg && (rc = fill_padded(h->opx, c.nx, c.dx))) return rc;
-    if (h->opy.breg && (rc = fill_padded(h->opy, c.ny, c.dy))) return rc;
+    if ((h->opx.breg || h->opx.breg2) && (rc = fill_padded(h->opx, c.nx, c.dx))) return rc;
+    if ((h->opy.breg || h->opy.breg2) && (rc = fill_padded(h->opy, c.ny, c.dy))) return rc;
     return MSL_OK;
 }
 
@@ -1138,6 +1158,45 @@ int msl_create(const msl_config* cfg, msl_handle** out) {
                     return fail(h, MSL_ERR_HIP, "chirp table upload failed");
                 return MSL_OK;
             }
+            if (!two_ok && want && n >= 513 && n <= 1024 && (!smooth || (n >= 640 && n != 768)) && !getenv("MSL_NO_BLUESTEIN_REG")) {
+                // 513..1024: chirp-z on the wave-per-line 2048-point register FFT (every non-smooth length; smooth ones where the
+                // Stockham kernel measured slower: 700: 930 -> 832 us per pass, 1000: 1450 -> 1210; 600 and 768 stay generic)
+                constexpr int M = 2048, NH = 1024;
+                o.R = 32; o.breg2 = true;
+                std::vector<float2> T(M), W(64), bw(NH, make_float2(0.f, 0.f)), bf(NH + 2, make_float2(0.f, 0.f));
+                for (int k1 = 0; k1 < 32; ++k1)
+                    for (int n2 = 0; n2 < 64; ++n2) {
+                        const double a = -2.0 * M_PI * (double)(k1 * n2) / (double)M;
+                        T[k1 * 64 + n2] = make_float2((float)cos(a), (float)sin(a));
+                    }
+                for (int m = 0; m < 32; ++m) {
+                    const double a = -2.0 * M_PI * m / 64.0;
+                    W[m] = make_float2(1.f, 0.f);                                   // even lane of a pair: no twiddle
+                    W[32 + m] = make_float2((float)cos(a), (float)sin(a));          // odd lane: W_64^m
+                }
+                std::vector<double> cr(M, 0.0), ci(M, 0.0);
+                for (int i = 0; i < n; ++i) {
+                    const long long q = ((long long)i * i) % (2LL * n);
+                    const double a = -M_PI * (double)q / (double)n;
+                    bw[i] = make_float2((float)cos(a), (float)sin(a));
+                    cr[i] = cos(a); ci[i] = -sin(a);
+                    if (i) { cr[M - i] = cr[i]; ci[M - i] = ci[i]; }
+                }
+                host_fft_pow2(cr, ci);
+                for (int j = 0; j <= NH; ++j) bf[j] = make_float2((float)(cr[j] / M), (float)(ci[j] / M));
+                int r;
+                if ((r = dalloc(h, &o.tw, (size_t)M))) return r;
+                if ((r = dalloc(h, &o.tw2, (size_t)64))) return r;
+                if ((r = dalloc(h, &o.bw, (size_t)NH))) return r;
+                if ((r = dalloc(h, &o.bf, (size_t)NH + 2))) return r;
+                if ((r = dalloc(h, &o.ptab, (size_t)NH))) return r;
+                if (hipMemcpy(o.tw, T.data(), M * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess ||
+                    hipMemcpy(o.tw2, W.data(), 64 * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess ||
+                    hipMemcpy(o.bw, bw.data(), NH * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess ||
+                    hipMemcpy(o.bf, bf.data(), (NH + 2) * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess)
+                    return fail(h, MSL_ERR_HIP, "chirp table upload failed");
+                return MSL_OK;
+            }
             if (!two_ok) {
                 // generic LDS kernel with a transposing store: tiles of >= 8 lines keep the stores at 64 bytes or more
                 const int M = (&o == &h->opx) ? h->plan_x.M : h->plan_y.M;
@@ -1160,7 +1219,8 @@ int msl_create(const msl_config* cfg, msl_handle** out) {
         if ((rc = setup_dir(h->opx, cfg->nx, cfg->ny, h->Rx, h->tw4_x))) return bail(rc);
         if ((rc = setup_dir(h->opy, cfg->ny, cfg->nx, h->Ry, h->tw4_y))) return bail(rc);
         h->onepass = want && (h->opx.R || h->opx.generic) && (h->opy.R || h->opy.generic) && !cfg->keep_potential;
-        h->scheme_b = h->onepass && (h->opx.two || h->opy.two || h->opx.generic || h->opy.generic || h->opx.breg || h->opy.breg);
+        h->scheme_b = h->onepass && (h->opx.two || h->opy.two || h->opx.generic || h->opy.generic || h->opx.breg || h->opy.breg ||
+                                     h->opx.breg2 || h->opy.breg2);
         if (h->pitch == cfg->ny && h->onepass) h->pitch = cfg->ny + 16;        // pad the work buffers of 2R^2 grids too
         if (h->onepass && (h->pitch & 1)) ++h->pitch;                          // even pitches: the transposed stores write two lines (16 bytes) at a time
         const size_t images = (size_t)cfg->n_probes * h->FB;
@@ -1212,7 +1272,7 @@ int msl_destroy(msl_handle* h) {
                     h->d_pos, h->d_Z, h->d_key, h->d_order, h->d_u1, h->d_u2, h->d_ex, h->d_ey, h->d_counts, h->d_start,
                     h->d_z2s, h->d_species, h->d_ff, h->d_xy, h->plan_x.tw, h->plan_y.tw, h->plan_t.tw, h->tw4_x, h->tw4_y,
                     h->scratch, h->psiT, h->psi0T, h->transT, h->bin_stage, h->st_acc, h->st_s1, h->st_s2, h->st_tw, h->st_bins, h->opx.tw2, h->opx.ptab, h->opy.tw2, h->opy.ptab,
-                    ((h->opx.two || h->opx.breg) ? h->opx.tw : nullptr), ((h->opy.two || h->opy.breg) ? h->opy.tw : nullptr),
+                    ((h->opx.two || h->opx.breg || h->opx.breg2) ? h->opx.tw : nullptr), ((h->opy.two || h->opy.breg || h->opy.breg2) ? h->opy.tw : nullptr),
                     h->opx.bf, h->opx.bw, h->opy.bf, h->opy.bw, h->plan_x.chirp, h->plan_x.bfilt, h->plan_y.chirp, h->plan_y.bfilt, h->plan_t.chirp, h->plan_t.bfilt};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->stream) (void)hipStreamDestroy(h->stream);

@@ -731,6 +731,24 @@ def test_any_length_register_kernel_matches_oracle(ps, orc, nx, ny, nz, P):
     assert ref_residual(got[chk], want) < RESID_TOL
 
 
+@pytest.mark.parametrize("nx,ny,nz,P", [(997, 600, 3, 2), (700, 700, 4, 1), (513, 1000, 2, 2), (1021, 576, 3, 1), (641, 333, 3, 2),
+                                        (768, 1024, 2, 1)])
+def test_lengths_513_to_1024_on_the_2048_point_wave_fft(ps, orc, nx, ny, nz, P):
+    """Lines of 513..1024 points (every non-smooth length, and smooth ones from 576) are chirp-z transforms on the wave-per-line
+    2048-point register FFT (rowTB2_pass_kernel): primes, range ends, line counts that are not multiples of 8, mixes with the
+    1024-point chirp-z kernel, the generic kernel and a power-of-two direction."""
+    from pyslice_amd.synthetic import synthetic_trajectory
+    tr = synthetic_trajectory(nx, nz, 1, ny=ny, density=0.02, seed=nx + 3 * ny)
+    lx, ly = tr.box_matrix[0, 0], tr.box_matrix[1, 1]
+    pp = [tuple(v) for v in np.random.default_rng(10).random((P, 2)) * [lx, ly]]
+    calc = ps.MultisliceCalculator(progress=False, dtype="complex64")
+    calc.setup(tr, aperture=30.0, voltage_eV=100e3, probe_positions=pp)
+    got = npy(calc.run().wavefunction_data)
+    want = orc.run_frames(tr.box_matrix, tr.positions, tr.atom_types, 30.0, 100e3, pp)["wavefunction_data"]
+    assert rel_l2(got, want) < WAVE_TOL
+    assert ref_residual(got, want) < RESID_TOL
+
+
 def test_any_length_register_kernel_deep_stack_and_generic_cross_check(ps, orc, monkeypatch):
     """501 x 491, 100 slices: error growth of the chirp-z passes (8 length-1024 FFTs per line and pass) stays inside the
     contract, and the generic LDS kernels (MSL_NO_BLUESTEIN_REG) give the same exit waves."""
