@@ -1471,6 +1471,138 @@ __global__ void __launch_bounds__(512, 2) rowTB2_pass_kernel(RowTJob job) {
     }
 }
 
+// Transposing pass A . t_k . A for 2048-point lines on fft2048_wave: one wave per line, 8 lines per workgroup, the next line
+// prefetched in registers, t_k in registers across a chunk of probes (rowT_pass_kernel's scheme; the 2 R^2 layout of
+// rowT2_pass_kernel<32> has room for neither).  IN_P / OUT_P: paired-lines layout of the work buffers between two passes.
+template <bool IN_P, bool OUT_P>
+__global__ void __launch_bounds__(512, 2) rowTW_pass_kernel(RowTJob job) {
+    constexpr int R = 32, N = 2048, H = 16, LINES = 8, NT = 512, TCH = 8;
+    constexpr int RS = N + 1;                                 // tile row in float2 (>= the 32 x 97 floats of transpose scratch; = 1 mod 32)
+    constexpr int NHT = N / 2 + 2;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float2* tw = reinterpret_cast<float2*>(smem_raw);         // 2048
+    float2* w64 = tw + N;                                     // 64
+    float2* plh = w64 + 64;                                   // N/2 + 2: symmetric Fresnel table, first half
+    float2* tile = plh + NHT;                                 // LINES * RS
+    const int tid = threadIdx.x;
+    for (int i = tid; i < N; i += NT) tw[i] = job.tw[i];
+    if (tid < 64) w64[tid] = job.tw2[tid];
+    for (int i = tid; i <= N / 2; i += NT) plh[i] = job.pl[i];
+    __syncthreads();
+    const int wv = tid >> 6, L = tid & 63, la = lam64(L);
+    const float sgn = (L & 1) ? -1.f : 1.f;
+    float2* myrow = tile + wv * RS;
+    float* scr = reinterpret_cast<float*>(myrow);
+    const float2* pa = plh + la;
+    const float2* pb = plh - la;
+    auto mul_p = [&](float2 (&vv)[R]) {
+#pragma unroll
+        for (int c = 0; c < R; c += TCH) {
+            float2 w[TCH];
+#pragma unroll
+            for (int j = 0; j < TCH; ++j) w[j] = (c + j < H) ? pa[(c + j) * 64] : pb[(R - (c + j)) * 64];
+#pragma unroll
+            for (int j = 0; j < TCH; ++j) vv[c + j] = cmulf(vv[c + j], w[j]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    const int lblocks = job.n_lines / LINES;
+    const int PC = job.pchunk;
+    const int pchunks = (job.n_images + PC - 1) / PC;
+    const int n_items = lblocks * pchunks;
+    const int step_lb = (int)gridDim.x / pchunks, step_pc = (int)gridDim.x % pchunks;
+    constexpr int ES = IN_P ? 2 : 1;
+    auto line_ptr = [&](int lbb, int pcc, int kk) {
+        const int Ln = lbb * LINES + wv;
+        const long long off = IN_P ? (long long)(Ln >> 1) * (2 * job.in_pitch) + (Ln & 1) : (long long)Ln * job.in_pitch;
+        return job.in + (long long)(pcc * PC + kk) * job.in_image_stride + off + la * ES;
+    };
+    int item = blockIdx.x;
+    int lb = item / pchunks, pc = item - lb * pchunks, k = 0;
+    float2 vn[R];
+    if (item < n_items) {
+        const float2* r = line_ptr(lb, pc, 0);
+#pragma unroll
+        for (int j = 0; j < R; ++j) vn[j] = r[j * 64 * ES];
+    }
+    float2 tv[R];
+    while (item < n_items) {
+        float2 v[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) v[j] = vn[j];
+        const int p = pc * PC + k;
+        const int cur_lb = lb;
+        if (k == 0) {
+            const float2* trow = job.trans + frame_off(job, pc * PC) + (long long)(lb * LINES + wv) * N + la;
+#pragma unroll
+            for (int j = 0; j < R; ++j) tv[j] = trow[j * 64];
+        }
+        int nitem = item, nlb = lb, npc = pc, nk = k + 1;
+        if (nk >= min(PC, job.n_images - pc * PC)) {
+            nk = 0; nitem = item + (int)gridDim.x; nlb = lb + step_lb; npc = pc + step_pc;
+            if (npc >= pchunks) { npc -= pchunks; ++nlb; }
+        }
+        auto prefetch_part = [&](auto lo_c, auto hi_c) {
+            constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
+            __builtin_amdgcn_sched_barrier(0);
+            if (nitem < n_items) {
+                const float2* r = line_ptr(nlb, npc, nk);
+#pragma unroll
+                for (int j = LO; j < HI; ++j) vn[j] = r[j * 64 * ES];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        if (job.flags & P2_PRE_A) fft2048_wave<false, TCH>(v, scr, tw, w64, L, la, sgn);
+        prefetch_part(MSL_IC(0), MSL_IC(8));
+        if (job.flags & P2_PRE_A) {
+            mul_p(v);
+            fft2048_wave<true, TCH>(v, scr, tw, w64, L, la, sgn);
+        }
+        prefetch_part(MSL_IC(8), MSL_IC(16));
+#pragma unroll
+        for (int j = 0; j < R; ++j) v[j] = cmulf(v[j], tv[j]);
+        if (job.flags & P2_POST_A) fft2048_wave<false, TCH>(v, scr, tw, w64, L, la, sgn);
+        prefetch_part(MSL_IC(16), MSL_IC(24));
+        if (job.flags & P2_POST_A) {
+            mul_p(v);
+            fft2048_wave<true, TCH>(v, scr, tw, w64, L, la, sgn);
+        }
+        prefetch_part(MSL_IC(24), MSL_IC(32));
+        wave_lds_fence();
+#pragma unroll
+        for (int j = 0; j < R; ++j) myrow[j * 64 + la] = v[j];
+        lds_barrier();
+        if constexpr (OUT_P) {
+            const int i = tid & 7, oct = tid >> 3, q = oct & 3, hh = oct >> 2;
+            const int mm0 = (hh & 3) + 4 * q + 16 * (hh >> 2);             // 0 .. 63
+            const float2* src = tile + i * RS + 2 * mm0;
+            float2* dst = job.out + (long long)p * job.out_image_stride + 2 * (cur_lb * LINES + i);
+            int off0 = mm0 * 2 * job.out_pitch;
+            asm volatile("" : "+v"(off0));
+            const int ostep = 64 * 2 * job.out_pitch;
+#pragma unroll
+            for (int it = 0; it < N / 2 / 64; ++it) {
+                const float2 a = src[it * 128], b = src[it * 128 + 1];
+                *reinterpret_cast<float4*>(dst + (off0 + it * ostep)) = make_float4(a.x, a.y, b.x, b.y);
+            }
+        } else {
+            const int q4 = tid & 3, e0 = tid >> 2;
+            float2* dst = job.out + (long long)p * job.out_image_stride + cur_lb * LINES + 2 * q4;
+            int off0 = e0 * job.out_pitch;
+            asm volatile("" : "+v"(off0));
+            const int ostep = (NT / 4) * job.out_pitch;
+#pragma unroll
+            for (int it = 0; it < N / (NT / 4); ++it) {
+                const int e = e0 + (NT / 4) * it;
+                const float2 a = tile[(2 * q4) * RS + e], b = tile[(2 * q4 + 1) * RS + e];
+                *reinterpret_cast<float4*>(dst + (off0 + it * ostep)) = make_float4(a.x, a.y, b.x, b.y);
+            }
+        }
+        lds_barrier();
+        item = nitem; lb = nlb; pc = npc; k = nk;
+    }
+}
+
 // ---- lines of N = 2 R^2 points (512 = 2*16^2, 2048 = 2*32^2) ----------------------------------------------
 // One radix-2 step wrapped around two four-step transforms.  A group of R lanes holds two register sets; in the
 // natural domain set b, register j, lane l is element b*R^2 + j*R + l.  The forward transform is decimation in

@@ -74,7 +74,7 @@ struct msl_handle {
     // one-pass kernel per direction: R^2 register kernel, 2 R^2 (two) register kernel with its tables, or the generic LDS kernel
     // (breg: any length <= R^2/2 by Bluestein's chirp-z on the R^2 register FFTs, with its filter bf and chirp bw)
     // (breg2: lengths 513..1024 by the same scheme on the wave-per-line 2048-point FFT; tw = T[k1*64+n2], tw2 = W_64 table)
-    struct OpDir { int R = 0; bool two = false; bool generic = false; bool breg = false; bool breg2 = false; float2* tw = nullptr; float2* tw2 = nullptr;
+    struct OpDir { int R = 0; bool two = false; bool generic = false; bool breg = false; bool breg2 = false; bool wave2k = false; float2* tw = nullptr; float2* tw2 = nullptr;
                    float2* ptab = nullptr; float2* bf = nullptr; float2* bw = nullptr; } opx, opy;
     float2* psiT = nullptr;
     float2* psi0T = nullptr;
@@ -751,6 +751,29 @@ int launch_rowTB2_io(msl_handle* h, RowTJob job, int kind) {
     return mark_launch(h, kind);
 }
 
+// 2048-point lines, one wave per line (fft2048_wave)
+template <bool IN_P, bool OUT_P>
+int launch_rowTW_io(msl_handle* h, RowTJob job, int kind) {
+    constexpr int N = 2048;
+    const size_t lds = ((size_t)N + 64 + N / 2 + 2 + (size_t)8 * (N + 1)) * 8;
+    const long long slots = h->n_cus;
+    const long long lb = job.n_lines / 8;
+    int pc = choose_pchunk(lb, job.n_images, slots, job.t_group);
+    if (h->row_pchunk > 0) { pc = std::min(h->row_pchunk, job.n_images); if (job.t_group > 0) while (job.t_group % pc) --pc; }
+    job.pchunk = pc;
+    const long long items = lb * ((job.n_images + pc - 1) / pc);
+    const int grid = (int)std::min<long long>(items, slots);
+    (void)hipFuncSetAttribute((const void*)rowTW_pass_kernel<IN_P, OUT_P>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
+    hipLaunchKernelGGL((rowTW_pass_kernel<IN_P, OUT_P>), dim3(grid), dim3(512), lds, h->stream, job);
+    HIPCHK(h, hipGetLastError());
+    return mark_launch(h, kind);
+}
+int launch_rowTW(msl_handle* h, const RowTJob& job, int kind) {
+    const bool in_p = job.flags & P2_IN_PAIRED, out_p = job.flags & P2_OUT_PAIRED;
+    if (in_p) return out_p ? launch_rowTW_io<true, true>(h, job, kind) : launch_rowTW_io<true, false>(h, job, kind);
+    return out_p ? launch_rowTW_io<false, true>(h, job, kind) : launch_rowTW_io<false, false>(h, job, kind);
+}
+
 // one transposing pass along direction `o`: register kernels for R^2 and 2 R^2 points, else the generic LDS kernel
 // running the same program (fft, x P, ifft, x t, fft, x P, ifft) with a transposing store
 int launch_rowT_dir(msl_handle* h, const msl_handle::OpDir& o, RowTJob job, int kind) {
@@ -779,6 +802,8 @@ int launch_rowT_dir(msl_handle* h, const msl_handle::OpDir& o, RowTJob job, int 
         return launch_lines(h, pl, a, kind);
     }
     job.tw = o.tw;
+    if (o.wave2k) { job.tw2 = o.tw2; return launch_rowTW(h, job, kind); }
+    job.flags &= ~(P2_IN_PAIRED | P2_OUT_PAIRED);
     if (o.breg || o.breg2) {
         job.pl = o.ptab; job.bf = o.bf; job.bw = o.bw;
         job.n_line = (&o == &h->opx) ? h->cfg.nx : h->cfg.ny;
@@ -810,6 +835,8 @@ int slice_loop_onepass_b(msl_handle* h, int fused_slot, int groups, int first_gr
         if (h->debug_flags_mask >= 0) j.flags &= h->debug_flags_mask;
         j.n_images = P;
         if (groups > 1) { j.t_group = c.n_probes; j.t_magic = (unsigned)((1ull << 32) / (unsigned)c.n_probes + 1); j.t_stride = (long long)c.nz * npix; }
+        if (h->opx.wave2k && h->opy.wave2k)               // work buffers between two of these passes: paired-lines layout
+            j.flags |= (k > 0 ? P2_IN_PAIRED : 0) | (k < nz - 1 ? P2_OUT_PAIRED : 0);
         if (!(k & 1)) {
             j.in = (k == 0) ? h->psi0 : h->psi; j.out = h->psiT;
             j.trans = h->trans + toff + (size_t)k * npix; j.pl = h->pyt;
@@ -1130,6 +1157,28 @@ int msl_create(const msl_config* cfg, msl_handle** out) {
             if (Rfast && lines_ok) { o.R = Rfast; o.two = false; o.tw = tw4; return MSL_OK; }
             const int R2 = (n == 512) ? 16 : (n == 2048 ? 32 : 0);
             const bool two_ok = R2 && lines_ok && want && !getenv("MSL_NO_TWO");
+            if (n == 2048 && two_ok && n_other % 8 == 0 && !(getenv("MSL_WAVE2K") && atoi(getenv("MSL_WAVE2K")) == 0)) {
+                // 2048-point lines on the wave-per-line FFT (tables: T[k1*64+n2], W_64; the natural Fresnel table serves as is)
+                o.R = 32; o.wave2k = true;
+                std::vector<float2> T(2048), W(64);
+                for (int k1 = 0; k1 < 32; ++k1)
+                    for (int n2 = 0; n2 < 64; ++n2) {
+                        const double a = -2.0 * M_PI * (double)(k1 * n2) / 2048.0;
+                        T[k1 * 64 + n2] = make_float2((float)cos(a), (float)sin(a));
+                    }
+                for (int m = 0; m < 32; ++m) {
+                    const double a = -2.0 * M_PI * m / 64.0;
+                    W[m] = make_float2(1.f, 0.f);
+                    W[32 + m] = make_float2((float)cos(a), (float)sin(a));
+                }
+                int r;
+                if ((r = dalloc(h, &o.tw, (size_t)2048))) return r;
+                if ((r = dalloc(h, &o.tw2, (size_t)64))) return r;
+                if (hipMemcpy(o.tw, T.data(), 2048 * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess ||
+                    hipMemcpy(o.tw2, W.data(), 64 * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess)
+                    return fail(h, MSL_ERR_HIP, "twiddle upload failed");
+                return MSL_OK;
+            }
             // chirp-z on the register FFTs of length M = R^2 >= 2n - 1.  A line costs the same whatever n is, so against the
             // generic Stockham kernel (cost ~ n log n) it wins for n <= 128 (M = 256) and from n ~ 270 up (M = 1024), and everywhere
             // the generic kernel would need its own, LDS-resident Bluestein transform (a prime factor above 13)
@@ -1220,7 +1269,7 @@ int msl_create(const msl_config* cfg, msl_handle** out) {
         if ((rc = setup_dir(h->opy, cfg->ny, cfg->nx, h->Ry, h->tw4_y))) return bail(rc);
         h->onepass = want && (h->opx.R || h->opx.generic) && (h->opy.R || h->opy.generic) && !cfg->keep_potential;
         h->scheme_b = h->onepass && (h->opx.two || h->opy.two || h->opx.generic || h->opy.generic || h->opx.breg || h->opy.breg ||
-                                     h->opx.breg2 || h->opy.breg2);
+                                     h->opx.breg2 || h->opy.breg2 || h->opx.wave2k || h->opy.wave2k);
         if (h->pitch == cfg->ny && h->onepass) h->pitch = cfg->ny + 16;        // pad the work buffers of 2R^2 grids too
         if (h->onepass && (h->pitch & 1)) ++h->pitch;                          // even pitches: the transposed stores write two lines (16 bytes) at a time
         const size_t images = (size_t)cfg->n_probes * h->FB;
@@ -1272,7 +1321,7 @@ int msl_destroy(msl_handle* h) {
                     h->d_pos, h->d_Z, h->d_key, h->d_order, h->d_u1, h->d_u2, h->d_ex, h->d_ey, h->d_counts, h->d_start,
                     h->d_z2s, h->d_species, h->d_ff, h->d_xy, h->plan_x.tw, h->plan_y.tw, h->plan_t.tw, h->tw4_x, h->tw4_y,
                     h->scratch, h->psiT, h->psi0T, h->transT, h->bin_stage, h->st_acc, h->st_s1, h->st_s2, h->st_tw, h->st_bins, h->opx.tw2, h->opx.ptab, h->opy.tw2, h->opy.ptab,
-                    ((h->opx.two || h->opx.breg || h->opx.breg2) ? h->opx.tw : nullptr), ((h->opy.two || h->opy.breg || h->opy.breg2) ? h->opy.tw : nullptr),
+                    ((h->opx.two || h->opx.breg || h->opx.breg2 || h->opx.wave2k) ? h->opx.tw : nullptr), ((h->opy.two || h->opy.breg || h->opy.breg2 || h->opy.wave2k) ? h->opy.tw : nullptr),
                     h->opx.bf, h->opx.bw, h->opy.bf, h->opy.bw, h->plan_x.chirp, h->plan_x.bfilt, h->plan_y.chirp, h->plan_y.bfilt, h->plan_t.chirp, h->plan_t.bfilt};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->stream) (void)hipStreamDestroy(h->stream);

@@ -749,6 +749,25 @@ def test_lengths_513_to_1024_on_the_2048_point_wave_fft(ps, orc, nx, ny, nz, P):
     assert ref_residual(got, want) < RESID_TOL
 
 
+@pytest.mark.parametrize("nx,ny,nz,P", [(2048, 2048, 3, 1), (2048, 2048, 4, 2), (2048, 512, 3, 2), (2048, 2048, 1, 1)])
+def test_2048_point_wave_per_line_kernel_matches_oracle(ps, orc, nx, ny, nz, P, monkeypatch):
+    """2048-point lines on fft2048_wave (one wave per line, paired-lines layout between two such passes; a 2048 x 512 grid
+    alternates with the 512-point kernel through the natural layout); odd and even depths; and the 2 R^2 kernel it replaced
+    (MSL_WAVE2K=0) on the same input."""
+    from pyslice_amd.synthetic import synthetic_trajectory
+    if nz == 3 and P == 1:
+        monkeypatch.setenv("MSL_WAVE2K", "0")
+    tr = synthetic_trajectory(nx, nz, 1, ny=ny, density=0.004, seed=nz)
+    lx, ly = tr.box_matrix[0, 0], tr.box_matrix[1, 1]
+    pp = [tuple(v) for v in np.random.default_rng(12).random((P, 2)) * [lx, ly]]
+    calc = ps.MultisliceCalculator(progress=False, dtype="complex64")
+    calc.setup(tr, aperture=30.0, voltage_eV=100e3, probe_positions=pp)
+    got = npy(calc.run().wavefunction_data)
+    want = orc.run_frames(tr.box_matrix, tr.positions, tr.atom_types, 30.0, 100e3, pp)["wavefunction_data"]
+    assert rel_l2(got, want) < WAVE_TOL
+    assert ref_residual(got, want) < RESID_TOL
+
+
 def test_any_length_register_kernel_deep_stack_and_generic_cross_check(ps, orc, monkeypatch):
     """501 x 491, 100 slices: error growth of the chirp-z passes (8 length-1024 FFTs per line and pass) stays inside the
     contract, and the generic LDS kernels (MSL_NO_BLUESTEIN_REG) give the same exit waves."""
