@@ -93,6 +93,56 @@ __device__ __forceinline__ void fourstep_split(float2 (&v)[R], float* scratch, c
     fft_regs<R, INV>(v);
 }
 
+// The same exchange with 16-byte reads: scratch rows of PW = R + 4 floats (16-byte aligned; a lane's R consecutive floats come
+// back as R/4 ds_read_b128, conflict-free at this pitch: 16 lanes x 4 dwords cover the 64 banks) -- half the LDS read cycles and
+// a quarter of the read instructions of the R + 1 pitch.  The scratch must be 16-byte aligned and hold R (R + 4) floats.
+template <int R, bool INV, int CH = 8>
+__device__ __forceinline__ void fourstep_split_wide(float2 (&v)[R], float* scratch, const float2* tw, int ln) {
+    static_assert(64 % R == 0 && R % 4 == 0, "an R-lane group must lie inside one wave; rows are read four floats at a time");
+    constexpr int PW = R + 4;
+    fft_regs<R, INV>(v);
+    mul_table<R, 1, INV, R, CH>(v, tw, ln);
+#pragma unroll
+    for (int k1 = 0; k1 < R; ++k1) scratch[k1 * PW + ln] = v[k1].x;
+    wave_lds_fence();
+#pragma unroll
+    for (int g = 0; g < R / 4; ++g) {
+        const float4 q = *reinterpret_cast<const float4*>(scratch + ln * PW + 4 * g);
+        v[4 * g].x = q.x; v[4 * g + 1].x = q.y; v[4 * g + 2].x = q.z; v[4 * g + 3].x = q.w;
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int k1 = 0; k1 < R; ++k1) scratch[k1 * PW + ln] = v[k1].y;
+    wave_lds_fence();
+#pragma unroll
+    for (int g = 0; g < R / 4; ++g) {
+        const float4 q = *reinterpret_cast<const float4*>(scratch + ln * PW + 4 * g);
+        v[4 * g].y = q.x; v[4 * g + 1].y = q.y; v[4 * g + 2].y = q.z; v[4 * g + 3].y = q.w;
+    }
+    wave_lds_fence();
+    fft_regs<R, INV>(v);
+}
+
+// Complex form of the wide exchange: 8-byte writes (one per register instead of two), 16-byte reads of two complex values;
+// scratch rows of R + 2 float2 (16-byte aligned, conflict-free for both patterns), R (R + 2) float2 in all.
+template <int R, bool INV, int CH = 8>
+__device__ __forceinline__ void fourstep_c64_wide(float2 (&v)[R], float2* scratch, const float2* tw, int ln) {
+    static_assert(64 % R == 0 && R % 2 == 0, "an R-lane group must lie inside one wave");
+    constexpr int PW = R + 2;
+    fft_regs<R, INV>(v);
+    mul_table<R, 1, INV, R, CH>(v, tw, ln);
+#pragma unroll
+    for (int k1 = 0; k1 < R; ++k1) scratch[k1 * PW + ln] = v[k1];
+    wave_lds_fence();
+#pragma unroll
+    for (int g = 0; g < R / 2; ++g) {
+        const float4 q = *reinterpret_cast<const float4*>(scratch + ln * PW + 2 * g);
+        v[2 * g] = make_float2(q.x, q.y); v[2 * g + 1] = make_float2(q.z, q.w);
+    }
+    wave_lds_fence();
+    fft_regs<R, INV>(v);
+}
+
 // same with a complex scratch of R*(R+1) float2 (column pass: the tile is in LDS anyway)
 template <int R, bool INV, int CH = 8>
 __device__ __forceinline__ void fourstep_c64(float2 (&v)[R], float2* scratch, const float2* tw, int ln) {
@@ -106,6 +156,19 @@ __device__ __forceinline__ void fourstep_c64(float2 (&v)[R], float2* scratch, co
     for (int n2 = 0; n2 < R; ++n2) v[n2] = scratch[ln * (R + 1) + n2];
     wave_lds_fence();
     fft_regs<R, INV>(v);
+}
+
+// Exchange variants of the transposing kernels: 0 = real and imaginary parts one after the other, rows of R + 1 floats;
+// 1 = complex, rows of R + 1 float2; 2 / 3 = the same with 16-byte reads (rows of R + 4 floats / R + 2 float2).
+template <int R, int XCH> constexpr int xch_scratch_float2() {      // scratch per line in float2
+    return XCH == 0 ? (R * (R + 1) + 1) / 2 : XCH == 1 ? R * (R + 1) : XCH == 2 ? R * (R + 4) / 2 : R * (R + 2);
+}
+template <int R, bool INV, int XCH, int CH>
+__device__ __forceinline__ void fourstep_x(float2 (&v)[R], float2* scratch, const float2* tw, int ln) {
+    if constexpr (XCH == 0) fourstep_split<R, INV, CH>(v, reinterpret_cast<float*>(scratch), tw, ln);
+    else if constexpr (XCH == 1) fourstep_c64<R, INV, CH>(v, scratch, tw, ln);
+    else if constexpr (XCH == 2) fourstep_split_wide<R, INV, CH>(v, reinterpret_cast<float*>(scratch), tw, ln);
+    else fourstep_c64_wide<R, INV, CH>(v, scratch, tw, ln);
 }
 
 // The two halves of a four-step transform (diagnostic build of the transposing pass: phase timing per half):
@@ -586,7 +649,7 @@ struct RowTJob {
 #define MSL_STAMP(id)
 #endif
 
-template <int R, int LINES, bool C64>
+template <int R, int LINES, int XCH>
 __global__ void __launch_bounds__(LINES * R, (R == 16) ? 3 : 2) rowT_pass_kernel(RowTJob job) {
     constexpr int N = R * R;
 #ifdef MSL_STAMPS
@@ -595,7 +658,9 @@ __global__ void __launch_bounds__(LINES * R, (R == 16) ? 3 : 2) rowT_pass_kernel
     constexpr int TCH = (R == 32) ? 16 : 8;             // table-multiply chunk (see mul_table)
 #endif
     constexpr int NT = LINES * R;
-    constexpr int CS = R * (R + 1) + 1;
+    // tile line pitch in float2: the 1024 positions of a line / the exchange scratch, whichever is larger; odd (narrow
+    // exchanges) or 2 mod 32 (wide ones, whose rows must be 16-byte aligned): conflict-free staging either way
+    constexpr int CS = (XCH < 2) ? R * (R + 1) + 1 : ((xch_scratch_float2<R, XCH>() > R * R ? xch_scratch_float2<R, XCH>() : R * R) + 33) / 32 * 32 + 2;
     constexpr int TPS = LINES / 2;                    // threads (16 B = 2 lines each) per output segment of LINES*8 bytes
     constexpr int POS_PER_IT = NT / TPS;
     constexpr int NIT = N / POS_PER_IT;
@@ -691,7 +756,7 @@ __global__ void __launch_bounds__(LINES * R, (R == 16) ? 3 : 2) rowT_pass_kernel
         };
         auto tail = [&](auto inv_c) {
             constexpr bool INV = decltype(inv_c)::value;
-            if constexpr (MSL_ABL & 4) fft_regs<R, INV>(v); else fourstep_tail<R, INV, C64>(v, myrow, ln);
+            if constexpr (MSL_ABL & 4) fft_regs<R, INV>(v); else fourstep_tail<R, INV, (XCH & 1) != 0>(v, myrow, ln);
         };
         auto mulp = [&]() {
             if constexpr (MSL_ABL & 8) {
@@ -719,23 +784,23 @@ __global__ void __launch_bounds__(LINES * R, (R == 16) ? 3 : 2) rowT_pass_kernel
         pf(MSL_IC(24), MSL_IC(32)); MSL_STAMP(17);
 #else
         if (job.flags & P2_PRE_A) {
-            if constexpr (C64) fourstep_c64<R, false, TCH>(v, myrow, tw, ln); else fourstep_split<R, false, TCH>(v, reinterpret_cast<float*>(myrow), tw, ln);
+            fourstep_x<R, false, XCH, TCH>(v, myrow, tw, ln);
         }
         prefetch_part(MSL_IC(0), MSL_IC(8));
         if (job.flags & P2_PRE_A) {
             mul_table<R, 0, false, R, TCH>(v, pl, ln);
-            if constexpr (C64) fourstep_c64<R, true, TCH>(v, myrow, tw, ln); else fourstep_split<R, true, TCH>(v, reinterpret_cast<float*>(myrow), tw, ln);
+            fourstep_x<R, true, XCH, TCH>(v, myrow, tw, ln);
         }
         prefetch_part(MSL_IC(8), MSL_IC(16));
 #pragma unroll
         for (int j = 0; j < R; ++j) v[j] = cmulf(v[j], tv[j]);
         if (job.flags & P2_POST_A) {
-            if constexpr (C64) fourstep_c64<R, false, TCH>(v, myrow, tw, ln); else fourstep_split<R, false, TCH>(v, reinterpret_cast<float*>(myrow), tw, ln);
+            fourstep_x<R, false, XCH, TCH>(v, myrow, tw, ln);
         }
         prefetch_part(MSL_IC(16), MSL_IC(24));
         if (job.flags & P2_POST_A) {
             mul_table<R, 0, false, R, TCH>(v, pl, ln);
-            if constexpr (C64) fourstep_c64<R, true, TCH>(v, myrow, tw, ln); else fourstep_split<R, true, TCH>(v, reinterpret_cast<float*>(myrow), tw, ln);
+            fourstep_x<R, true, XCH, TCH>(v, myrow, tw, ln);
         }
         prefetch_part(MSL_IC(24), MSL_IC(32));
 #endif
@@ -1091,7 +1156,7 @@ __global__ void __launch_bounds__(256, 3) rowT3_pass_kernel(RowTJob job) {
 template <int R>
 __global__ void __launch_bounds__(16 * R, (R == 32) ? 2 : 4) rowTB_pass_kernel(RowTJob job) {
     constexpr int M = R * R, H = R / 2, NH = M / 2, LINES = 16, NT = LINES * R, TCH = 8;
-    constexpr int CS = R * (R + 1) + 1;
+    constexpr int CS = R * (R + 1) + 2;               // even (16-byte aligned rows for the wide exchange), conflict-free staging
     constexpr int TPS = LINES / 2, POS_PER_IT = NT / TPS, NIT = NH / POS_PER_IT;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float2* tw = reinterpret_cast<float2*>(smem_raw);         // M: four-step twiddles
@@ -1187,15 +1252,15 @@ __global__ void __launch_bounds__(16 * R, (R == 32) ? 2 : 4) rowTB_pass_kernel(R
         // A = ifft_N . P . fft_N on the zero-padded line
         auto a_first = [&]() {
             mul_half(v, bw, std::false_type{});
-            fourstep_split<R, false, TCH>(v, scr, tw, ln);
+            fourstep_split_wide<R, false, TCH>(v, scr, tw, ln);
             mul_filter(v, std::false_type{});
-            fourstep_split<R, true, TCH>(v, scr, tw, ln);
+            fourstep_split_wide<R, true, TCH>(v, scr, tw, ln);
         };
         auto a_second = [&]() {
             mul_half(v, bp, std::false_type{});
-            fourstep_split<R, false, TCH>(v, scr, tw, ln);
+            fourstep_split_wide<R, false, TCH>(v, scr, tw, ln);
             mul_filter(v, std::true_type{});
-            fourstep_split<R, true, TCH>(v, scr, tw, ln);
+            fourstep_split_wide<R, true, TCH>(v, scr, tw, ln);
             mul_half(v, bw, std::true_type{});
         };
         if (job.flags & P2_PRE_A) a_first();

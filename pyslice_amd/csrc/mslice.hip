@@ -86,7 +86,7 @@ struct msl_handle {
     unsigned stage_pos = 0;
     float2* transT = nullptr;
     int pitchT = 0;
-    int rowT_variant = 0;
+    int rowT_variant = 2;
     int rowT_paired = 0;           // MSL_ROWT_PAIRED=1: 8-line tiles in the paired-lines layout, two workgroups per CU (measured equal: DESIGN 4.1)
     int debug_flags_mask = -1;
     int row_pchunk = 0;         // 0 = auto (MSL_ROW_PCHUNK)
@@ -620,11 +620,12 @@ int transpose_odd_slices(msl_handle* h) {
     return MSL_OK;
 }
 
-template <int R, int LINES, bool C64>
+template <int R, int LINES, int XCH>
 int launch_rowT_v(msl_handle* h, RowTJob job, int kind) {
-    constexpr int N = R * R, CS = R * (R + 1) + 1;
+    constexpr int N = R * R;
+    constexpr int CS = (XCH < 2) ? R * (R + 1) + 1 : ((xch_scratch_float2<R, XCH>() > R * R ? xch_scratch_float2<R, XCH>() : R * R) + 33) / 32 * 32 + 2;
     const size_t lds = ((size_t)2 * N + (size_t)LINES * CS) * 8;
-    // R = 32: 245 VGPRs, 151 KB -> one workgroup per CU; R = 16: 135 VGPRs, 39 KB -> three (MSL_ROWT_PER_CU overrides)
+    // R = 32: ~250 VGPRs, 152-156 KB -> one workgroup per CU; R = 16: 135 VGPRs, 39 KB -> three (MSL_ROWT_PER_CU overrides)
     int cap = (R == 16) ? 3 : 2;
     { const char* e = getenv("MSL_ROWT_PER_CU"); if (e && atoi(e) > 0) cap = atoi(e); }
     const int per_cu = std::max(1, std::min(cap, (int)((size_t)h->lds_limit / lds)));
@@ -635,16 +636,22 @@ int launch_rowT_v(msl_handle* h, RowTJob job, int kind) {
     job.pchunk = pc;
     const long long items = lb * ((job.n_images + pc - 1) / pc);
     const int grid = (int)std::min<long long>(items, slots);
-    (void)hipFuncSetAttribute((const void*)rowT_pass_kernel<R, LINES, C64>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
-    hipLaunchKernelGGL((rowT_pass_kernel<R, LINES, C64>), dim3(grid), dim3(LINES * R), lds, h->stream, job);
+    (void)hipFuncSetAttribute((const void*)rowT_pass_kernel<R, LINES, XCH>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
+    hipLaunchKernelGGL((rowT_pass_kernel<R, LINES, XCH>), dim3(grid), dim3(LINES * R), lds, h->stream, job);
     HIPCHK(h, hipGetLastError());
     return mark_launch(h, kind);
 }
 
-// MSL_ROWT_VARIANT: 0 (default) = real and imaginary parts transposed one after the other, 1 = complex (b64) transposes
+// MSL_ROWT_VARIANT = exchange through the LDS inside the four-step transforms: 0 = real and imaginary parts one after the
+// other, 1 = complex, 2 / 3 = the same with 16-byte reads (default 2: 284 -> 275 us per 1024^2 x 64 pass)
 template <int R>
 int launch_rowT_r(msl_handle* h, RowTJob job, int kind) {
-    return h->rowT_variant == 1 ? launch_rowT_v<R, 16, true>(h, job, kind) : launch_rowT_v<R, 16, false>(h, job, kind);
+    switch (h->rowT_variant) {
+        case 0: return launch_rowT_v<R, 16, 0>(h, job, kind);
+        case 1: return launch_rowT_v<R, 16, 1>(h, job, kind);
+        case 3: return launch_rowT_v<R, 16, 3>(h, job, kind);
+        default: return launch_rowT_v<R, 16, 2>(h, job, kind);
+    }
 }
 
 // paired-lines transposing pass (1024-point lines in both directions): two 256-thread workgroups per CU
@@ -717,7 +724,7 @@ int launch_rowT2_r(msl_handle* h, RowTJob job, int kind) {
 // lines of any length <= R^2/2: Bluestein on the register FFTs
 template <int R>
 int launch_rowTB_r(msl_handle* h, RowTJob job, int kind) {
-    constexpr int M = R * R, NH = M / 2, CS = R * (R + 1) + 1;
+    constexpr int M = R * R, NH = M / 2, CS = R * (R + 1) + 2;
     const size_t lds = ((size_t)M + NH + 2 + NH + NH + (size_t)16 * CS) * 8;
     const int per_cu = std::max(1, std::min(R == 16 ? 4 : 1, (int)((size_t)h->lds_limit / lds)));
     const long long slots = (long long)h->n_cus * per_cu;
