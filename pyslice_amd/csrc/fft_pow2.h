@@ -1674,7 +1674,7 @@ __global__ void __launch_bounds__(512, 2) rowTW_pass_kernel(RowTJob job) {
 // frequency (a = x0 + x1, d = (x0 - x1) W_N^m, then N/2-point transforms of a and d give X[2k] and X[2k+1]); the
 // inverse is the mirror decimation in time.  The frequency domain therefore lives in "split" order -- set b, slot k
 // holds X[2k+b] -- which never leaves the kernel: the propagator table is stored in the same order.
-template <int R, bool INV>
+template <int R, bool INV, bool WIDE = false>
 __device__ __forceinline__ void line2_transform(float2 (&v)[2 * R], float* scratch, const float2* tw, const float2* tw2, int ln) {
     static_assert(64 % R == 0, "an R-lane group must lie inside one wave: the scratch is ordered per wave only");
     float2 (&lo)[R] = reinterpret_cast<float2 (&)[R]>(v[0]);
@@ -1694,13 +1694,13 @@ __device__ __forceinline__ void line2_transform(float2 (&v)[2 * R], float* scrat
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        fourstep_split<R, false>(lo, scratch, tw, ln);
+        (WIDE ? fourstep_split_wide<R, false>(lo, scratch, tw, ln) : fourstep_split<R, false>(lo, scratch, tw, ln));
         __builtin_amdgcn_sched_barrier(0);
-        fourstep_split<R, false>(hi, scratch, tw, ln);
+        (WIDE ? fourstep_split_wide<R, false>(hi, scratch, tw, ln) : fourstep_split<R, false>(hi, scratch, tw, ln));
     } else {
-        fourstep_split<R, true>(lo, scratch, tw, ln);
+        (WIDE ? fourstep_split_wide<R, true>(lo, scratch, tw, ln) : fourstep_split<R, true>(lo, scratch, tw, ln));
         __builtin_amdgcn_sched_barrier(0);
-        fourstep_split<R, true>(hi, scratch, tw, ln);
+        (WIDE ? fourstep_split_wide<R, true>(hi, scratch, tw, ln) : fourstep_split<R, true>(hi, scratch, tw, ln));
 #pragma unroll
         for (int c = 0; c < R; c += CH) {
             float2 w[CH];
@@ -1726,7 +1726,8 @@ __global__ void __launch_bounds__(16 * R, 2) rowT2_pass_kernel(RowTJob job) {   
     constexpr bool BIG = (R == 32);
     constexpr int CPOS = BIG ? N2 : N;                 // positions per store chunk
     constexpr int NCHUNK = N / CPOS;
-    constexpr int CS = CPOS + 1;                       // tile line pitch (odd)
+    constexpr bool WIDE = !BIG;                        // 16-byte exchange reads (rows 16-byte aligned: even pitch)
+    constexpr int CS = BIG ? CPOS + 1 : CPOS + 2;      // tile line pitch: odd, or 2 mod 32 -- conflict-free staging either way
     constexpr int POS_PER_IT = NT / 8;
     constexpr int NIT = CPOS / POS_PER_IT;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -1826,9 +1827,9 @@ __global__ void __launch_bounds__(16 * R, 2) rowT2_pass_kernel(RowTJob job) {   
             for (int j = 0; j < 2 * R; ++j) vn[j] = r[ioff + j * R];
         }
         if (job.flags & P2_PRE_A) {
-            line2_transform<R, false>(v, scratch, tw, tw2, ln);
+            line2_transform<R, false, WIDE>(v, scratch, tw, tw2, ln);
             if constexpr (BIG) mul_p_big(v); else mul_table<2 * R, 0, false, R>(v, pl, ln);
-            line2_transform<R, true>(v, scratch, tw, tw2, ln);
+            line2_transform<R, true, WIDE>(v, scratch, tw, tw2, ln);
         }
         if constexpr (BIG) {
             // uniform 64-bit base (scalar registers) + one 32-bit per-thread offset, laundered so that the table addresses
@@ -1841,9 +1842,9 @@ __global__ void __launch_bounds__(16 * R, 2) rowT2_pass_kernel(RowTJob job) {   
             for (int j = 0; j < 2 * R; ++j) v[j] = cmulf(v[j], tv[j]);
         }
         if (job.flags & P2_POST_A) {
-            line2_transform<R, false>(v, scratch, tw, tw2, ln);
+            line2_transform<R, false, WIDE>(v, scratch, tw, tw2, ln);
             if constexpr (BIG) mul_p_big(v); else mul_table<2 * R, 0, false, R>(v, pl, ln);
-            line2_transform<R, true>(v, scratch, tw, tw2, ln);
+            line2_transform<R, true, WIDE>(v, scratch, tw, tw2, ln);
         }
         float2* dst = job.out + ((long long)p * job.out_image_stride + cur_lb * 16);
         int off0 = 2 * q + r0 * job.out_pitch;

@@ -706,7 +706,7 @@ template <int R>
 int launch_rowT2_r(msl_handle* h, RowTJob job, int kind) {
     constexpr int N2 = R * R, N = 2 * N2;
     constexpr bool BIG = (R == 32);
-    const size_t lds = BIG ? ((size_t)2 * N2 + (size_t)16 * (N2 + 1)) * 8 : ((size_t)2 * N2 + N + (size_t)16 * (N + 1)) * 8;
+    const size_t lds = BIG ? ((size_t)2 * N2 + (size_t)16 * (N2 + 1)) * 8 : ((size_t)2 * N2 + N + (size_t)16 * (N + 2)) * 8;
     const int per_cu = std::max(1, std::min(2, (int)((size_t)h->lds_limit / lds)));
     const long long slots = (long long)h->n_cus * per_cu;
     const long long lb = job.n_lines / 16;
