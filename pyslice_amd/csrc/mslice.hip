@@ -86,7 +86,7 @@ struct msl_handle {
     unsigned stage_pos = 0;
     float2* transT = nullptr;
     int pitchT = 0;
-    int rowT_variant = 2;
+    int rowT_variant = 4;
     int rowT_paired = 0;           // MSL_ROWT_PAIRED=1: 8-line tiles in the paired-lines layout, two workgroups per CU (measured equal: DESIGN 4.1)
     int debug_flags_mask = -1;
     int row_pchunk = 0;         // 0 = auto (MSL_ROW_PCHUNK)
@@ -643,14 +643,16 @@ int launch_rowT_v(msl_handle* h, RowTJob job, int kind) {
 }
 
 // MSL_ROWT_VARIANT = exchange through the LDS inside the four-step transforms: 0 = real and imaginary parts one after the
-// other, 1 = complex, 2 / 3 = the same with 16-byte reads (default 2: 284 -> 275 us per 1024^2 x 64 pass)
+// other, 1 = complex, 2 / 3 = the same with 16-byte reads, 4 = 16-byte reads and ds_write_addtid_b32 stores (default:
+// 288 -> 280 -> 273 us per 1024^2 x 64 pass for 0 -> 2 -> 4)
 template <int R>
 int launch_rowT_r(msl_handle* h, RowTJob job, int kind) {
     switch (h->rowT_variant) {
         case 0: return launch_rowT_v<R, 16, 0>(h, job, kind);
         case 1: return launch_rowT_v<R, 16, 1>(h, job, kind);
+        case 2: return launch_rowT_v<R, 16, 2>(h, job, kind);
         case 3: return launch_rowT_v<R, 16, 3>(h, job, kind);
-        default: return launch_rowT_v<R, 16, 2>(h, job, kind);
+        default: return launch_rowT_v<R, 16, 4>(h, job, kind);
     }
 }
 
