@@ -1715,8 +1715,11 @@ __global__ void __launch_bounds__(512, 2) rowTW_pass_kernel(RowTJob job) {
 // frequency (a = x0 + x1, d = (x0 - x1) W_N^m, then N/2-point transforms of a and d give X[2k] and X[2k+1]); the
 // inverse is the mirror decimation in time.  The frequency domain therefore lives in "split" order -- set b, slot k
 // holds X[2k+b] -- which never leaves the kernel: the propagator table is stored in the same order.
-template <int R, bool INV, bool WIDE = false>
-__device__ __forceinline__ void line2_transform(float2 (&v)[2 * R], float* scratch, const float2* tw, const float2* tw2, int ln) {
+// XM: exchange of the two R^2-point transforms -- 0 narrow, 1 wide reads, 2 wide reads + add-tid stores (then wscr / wscr_lds /
+// lane64 describe the wave's shared scratch, see fourstep_split_addtid)
+template <int R, bool INV, int XM = 0>
+__device__ __forceinline__ void line2_transform(float2 (&v)[2 * R], float* scratch, const float2* tw, const float2* tw2, int ln,
+                                                const float* wscr = nullptr, unsigned wscr_lds = 0, int lane64 = 0) {
     static_assert(64 % R == 0, "an R-lane group must lie inside one wave: the scratch is ordered per wave only");
     float2 (&lo)[R] = reinterpret_cast<float2 (&)[R]>(v[0]);
     float2 (&hi)[R] = reinterpret_cast<float2 (&)[R]>(v[R]);
@@ -1735,13 +1738,13 @@ __device__ __forceinline__ void line2_transform(float2 (&v)[2 * R], float* scrat
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        (WIDE ? fourstep_split_wide<R, false>(lo, scratch, tw, ln) : fourstep_split<R, false>(lo, scratch, tw, ln));
+        { if constexpr (XM == 2) fourstep_split_addtid<R, false>(lo, wscr, wscr_lds, tw, ln, lane64); else if constexpr (XM == 1) fourstep_split_wide<R, false>(lo, scratch, tw, ln); else fourstep_split<R, false>(lo, scratch, tw, ln); }
         __builtin_amdgcn_sched_barrier(0);
-        (WIDE ? fourstep_split_wide<R, false>(hi, scratch, tw, ln) : fourstep_split<R, false>(hi, scratch, tw, ln));
+        { if constexpr (XM == 2) fourstep_split_addtid<R, false>(hi, wscr, wscr_lds, tw, ln, lane64); else if constexpr (XM == 1) fourstep_split_wide<R, false>(hi, scratch, tw, ln); else fourstep_split<R, false>(hi, scratch, tw, ln); }
     } else {
-        (WIDE ? fourstep_split_wide<R, true>(lo, scratch, tw, ln) : fourstep_split<R, true>(lo, scratch, tw, ln));
+        { if constexpr (XM == 2) fourstep_split_addtid<R, true>(lo, wscr, wscr_lds, tw, ln, lane64); else if constexpr (XM == 1) fourstep_split_wide<R, true>(lo, scratch, tw, ln); else fourstep_split<R, true>(lo, scratch, tw, ln); }
         __builtin_amdgcn_sched_barrier(0);
-        (WIDE ? fourstep_split_wide<R, true>(hi, scratch, tw, ln) : fourstep_split<R, true>(hi, scratch, tw, ln));
+        { if constexpr (XM == 2) fourstep_split_addtid<R, true>(hi, wscr, wscr_lds, tw, ln, lane64); else if constexpr (XM == 1) fourstep_split_wide<R, true>(hi, scratch, tw, ln); else fourstep_split<R, true>(hi, scratch, tw, ln); }
 #pragma unroll
         for (int c = 0; c < R; c += CH) {
             float2 w[CH];
@@ -1767,7 +1770,7 @@ __global__ void __launch_bounds__(16 * R, 2) rowT2_pass_kernel(RowTJob job) {   
     constexpr bool BIG = (R == 32);
     constexpr int CPOS = BIG ? N2 : N;                 // positions per store chunk
     constexpr int NCHUNK = N / CPOS;
-    constexpr bool WIDE = !BIG;                        // 16-byte exchange reads (rows 16-byte aligned: even pitch)
+    constexpr int XM = BIG ? 0 : 2;                    // exchange: 16-byte reads and add-tid stores (rows 16-byte aligned: even pitch)
     constexpr int CS = BIG ? CPOS + 1 : CPOS + 2;      // tile line pitch: odd, or 2 mod 32 -- conflict-free staging either way
     constexpr int POS_PER_IT = NT / 8;
     constexpr int NIT = CPOS / POS_PER_IT;
@@ -1813,6 +1816,8 @@ __global__ void __launch_bounds__(16 * R, 2) rowT2_pass_kernel(RowTJob job) {   
     const int grp = tid / R, ln = tid % R;
     const int q = tid & 7, r0 = tid >> 3;
     float* scratch = reinterpret_cast<float*>(tile + grp * CS);
+    const float* wscr = reinterpret_cast<const float*>(tile + (grp - grp % (64 / R)) * CS);     // the wave's shared exchange scratch
+    const unsigned wscr_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(tile + (grp - grp % (64 / R)) * CS));
     const int lblocks = job.n_lines / 16;
     const int PC = BIG ? 1 : job.pchunk;
     const int pchunks = (job.n_images + PC - 1) / PC;
@@ -1868,9 +1873,9 @@ __global__ void __launch_bounds__(16 * R, 2) rowT2_pass_kernel(RowTJob job) {   
             for (int j = 0; j < 2 * R; ++j) vn[j] = r[ioff + j * R];
         }
         if (job.flags & P2_PRE_A) {
-            line2_transform<R, false, WIDE>(v, scratch, tw, tw2, ln);
+            line2_transform<R, false, XM>(v, scratch, tw, tw2, ln, wscr, wscr_lds, tid & 63);
             if constexpr (BIG) mul_p_big(v); else mul_table<2 * R, 0, false, R>(v, pl, ln);
-            line2_transform<R, true, WIDE>(v, scratch, tw, tw2, ln);
+            line2_transform<R, true, XM>(v, scratch, tw, tw2, ln, wscr, wscr_lds, tid & 63);
         }
         if constexpr (BIG) {
             // uniform 64-bit base (scalar registers) + one 32-bit per-thread offset, laundered so that the table addresses
@@ -1883,9 +1888,9 @@ __global__ void __launch_bounds__(16 * R, 2) rowT2_pass_kernel(RowTJob job) {   
             for (int j = 0; j < 2 * R; ++j) v[j] = cmulf(v[j], tv[j]);
         }
         if (job.flags & P2_POST_A) {
-            line2_transform<R, false, WIDE>(v, scratch, tw, tw2, ln);
+            line2_transform<R, false, XM>(v, scratch, tw, tw2, ln, wscr, wscr_lds, tid & 63);
             if constexpr (BIG) mul_p_big(v); else mul_table<2 * R, 0, false, R>(v, pl, ln);
-            line2_transform<R, true, WIDE>(v, scratch, tw, tw2, ln);
+            line2_transform<R, true, XM>(v, scratch, tw, tw2, ln, wscr, wscr_lds, tid & 63);
         }
         float2* dst = job.out + ((long long)p * job.out_image_stride + cur_lb * 16);
         int off0 = 2 * q + r0 * job.out_pitch;
