@@ -124,3 +124,24 @@ def test_synthetic_workload_grids():
     tr = synthetic_trajectory(64, 6, 3, seed=2)
     assert tr.positions.shape[0] == 3 and (tr.positions[:, :, 2] >= 0).all()
     assert stem_probe_grid(8).shape == (64, 2)
+
+
+def test_m0_is_only_touched_by_the_addtid_exchange(tmp_path):
+    """The lane<->register exchange stores with ds_write_addtid_b32 (inline asm), whose address base is M0.  The compiler
+    does not know about that: the scheme is sound only while nothing else in the device code reads or writes M0, and every
+    write of M0 is followed by the wait state the add-tid instruction needs.  Checked on the generated ISA."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    out = tmp_path / "dev.s"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "--cuda-device-only", "-S", "-o", str(out),
+                    os.path.join(REPO, "pyslice_amd", "csrc", "mslice.hip")], check=True, capture_output=True)
+    lines = [l.strip() for l in open(out)]
+    m0 = [i for i, l in enumerate(lines) if re.search(r"\bm0\b", l) and not l.startswith(";")]
+    assert m0, "no add-tid exchange in the build?"
+    for i in m0:
+        assert lines[i].startswith("s_mov_b32 m0,"), lines[i]
+        assert lines[i + 1].startswith("s_nop"), (lines[i], lines[i + 1])
+    assert sum(l.startswith("ds_write_addtid_b32") for l in lines) > 0
