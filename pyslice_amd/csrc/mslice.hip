@@ -1552,17 +1552,24 @@ int msl_build_potential(msl_handle* h, const double* pos, const int32_t* Z, int6
             // atoms that fell into a slice: d_start[nkeys], read by the kernels themselves (grids sized for all n atoms)
             const int* n_sorted = h->d_start + nkeys;
             recip_written = true;
-            long long tx = (long long)n * c.nx, ty = (long long)n * c.ny;
+            // default: matrix-core kernel over the quadrant of non-negative frequencies (any nx, ny); the older forms are A/B switches
+            const bool quad = !getenv("MSL_NO_QUAD") && !getenv("MSL_NO_MFMA") && !getenv("MSL_NO_HERMITIAN");
+            const int cx = quad ? c.nx / 2 + 1 : c.nx, cy = quad ? c.ny / 2 + 1 : c.ny;     // table columns the kernels read
+            long long tx = (long long)n * cx, ty = (long long)n * cy;
             hipLaunchKernelGGL(phase_table_kernel, dim3((unsigned)((tx + 255) / 256)), dim3(256), 0, h->stream, h->d_ex, h->d_u1,
-                               h->d_order, n_sorted, c.nx);
+                               h->d_order, n_sorted, c.nx, cx);
             hipLaunchKernelGGL(phase_table_kernel, dim3((unsigned)((ty + 255) / 256)), dim3(256), 0, h->stream, h->d_ey, h->d_u2,
-                               h->d_order, n_sorted, c.ny);
+                               h->d_order, n_sorted, c.ny, cy);
             const int tiles_y = (c.ny + SF_TILE - 1) / SF_TILE;
-            const bool hermitian = (c.nx % (2 * SF_TILE) == 0) && (c.ny % 2 == 0) && !getenv("MSL_NO_HERMITIAN");
+            const bool hermitian = !quad && (c.nx % (2 * SF_TILE) == 0) && (c.ny % 2 == 0) && !getenv("MSL_NO_HERMITIAN");
             const int tiles_x = hermitian ? c.nx / 2 / SF_TILE : (c.nx + SF_TILE - 1) / SF_TILE;
-            // matrix-core variant: whole 32x32 tiles only (rows kx < nx/2 of the Hermitian path, ny % 32 == 0)
+            // Hermitian matrix-core variant: whole 32x32 tiles only (rows kx < nx/2, ny % 32 == 0)
             const bool use_mfma = hermitian && (c.ny % 32 == 0) && !getenv("MSL_NO_MFMA");
-            if (use_mfma) {
+            if (quad) {
+                const int qy = (c.ny / 2 + 32) / 32, n_tiles = ((c.nx / 2 + 32) / 32) * qy;      // ceil((n/2 + 1) / 32) per axis
+                hipLaunchKernelGGL(structure_factor_quad_kernel, dim3((n_tiles + 3) / 4, c.nz), dim3(256), 0, h->stream, TR,
+                                   h->d_ex, h->d_ey, h->d_ff, h->d_start, nsp, c.nx, c.ny, qy, n_tiles);
+            } else if (use_mfma) {
                 const int ty32 = c.ny / 32, n_tiles = (c.nx / 2 / 32) * ty32;
                 hipLaunchKernelGGL(structure_factor_mfma_kernel, dim3((n_tiles + 3) / 4, c.nz), dim3(256), 0, h->stream, TR,
                                    h->d_ex, h->d_ey, h->d_ff, h->d_start, nsp, c.nx, c.ny, ty32, n_tiles);

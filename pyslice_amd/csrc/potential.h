@@ -109,16 +109,18 @@ __global__ void __launch_bounds__(1024) bin_fill_kernel(const int* __restrict__ 
 
 // table[i][m] = exp(-2 pi i * f(m) * u[order[i]]),  f = signed FFT frequency index
 // (n_sorted is read on the device -- the number of atoms that fell into a slice -- so that the host never waits for it)
+// Only the first n_cols columns of every row of n are filled (the quadrant kernel reads m <= n/2).  The reduction t - rint(t)
+// is odd in t, so the full table is exactly conjugate-symmetric: table[a][n-m] == conj(table[a][m]).
 __global__ void phase_table_kernel(float2* __restrict__ table, const double* __restrict__ u,
-                                   const int* __restrict__ order, const int* __restrict__ n_sorted_ptr, int n) {
+                                   const int* __restrict__ order, const int* __restrict__ n_sorted_ptr, int n, int n_cols) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long long)(*n_sorted_ptr) * n) return;
-    int a = (int)(i / n), m = (int)(i - (long long)a * n);
+    if (i >= (long long)(*n_sorted_ptr) * n_cols) return;
+    int a = (int)(i / n_cols), m = (int)(i - (long long)a * n_cols);
     double t = (double)signed_freq(m, n) * u[order[a]];
     t -= rint(t);
     float sn, cs;
     sincospif((float)(-2.0 * t), &sn, &cs);
-    table[i] = make_float2(cs, sn);
+    table[(long long)a * n + m] = make_float2(cs, sn);
 }
 
 // R[s][kx][ky] = sum_species ff[sp][kx][ky] * sum_{atoms of (s,sp)} ex[a][kx] * ey[a][ky]
@@ -267,6 +269,85 @@ __global__ void __launch_bounds__(256) structure_factor_mfma_kernel(float2* __re
     for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
         out[(size_t)(kx0 + row) * ny + ky0 + i] = make_float2(tot_re[r], tot_im[r]);
+    }
+}
+
+// Quadrant form of the matrix-core kernel (default).  With x = ex[a][mx] = (c_x, -s_x), y = ey[a][my] = (c_y, -s_y) the four real
+// products an atom contributes,  A = x.x y.x,  B = x.y y.y,  C = x.x y.y,  D = x.y y.x,  give the bin and its three mirror images:
+//     S[ mx,  my] = (A - B,  C + D)      S[-mx,  my] = (A + B,  C - D)
+//     S[ mx, -my] = (A + B, -C + D)      S[-mx, -my] = (A - B, -C - D)
+// (the phase table is exactly conjugate-symmetric, ex[a][n-m] = conj ex[a][m], and f_Z depends on mx^2, my^2 only).  A wave
+// therefore accumulates A, B, C, D separately -- the same four MFMAs per atom pair as the complex product -- over a 32 x 32
+// tile of the non-negative frequencies 0..n/2 only and writes up to four bins per accumulator element: a quarter of the
+// arithmetic of the full grid, half of the Hermitian form, any nx, ny (loads clamped, stores guarded), and neither the
+// Nyquist nor the mirror kernel.  Bins on the axes (m = 0) and on the Nyquist lines (2m = n) are their own mirror image.
+__global__ void __launch_bounds__(256) structure_factor_quad_kernel(float2* __restrict__ recip,
+                                                                    const float2* __restrict__ ex,
+                                                                    const float2* __restrict__ ey,
+                                                                    const float* __restrict__ ff,
+                                                                    const int* __restrict__ start, int n_species,
+                                                                    int nx, int ny, int tiles_y, int n_tiles) {
+    const int s = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= n_tiles) return;
+    const int hx = nx / 2, hy = ny / 2;                     // largest non-negative frequency index of each axis
+    const int kx0 = (tile / tiles_y) * 32, ky0 = (tile % tiles_y) * 32;
+    const int i = lane & 31, kk = lane >> 5;
+    const int lx = min(kx0 + i, hx), ly = min(ky0 + i, hy); // surplus rows / columns of the last tiles recompute the last valid one
+    f32x16 tA = {0}, tB = {0}, tC = {0}, tD = {0};
+    for (int sp = 0; sp < n_species; ++sp) {
+        const int a0 = start[s * n_species + sp], a1 = start[s * n_species + sp + 1];
+        if (a0 == a1) continue;
+        f32x16 A = {0}, B = {0}, C = {0}, D = {0};
+        const float2* px = ex + (size_t)(a0 + kk) * nx + lx;
+        const float2* py = ey + (size_t)(a0 + kk) * ny + ly;
+        auto load8 = [&](int a, float2 (&x)[4], float2 (&y)[4]) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                x[u] = make_float2(0.f, 0.f); y[u] = make_float2(0.f, 0.f);
+                if (a + 2 * u < a1) { x[u] = px[(size_t)(2 * u) * nx]; y[u] = py[(size_t)(2 * u) * ny]; }
+            }
+            px += 8 * (size_t)nx; py += 8 * (size_t)ny;
+        };
+        float2 xn[4], yn[4];
+        load8(a0 + kk, xn, yn);
+        for (int a = a0 + kk; a < a1 + kk; a += 8) {           // same trip count for both lane halves
+            float2 x[4], y[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { x[u] = xn[u]; y[u] = yn[u]; }
+            load8(a + 8, xn, yn);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                A = __builtin_amdgcn_mfma_f32_32x32x2f32(x[u].x, y[u].x, A, 0, 0, 0);
+                B = __builtin_amdgcn_mfma_f32_32x32x2f32(x[u].y, y[u].y, B, 0, 0, 0);
+                C = __builtin_amdgcn_mfma_f32_32x32x2f32(x[u].x, y[u].y, C, 0, 0, 0);
+                D = __builtin_amdgcn_mfma_f32_32x32x2f32(x[u].y, y[u].x, D, 0, 0, 0);
+            }
+        }
+        const float* f = ff + (size_t)sp * nx * ny;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;      // C/D layout of the 32x32 MFMA
+            const float w = f[(size_t)min(kx0 + row, hx) * ny + ly];
+            tA[r] = fmaf(w, A[r], tA[r]); tB[r] = fmaf(w, B[r], tB[r]);
+            tC[r] = fmaf(w, C[r], tC[r]); tD[r] = fmaf(w, D[r], tD[r]);
+        }
+    }
+    float2* out = recip + (size_t)s * nx * ny;
+    const int my = ky0 + i;
+    if (my > hy) return;
+    const bool mir_y = my > 0 && 2 * my != ny;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int mx = kx0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+        if (mx > hx) continue;
+        const bool mir_x = mx > 0 && 2 * mx != nx;
+        const float dre = tA[r] - tB[r], sre = tA[r] + tB[r], sim = tC[r] + tD[r], dim = tC[r] - tD[r];
+        out[(size_t)mx * ny + my] = make_float2(dre, sim);
+        if (mir_x) out[(size_t)(nx - mx) * ny + my] = make_float2(sre, dim);
+        if (mir_y) out[(size_t)mx * ny + (ny - my)] = make_float2(sre, -dim);
+        if (mir_x && mir_y) out[(size_t)(nx - mx) * ny + (ny - my)] = make_float2(dre, -sim);
     }
 }
 
