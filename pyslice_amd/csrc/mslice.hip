@@ -1568,7 +1568,7 @@ int msl_build_potential(msl_handle* h, const double* pos, const int32_t* Z, int6
             if (quad) {
                 const int qy = (c.ny / 2 + 32) / 32, n_tiles = ((c.nx / 2 + 32) / 32) * qy;      // ceil((n/2 + 1) / 32) per axis
                 hipLaunchKernelGGL(structure_factor_quad_kernel, dim3((n_tiles + 3) / 4, c.nz), dim3(256), 0, h->stream, TR,
-                                   h->d_ex, h->d_ey, h->d_ff, h->d_start, nsp, c.nx, c.ny, qy, n_tiles);
+                                   h->d_ex, h->d_ey, h->d_ff, h->d_start, nsp, c.nx, c.ny, qy, n_tiles, (int)n);
             } else if (use_mfma) {
                 const int ty32 = c.ny / 32, n_tiles = (c.nx / 2 / 32) * ty32;
                 hipLaunchKernelGGL(structure_factor_mfma_kernel, dim3((n_tiles + 3) / 4, c.nz), dim3(256), 0, h->stream, TR,

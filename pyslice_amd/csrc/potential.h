@@ -286,7 +286,7 @@ __global__ void __launch_bounds__(256) structure_factor_quad_kernel(float2* __re
                                                                     const float2* __restrict__ ey,
                                                                     const float* __restrict__ ff,
                                                                     const int* __restrict__ start, int n_species,
-                                                                    int nx, int ny, int tiles_y, int n_tiles) {
+                                                                    int nx, int ny, int tiles_y, int n_tiles, int n_rows) {
     const int s = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -300,30 +300,34 @@ __global__ void __launch_bounds__(256) structure_factor_quad_kernel(float2* __re
         const int a0 = start[s * n_species + sp], a1 = start[s * n_species + sp + 1];
         if (a0 == a1) continue;
         f32x16 A = {0}, B = {0}, C = {0}, D = {0};
-        const float2* px = ex + (size_t)(a0 + kk) * nx + lx;
-        const float2* py = ey + (size_t)(a0 + kk) * ny + ly;
-        auto load8 = [&](int a, float2 (&x)[4], float2 (&y)[4]) {
+        // 8 atoms (4 MFMA k-steps) per half trip, two register sets in turn: the loads of one set fly while the sixteen MFMAs of
+        // the other run.  Loads are unconditional (rows clamped to the table; rows past the species' last atom are zeroed in
+        // registers just before use) so that no branch and no register copy ties a wait to the set in flight.
+        auto load4 = [&](int a, float2 (&x)[4], float2 (&y)[4]) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                x[u] = make_float2(0.f, 0.f); y[u] = make_float2(0.f, 0.f);
-                if (a + 2 * u < a1) { x[u] = px[(size_t)(2 * u) * nx]; y[u] = py[(size_t)(2 * u) * ny]; }
+                const int r = min(a + 2 * u, n_rows - 1);
+                x[u] = ex[(size_t)r * nx + lx];
+                y[u] = ey[(size_t)r * ny + ly];
             }
-            px += 8 * (size_t)nx; py += 8 * (size_t)ny;
         };
-        float2 xn[4], yn[4];
-        load8(a0 + kk, xn, yn);
-        for (int a = a0 + kk; a < a1 + kk; a += 8) {           // same trip count for both lane halves
-            float2 x[4], y[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { x[u] = xn[u]; y[u] = yn[u]; }
-            load8(a + 8, xn, yn);
+        auto mfma16 = [&](int a, float2 (&x)[4], float2 (&y)[4]) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
+                if (a + 2 * u >= a1) { x[u] = make_float2(0.f, 0.f); y[u] = make_float2(0.f, 0.f); }
                 A = __builtin_amdgcn_mfma_f32_32x32x2f32(x[u].x, y[u].x, A, 0, 0, 0);
                 B = __builtin_amdgcn_mfma_f32_32x32x2f32(x[u].y, y[u].y, B, 0, 0, 0);
                 C = __builtin_amdgcn_mfma_f32_32x32x2f32(x[u].x, y[u].y, C, 0, 0, 0);
                 D = __builtin_amdgcn_mfma_f32_32x32x2f32(x[u].y, y[u].x, D, 0, 0, 0);
             }
+        };
+        float2 xa[4], ya[4], xb[4], yb[4];
+        load4(a0 + kk, xa, ya);
+        for (int ab = a0; ab < a1; ab += 16) {                 // uniform trip count
+            load4(ab + 8 + kk, xb, yb);
+            mfma16(ab + kk, xa, ya);
+            load4(ab + 16 + kk, xa, ya);
+            if (ab + 8 < a1) mfma16(ab + 8 + kk, xb, yb);
         }
         const float* f = ff + (size_t)sp * nx * ny;
 #pragma unroll
