@@ -422,32 +422,34 @@ struct ColJob {
 //                line index fftshifted (tacaw_data.py:94-104); the "columns" are pixels, the lines run along time
 enum { COL_FWD = 1, COL_MULPX = 2, COL_INV = 4, COL_SHIFT = 8, COL_POTENTIAL = 16, COL_TPOT = 32, COL_INTENSITY = 64 };
 
-// Column pass.  Workgroup = 16*R threads owns a tile of 16 neighbouring columns (128-byte row
+// Column pass.  Workgroup = COLS*R threads owns a tile of COLS = 16 neighbouring columns (128-byte row
 // segments in HBM) x N rows: staged into LDS column-major, one R-lane group per column, results
 // staged back and stored as 128-byte segments.  Persistent over tiles with the next tile's loads in
 // flight in registers while the current one is transformed.
-template <int R>
-__global__ void __launch_bounds__(16 * R) col_pass_kernel(ColJob job) {
+// COLS = 32 (TACAW time transform only: no window, no shift): 256-byte row segments in, 128-byte segments of the float output.
+template <int R, int COLS = 16>
+__global__ void __launch_bounds__(COLS * R) col_pass_kernel(ColJob job) {
     constexpr int N = R * R;
-    constexpr int NT = 16 * R;                        // threads
+    constexpr int NT = COLS * R;                      // threads
     constexpr int CS = R * (R + 1) + 1;               // LDS column stride in float2 (odd*8 B: conflict-free staging)
-    constexpr int ROWS_PER_IT = NT / 8;               // 8 threads (16 B each) per 128-byte row segment
+    constexpr int QN = COLS / 2;                      // threads (16 B each) per row segment
+    constexpr int ROWS_PER_IT = NT / QN;
     constexpr int NIT = N / ROWS_PER_IT;              // float4 per thread per tile
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float2* tw = reinterpret_cast<float2*>(smem_raw);                 // N
     float2* px = tw + N;                                              // N
-    float2* cols = px + N;                                            // 16 * CS
+    float2* cols = px + N;                                            // COLS * CS
     const int tid = threadIdx.x;
     for (int i = tid; i < N; i += NT) { tw[i] = job.tw[i]; px[i] = job.px ? job.px[i] : make_float2(1.f, 0.f); }
     const int grp = tid / R, ln = tid % R;            // column handled in the transform phase
-    const int q = tid & 7, r0 = tid >> 3;             // staging role: column pair q, row r0 + ROWS_PER_IT*i
+    const int q = tid % QN, r0 = tid / QN;            // staging role: column pair q, row r0 + ROWS_PER_IT*i
     float2* mycol = cols + grp * CS;
     const bool windowed = (job.flags & COL_SHIFT) && job.win_nc > 0;
-    const int tiles_per_image = (windowed ? job.win_nc : job.ny) / 16;
+    const int tiles_per_image = (windowed ? job.win_nc : job.ny) / COLS;
     const long long n_tiles = (long long)tiles_per_image * job.n_images;
     // first (unshifted) column of tile t of an image
     auto tile_col = [&](long long t) {
-        int c = (int)t * 16;
+        int c = (int)t * COLS;
         if (windowed) { c += job.win_c0 + job.ny / 2; if (c >= job.ny) c -= job.ny; }
         return c;
     };
