@@ -496,14 +496,15 @@ int launch_col_fast_r(msl_handle* h, const ColJob& job, int kind) {
 }
 
 // TACAW time transform of 256 frames on 32-column tiles (COL_FWD | COL_INTENSITY only)
-int launch_col_time32(msl_handle* h, const ColJob& job, int kind) {
+template <int COLS>
+int launch_col_time(msl_handle* h, const ColJob& job, int kind) {
     constexpr int R = 16, N = R * R, CS = R * (R + 1) + 1;
-    const size_t lds = ((size_t)2 * N + (size_t)32 * CS) * 8;
-    const long long tiles = (long long)(job.ny / 32) * job.n_images;
+    const size_t lds = ((size_t)2 * N + (size_t)COLS * CS) * 8;
+    const long long tiles = (long long)(job.ny / COLS) * job.n_images;
     const int per_cu = std::max(1, (int)((size_t)h->lds_limit / lds));
     const int grid = (int)std::min<long long>(tiles, (long long)h->n_cus * std::min(per_cu, 2));
-    (void)hipFuncSetAttribute((const void*)col_pass_kernel<16, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
-    hipLaunchKernelGGL((col_pass_kernel<16, 32>), dim3(grid), dim3(32 * R), lds, h->stream, job);
+    (void)hipFuncSetAttribute((const void*)col_pass_kernel<16, COLS>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
+    hipLaunchKernelGGL((col_pass_kernel<16, COLS>), dim3(grid), dim3(COLS * R), lds, h->stream, job);
     HIPCHK(h, hipGetLastError());
     return mark_launch(h, kind);
 }
@@ -1789,7 +1790,7 @@ int msl_tacaw(msl_handle* h, const void* d_src, void* d_dst, int64_t batch, int3
         j.in_pitch = j.out_pitch = (int)npix; j.ny = (int)npix; j.n_images = (int)batch;
         j.flags = COL_FWD | COL_INTENSITY; j.scale = 1.f;
         if (Rt == 16 && npix % 32 == 0 && !getenv("MSL_TACAW_COLS16")) {
-            rc = launch_col_time32(h, j, K_OTHER);
+            rc = launch_col_time<32>(h, j, K_OTHER);          // 64-pixel tiles (one workgroup per CU): 47.9 vs 41.7 ms
         } else {
             const int saved = h->Rx;
             h->Rx = Rt;
