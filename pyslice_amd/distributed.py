@@ -13,8 +13,9 @@ and nothing is exchanged while frames are propagated.  Two exchanges exist, both
 Every exchange receives STRAIGHT INTO THE DESTINATION: the result array is allocated once in its final
 (P, T, ...) layout and each peer's contribution -- for one probe a contiguous run of T_r frames -- is
 received into its slice by a point-to-point operation; senders send slices of their shard in place.
-All operations of one exchange are issued as ONE group (torch.distributed.batch_isend_irecv =
-ncclGroupStart/End on RCCL), so every pair of GPUs uses its own xGMI link concurrently.  No padded
+The operations of one exchange are issued as grouped launches (torch.distributed.batch_isend_irecv =
+ncclGroupStart/End on RCCL) of at most MAX_GROUP_OPS operations -- one launch at C4 -- so every pair of GPUs uses its own
+xGMI link concurrently.  No padded
 copies, no list of per-rank buffers, no concatenation: the only allocation is the result itself
 (`alloc_log` records it; tests/test_distributed.py asserts it).  Footprint on rank 0 of BASELINE
 config C4 (64 probes x 256 frames x 1024^2 on 8 GPUs, gather="rank0", output="device"): 137.4 GB result
@@ -86,14 +87,23 @@ def _chunk(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
-def _exchange(sends, recvs):
-    """sends: [(tensor, peer)], recvs: [(tensor, peer)] -- one grouped launch, every pair its own link"""
-    ops = [dist.P2POp(dist.irecv, t, peer) for t, peer in recvs if t.numel()]
-    ops += [dist.P2POp(dist.isend, t, peer) for t, peer in sends if t.numel()]
-    if not ops:
-        return
-    for req in dist.batch_isend_irecv(ops):
-        req.wait()
+MAX_GROUP_OPS = 1024      # point-to-point operations per grouped launch (RCCL bounds the operations of one group)
+
+
+def _exchange(sends, recvs, world):
+    """sends / recvs: [(tensor, peer, ordinal)].  Grouped launches (every pair of GPUs on its own link at once) of at most
+    MAX_GROUP_OPS operations: round k carries the ordinals [k*B, (k+1)*B) -- the ordinal is the probe's position in the
+    sender-to-receiver stream, the same number on both sides, so every rank cuts the rounds at the same places."""
+    per = max(1, MAX_GROUP_OPS // (2 * max(1, world - 1)))
+    top = max([j for _, _, j in sends] + [j for _, _, j in recvs] + [-1])
+    # every rank must run the same number of rounds only if it takes part in them: a round with no operation is skipped locally
+    for lo in range(0, top + 1, per):
+        ops = [dist.P2POp(dist.irecv, t, peer) for t, peer, j in recvs if lo <= j < lo + per and t.numel()]
+        ops += [dist.P2POp(dist.isend, t, peer) for t, peer, j in sends if lo <= j < lo + per and t.numel()]
+        if not ops:
+            continue
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
 
 
 def gather_frames(local, n_frames: int, dst: Optional[int] = 0):
@@ -114,11 +124,11 @@ def gather_frames(local, n_frames: int, dst: Optional[int] = 0):
         for r in range(world):
             if r != rank:
                 lo, hi = bounds[r]
-                recvs += [(full[p, lo:hi], r) for p in range(P)]
+                recvs += [(full[p, lo:hi], r, p) for p in range(P)]
     for d in receivers:
         if d != rank:
-            sends += [(_chunk(local[p]), d) for p in range(P)]
-    _exchange(sends, recvs)
+            sends += [(_chunk(local[p]), d, p) for p in range(P)]
+    _exchange(sends, recvs, world)
     return _restore(full, cplx, dev)
 
 
@@ -140,9 +150,9 @@ def frames_to_probes(local, n_frames: int):
         if r == rank:
             continue
         lo, hi = tb[r]
-        recvs += [(mine[p - p0, lo:hi], r) for p in range(p0, p1)]                  # my probes, rank r's frames
-        sends += [(_chunk(local[p]), r) for p in range(pb[r][0], pb[r][1])]         # rank r's probes, my frames
-    _exchange(sends, recvs)
+        recvs += [(mine[p - p0, lo:hi], r, p - p0) for p in range(p0, p1)]                      # my probes, rank r's frames
+        sends += [(_chunk(local[p]), r, p - pb[r][0]) for p in range(pb[r][0], pb[r][1])]       # rank r's probes, my frames
+    _exchange(sends, recvs, world)
     return _restore(mine, cplx, dev)
 
 
@@ -159,7 +169,7 @@ def gather_probes(local, n_probes: int, dst: Optional[int] = 0):
     if rank in receivers:
         full = _alloc((n_probes,) + tuple(local.shape[1:]), local.dtype, local.device)
         full[pb[rank][0]:pb[rank][1]].copy_(local)
-        recvs = [(full[pb[r][0]:pb[r][1]], r) for r in range(world) if r != rank]
-    sends = [(_chunk(local), d) for d in receivers if d != rank]
-    _exchange(sends, recvs)
+        recvs = [(full[pb[r][0]:pb[r][1]], r, 0) for r in range(world) if r != rank]
+    sends = [(_chunk(local), d, 0) for d in receivers if d != rank]
+    _exchange(sends, recvs, world)
     return _restore(full, cplx, dev)

@@ -18,12 +18,14 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, P, T, npix, q):
+def _worker(rank, world, port, P, T, npix, q, max_ops=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from pyslice_amd import distributed as D
+        if max_ops:
+            D.MAX_GROUP_OPS = max_ops           # force several grouped launches per exchange
         rng = np.random.default_rng(0)
         full = torch.from_numpy((rng.standard_normal((P, T, npix)) + 1j * rng.standard_normal((P, T, npix))).astype(np.complex64))
         frames = D.shard_frames(T, world, rank)
@@ -65,13 +67,12 @@ def _worker(rank, world, port, P, T, npix, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("P,T", [(4, 6), (3, 5), (1, 2)])
-def test_frame_shard_exchanges_gloo(P, T):
-    world = 2
+@pytest.mark.parametrize("P,T,world,max_ops", [(4, 6, 2, None), (3, 5, 2, None), (1, 2, 2, None), (7, 5, 3, 4)])
+def test_frame_shard_exchanges_gloo(P, T, world, max_ops):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, P, T, 12, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, P, T, 12, q, max_ops)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in range(world)]
