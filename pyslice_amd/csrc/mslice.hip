@@ -1290,7 +1290,7 @@ int msl_create(const msl_config* cfg, msl_handle** out) {
         };
         if ((rc = setup_dir(h->opx, cfg->nx, cfg->ny, h->Rx, h->tw4_x))) return bail(rc);
         if ((rc = setup_dir(h->opy, cfg->ny, cfg->nx, h->Ry, h->tw4_y))) return bail(rc);
-        h->onepass = want && (h->opx.R || h->opx.generic) && (h->opy.R || h->opy.generic) && !cfg->keep_potential;
+        h->onepass = want && (h->opx.R || h->opx.generic) && (h->opy.R || h->opy.generic);
         h->scheme_b = h->onepass && (h->opx.two || h->opy.two || h->opx.generic || h->opy.generic || h->opx.breg || h->opy.breg ||
                                      h->opx.breg2 || h->opy.breg2 || h->opx.wave2k || h->opy.wave2k);
         if (h->pitch == cfg->ny && h->onepass) h->pitch = cfg->ny + 16;        // pad the work buffers of 2R^2 grids too
@@ -1389,6 +1389,7 @@ int msl_set_beam(msl_handle* h, double wavelength, double sigma, double dz) {
         hipLaunchKernelGGL(transmission_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->trans, h->V,
                            (long long)n, (float)sigma);
         HIPCHK(h, hipGetLastError());
+        if ((rc = transpose_odd_slices(h))) return rc;
         HIPCHK(h, hipStreamSynchronize(h->stream));
     }
     return MSL_OK;
@@ -1652,8 +1653,10 @@ int msl_build_potential(msl_handle* h, const double* pos, const int32_t* Z, int6
     } else if (h->Rx) {
         ColJob k = col_job(h, TR, TR, c.nz, c.ny, c.ny);
         k.flags = COL_INV | COL_POTENTIAL; k.scale = vscale; k.sigma = (float)c.sigma; k.out_real = h->V;
-        if (h->onepass) { k.flags |= COL_TPOT; k.tparity = h->scheme_b ? 0 : ((c.nz - 1) & 1); k.out_t = TRT; }
+        // (a kept V is written by the untransposed store only: with keep_potential the x-pass slices are transposed afterwards)
+        if (h->onepass && !h->V) { k.flags |= COL_TPOT; k.tparity = h->scheme_b ? 0 : ((c.nz - 1) & 1); k.out_t = TRT; }
         if ((rc = launch_col_fast(h, k, K_OTHER))) return rc;
+        if (h->onepass && h->V && (rc = transpose_odd_slices(h))) return rc;
     } else {
         LineArgs k = col_args(h, TR, TR, c.nz, c.ny, c.ny);
         k.fft1 = -1;
