@@ -1349,12 +1349,20 @@ __global__ void __launch_bounds__(16 * R, (R == 32) ? 2 : 4) rowTB_pass_kernel(R
 // The inverse runs the mirror image with conjugated twiddles.  Against the 2 R^2 layout of rowT2_pass_kernel<32> (64 complex
 // per lane) a lane holds 32 complex, which leaves registers for the prefetch of the next line and for t_k.
 __device__ __forceinline__ int lam64(int L) { return 32 * (L & 1) + (L >> 1); }
+// LDS images of the tables and of the tile rows keep every block of 64 elements in PHYSICAL lane order (element 64 b + lam(L) at
+// 64 b + L): a table or tile access of a wave is then 64 consecutive 8-byte words.  In logical order the lanes L and L ^ 1 sit
+// 256 bytes apart -- the same banks, a two-way conflict on every such read and write (r02 profile: 33 % of the LDS cycles).
+__device__ __forceinline__ int lam64_inv(int m) { return 2 * (m & 31) + (m >> 5); }
+__device__ __forceinline__ int lds_pos64(int e) { return (e & ~63) + lam64_inv(e & 63); }
+// lane whose element mirrors this lane's one inside a block of 64, as an offset from the block that holds element 64 r - lam(L):
+// lane 0 -> element 64 r itself (next block, position 0); else block r - 1, element 64 - lam(L) = position 1 (L == 1) or 65 - L
+__device__ __forceinline__ int lds_mirror64(int L) { return L == 0 ? 0 : (L == 1 ? 1 : 65 - L) - 64; }
 __device__ __forceinline__ float dpp_swap_pair(float x) {          // value of the neighbouring lane (L ^ 1)
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true));
 }
 constexpr int W2K_PITCH = 97;               // floats per k1 row of the transpose scratch: n2 < 32 at [0,32), n2 >= 32 at [48,80); 97 = 1 mod 32
 
-// tw: LDS table T[k1 * 64 + n2] = exp(-2 pi i k1 n2 / 2048); w64: LDS table [h * 32 + m] = (h ? exp(-2 pi i m / 64) : 1);
+// tw: LDS table T[k1 * 64 + n2] = exp(-2 pi i k1 n2 / 2048) stored at lds_pos64 (lane L reads tw[k1 * 64 + L]); w64: LDS table [h * 32 + m] = (h ? exp(-2 pi i m / 64) : 1);
 // scr: this wave's scratch of 32 * W2K_PITCH floats; L = lane, la = lam64(L), sgn = (L & 1) ? -1 : +1
 template <bool INV, int CH = 8>
 __device__ __forceinline__ void fft2048_wave(float2 (&v)[32], float* scr, const float2* tw, const float2* w64, int L, int la, float sgn) {
@@ -1379,7 +1387,7 @@ __device__ __forceinline__ void fft2048_wave(float2 (&v)[32], float* scr, const 
     };
     if constexpr (!INV) {
         fft_regs<R, false>(v);
-        mul_table<R, 1, false, 64, CH>(v, tw, la);
+        mul_table<R, 1, false, 64, CH>(v, tw, L);
 #pragma unroll
         for (int k1 = 0; k1 < R; ++k1) scr[k1 * W2K_PITCH + col] = v[k1].x;
         wave_lds_fence();
@@ -1409,7 +1417,7 @@ __device__ __forceinline__ void fft2048_wave(float2 (&v)[32], float* scr, const 
 #pragma unroll
         for (int k1 = 0; k1 < R; ++k1) v[k1].y = scr[k1 * W2K_PITCH + col];
         wave_lds_fence();
-        mul_table<R, 1, true, 64, CH>(v, tw, la);
+        mul_table<R, 1, true, 64, CH>(v, tw, L);
         fft_regs<R, true>(v);
     }
 }
@@ -1430,7 +1438,7 @@ __global__ void __launch_bounds__(512, 2) rowTB2_pass_kernel(RowTJob job) {
     float2* tile = bw + NH;                                   // LINES * RS
     const int tid = threadIdx.x;
     const int N = job.n_line;
-    for (int i = tid; i < M; i += NT) tw[i] = job.tw[i];
+    for (int i = tid; i < M; i += NT) tw[lds_pos64(i)] = job.tw[i];
     if (tid < 64) w64[tid] = job.tw2[tid];
     for (int i = tid; i <= NH; i += NT) bf[i] = job.bf[i];
     for (int i = tid; i < NH; i += NT) { bp[i] = job.pl[i]; bw[i] = job.bw[i]; }
@@ -1586,23 +1594,23 @@ template <bool IN_P, bool OUT_P>
 __global__ void __launch_bounds__(512, 2) rowTW_pass_kernel(RowTJob job) {
     constexpr int R = 32, N = 2048, H = 16, LINES = 8, NT = 512, TCH = 8;
     constexpr int RS = N + 1;                                 // tile row in float2 (>= the 32 x 97 floats of transpose scratch; = 1 mod 32)
-    constexpr int NHT = N / 2 + 2;
+    constexpr int NHT = N / 2 + 64;                           // N/2 + 2 entries; the last block is stored in lane order too
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float2* tw = reinterpret_cast<float2*>(smem_raw);         // 2048
     float2* w64 = tw + N;                                     // 64
     float2* plh = w64 + 64;                                   // N/2 + 2: symmetric Fresnel table, first half
     float2* tile = plh + NHT;                                 // LINES * RS
     const int tid = threadIdx.x;
-    for (int i = tid; i < N; i += NT) tw[i] = job.tw[i];
+    for (int i = tid; i < N; i += NT) tw[lds_pos64(i)] = job.tw[i];
     if (tid < 64) w64[tid] = job.tw2[tid];
-    for (int i = tid; i <= N / 2; i += NT) plh[i] = job.pl[i];
+    for (int i = tid; i <= N / 2; i += NT) plh[lds_pos64(i)] = job.pl[i];
     __syncthreads();
     const int wv = tid >> 6, L = tid & 63, la = lam64(L);
     const float sgn = (L & 1) ? -1.f : 1.f;
     float2* myrow = tile + wv * RS;
     float* scr = reinterpret_cast<float*>(myrow);
-    const float2* pa = plh + la;
-    const float2* pb = plh - la;
+    const float2* pa = plh + L;                               // P[64 j + lam(L)]
+    const float2* pb = plh + lds_mirror64(L);                 // pb[64 r] = P[64 r - lam(L)]
     auto mul_p = [&](float2 (&vv)[R]) {
 #pragma unroll
         for (int c = 0; c < R; c += TCH) {
@@ -1678,19 +1686,20 @@ __global__ void __launch_bounds__(512, 2) rowTW_pass_kernel(RowTJob job) {
         prefetch_part(MSL_IC(24), MSL_IC(32));
         wave_lds_fence();
 #pragma unroll
-        for (int j = 0; j < R; ++j) myrow[j * 64 + la] = v[j];
+        for (int j = 0; j < R; ++j) myrow[j * 64 + L] = v[j];          // element 64 j + lam(L) at lds_pos64
         lds_barrier();
         if constexpr (OUT_P) {
             const int i = tid & 7, oct = tid >> 3, q = oct & 3, hh = oct >> 2;
-            const int mm0 = (hh & 3) + 4 * q + 16 * (hh >> 2);             // 0 .. 63
-            const float2* src = tile + i * RS + 2 * mm0;
+            // pair index 0 .. 63: the four octets of a half-wave take pairs whose tile positions are 8 apart (different banks)
+            const int mm0 = 2 * q + (hh & 1) + 8 * ((hh >> 1) & 1) + 16 * ((hh >> 2) & 1) + 32 * (hh >> 3);
+            const float2* src = tile + i * RS + lds_pos64(2 * mm0);
             float2* dst = job.out + (long long)p * job.out_image_stride + 2 * (cur_lb * LINES + i);
             int off0 = mm0 * 2 * job.out_pitch;
             asm volatile("" : "+v"(off0));
             const int ostep = 64 * 2 * job.out_pitch;
 #pragma unroll
             for (int it = 0; it < N / 2 / 64; ++it) {
-                const float2 a = src[it * 128], b = src[it * 128 + 1];
+                const float2 a = src[it * 128], b = src[it * 128 + 2];       // elements 2 mm, 2 mm + 1: two lanes apart
                 *reinterpret_cast<float4*>(dst + (off0 + it * ostep)) = make_float4(a.x, a.y, b.x, b.y);
             }
         } else {
@@ -1702,7 +1711,7 @@ __global__ void __launch_bounds__(512, 2) rowTW_pass_kernel(RowTJob job) {
 #pragma unroll
             for (int it = 0; it < N / (NT / 4); ++it) {
                 const int e = e0 + (NT / 4) * it;
-                const float2 a = tile[(2 * q4) * RS + e], b = tile[(2 * q4 + 1) * RS + e];
+                const float2 a = tile[(2 * q4) * RS + lds_pos64(e)], b = tile[(2 * q4 + 1) * RS + lds_pos64(e)];
                 *reinterpret_cast<float4*>(dst + (off0 + it * ostep)) = make_float4(a.x, a.y, b.x, b.y);
             }
         }

@@ -778,7 +778,7 @@ int launch_rowTB2_io(msl_handle* h, RowTJob job, int kind) {
 template <bool IN_P, bool OUT_P>
 int launch_rowTW_io(msl_handle* h, RowTJob job, int kind) {
     constexpr int N = 2048;
-    const size_t lds = ((size_t)N + 64 + N / 2 + 2 + (size_t)8 * (N + 1)) * 8;
+    const size_t lds = ((size_t)N + 64 + N / 2 + 64 + (size_t)8 * (N + 1)) * 8;
     const long long slots = h->n_cus;
     const long long lb = job.n_lines / 8;
     int pc = choose_pchunk(lb, job.n_images, slots, job.t_group);
