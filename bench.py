@@ -55,7 +55,7 @@ def parse():
     ap.add_argument("--frames-per-step", type=int, default=8,
                     help="--scaling strong: MD frames per step, sharded over the ranks (fixed total work)")
     ap.add_argument("--frame-batch", type=int, default=0,
-                    help="MD frames sharing every slice-loop launch (0 = the calculator's rule: about 64 images per launch)")
+                    help="MD frames sharing every slice-loop launch (0 = the calculator's rule, calculators.default_frame_batch: about 256 images per launch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-slices", type=int, default=100,
                     help="slices of the bounded CPU sample (100 of 200 at 1024^2: about 12 s of single-thread work)")
@@ -227,9 +227,8 @@ def run(a):
             slots, tacaw_T = want, want
         else:
             tacaw_T = n_local
-    fb = a.frame_batch if a.frame_batch > 0 else max(1, min(-(-64 // P), int(16e9 // (16.0 * nz * npix))))
-    if a.frame_batch <= 0 and fb >= 16:
-        fb -= fb % 16
+    from pyslice_amd.calculators import default_frame_batch
+    fb = a.frame_batch if a.frame_batch > 0 else default_frame_batch(P, nz, n, n)      # the calculator's own default
     fb = max(1, min(fb, a.steps))
     eng = _native.Engine(n, n, nz, xs[1] - xs[0], ys[1] - ys[0], zs[1] - zs[0] if nz > 1 else 0.5, wavelength(100e3),
                          interaction_sigma(100e3), n_probes=P, n_frames=slots, device=local_rank,

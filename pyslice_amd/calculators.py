@@ -33,6 +33,22 @@ if TORCH_AVAILABLE:
 logger = logging.getLogger(__name__)
 
 
+def default_frame_batch(n_probes: int, n_slices: int, nx: int, ny: int) -> int:
+    """Frames per sequence of launches when the caller does not say (MultisliceCalculator(frame_batch=None), bench.py).
+
+    About 256 images (probes x frames) per launch: a launch of the slice loop is one round of persistent workgroups over the
+    256 CUs, and its fixed part (tables into LDS, the first un-prefetched line, the tail of the last round) is amortised over
+    the items of a workgroup -- 64 probes x 1024^2 x 200 slices: 277 / 270 / 267 us per 64 images at 1 / 2 / 4 frames per
+    launch.  Bounded by 16 GB for the two orientations of the batch's transmission stacks and 8 GB for the three work buffers."""
+    by_images = -(-256 // max(1, n_probes))
+    by_stacks = int(16e9 // (16.0 * n_slices * nx * ny))
+    by_work = int(8e9 // (24.0 * nx * ny * max(1, n_probes)))
+    batch = max(1, min(by_images, by_stacks, by_work))
+    if batch >= 16:
+        batch -= batch % 16               # whole rounds of work items over the CUs (16-line tiles, 256 CUs x 2 workgroups)
+    return batch
+
+
 class MultisliceCalculator:
 
     def __init__(self, device=None, force_cpu=False, *, output="host", dtype="complex128", progress=True,
@@ -166,10 +182,7 @@ class MultisliceCalculator:
         self._engine = None
         batch = self._frame_batch
         if batch is None:
-            # about 64 images per launch, at most 16 GB for the two orientations of the batch's transmission stacks
-            batch = max(1, min(-(-64 // self.n_probes), int(16e9 // (16.0 * n_slices * nx * ny))))
-            if batch >= 16:
-                batch -= batch % 16           # whole rounds of work items over the CUs (16-line tiles, 256 CUs x 2 workgroups)
+            batch = default_frame_batch(self.n_probes, n_slices, nx, ny)
         batch = 1 if self._cache else max(1, min(batch, len(self._frames)))
         slots = max(1, len(self._frames))
         if self._stream_tile is not None:

@@ -398,7 +398,9 @@ def test_frame_batching_default_for_single_probe_runs(ps, orc):
     tr = synthetic_trajectory(256, 6, 70, density=0.03, seed=12)
     calc = ps.MultisliceCalculator(progress=False)
     calc.setup(tr, aperture=30.0, voltage_eV=100e3)
-    assert calc._engine.frame_batch == 64
+    from pyslice_amd.calculators import default_frame_batch
+    assert default_frame_batch(1, 6, 256, 256) == 256 and default_frame_batch(64, 200, 1024, 1024) == 4
+    assert calc._engine.frame_batch == 70            # about 256 images per launch, capped by the run's 70 frames
     got = npy(calc.run().wavefunction_data)
     idx = [0, 1, 63, 64, 69]
     want = orc.run_frames(tr.box_matrix, tr.positions, tr.atom_types, 30.0, 100e3, None, frames=idx)["wavefunction_data"]
