@@ -360,7 +360,8 @@ def run(a):
             tpath = os.path.join(REPO, "profiles", "pmc_traffic_current.json")
             if os.path.exists(tpath):
                 tj = json.load(open(tpath))
-                if tj.get("grid") == n and tj.get("probes") == P and round(passes_per_slice) == tj.get("passes_per_slice"):
+                if (tj.get("grid") == n and tj.get("probes") == P and tj.get("frame_batch", 1) == eng.frame_batch
+                        and round(passes_per_slice) == tj.get("passes_per_slice")):
                     traffic = tj.get("hbm_bytes_per_launch")
                     tsrc = "profiles/pmc_traffic_current.json (rocprofv3 --pmc passes of this command, committed; not re-measured in this run)"
             loop_32 = (32.0 * npix * P * nz * frames_timed_local / (ctr["ms_slice_kernels"] * 1e-3) / 1e9) if ctr["ms_slice_kernels"] else None
