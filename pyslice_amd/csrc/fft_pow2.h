@@ -442,7 +442,9 @@ enum { COL_FWD = 1, COL_MULPX = 2, COL_INV = 4, COL_SHIFT = 8, COL_POTENTIAL = 1
 // staged back and stored as 128-byte segments.  Persistent over tiles with the next tile's loads in
 // flight in registers while the current one is transformed.
 // COLS = 32 (TACAW time transform only: no window, no shift): 256-byte row segments in, 128-byte segments of the float output.
-template <int R, int COLS = 16>
+// HERM (potential build): the input is Hermitian along the column, in[N - x] = conj(in[x]) -- the spectrum of a real image after
+// its row pass -- and only rows 0 .. N/2 exist: a tile reads half the rows and mirrors them while staging into the LDS.
+template <int R, int COLS = 16, bool HERM = false>
 __global__ void __launch_bounds__(COLS * R) col_pass_kernel(ColJob job) {
     constexpr int N = R * R;
     constexpr int NT = COLS * R;                      // threads
@@ -468,34 +470,44 @@ __global__ void __launch_bounds__(COLS * R) col_pass_kernel(ColJob job) {
         if (windowed) { c += job.win_c0 + job.ny / 2; if (c >= job.ny) c -= job.ny; }
         return c;
     };
+    constexpr int NLD = HERM ? NIT / 2 : NIT;         // rows r0 + ROWS_PER_IT * i < N/2; row N/2 is the extra load of the r0 == 0 threads
     float4 stage[NIT];
-    long long tile = blockIdx.x;
-    if (tile < n_tiles) {
-        const long long p = tile / tiles_per_image, c0 = tile_col(tile % tiles_per_image);
+    float4 stage_ny = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto load_tile = [&](long long t) {
+        const long long p = t / tiles_per_image, c0 = tile_col(t % tiles_per_image);
         const float2* src = job.in + p * job.in_image_stride + c0 + 2 * q;
 #pragma unroll
-        for (int i = 0; i < NIT; ++i)
+        for (int i = 0; i < NLD; ++i)
             stage[i] = *reinterpret_cast<const float4*>(src + (long long)(r0 + ROWS_PER_IT * i) * job.in_pitch);
-    }
+        if constexpr (HERM) { if (r0 == 0) stage_ny = *reinterpret_cast<const float4*>(src + (long long)(N / 2) * job.in_pitch); }
+    };
+    long long tile = blockIdx.x;
+    if (tile < n_tiles) load_tile(tile);
     __syncthreads();
     for (; tile < n_tiles; tile += gridDim.x) {
         // ---- registers -> LDS, column-major
 #pragma unroll
-        for (int i = 0; i < NIT; ++i) {
+        for (int i = 0; i < NLD; ++i) {
             const int x = r0 + ROWS_PER_IT * i;
             cols[(2 * q) * CS + x] = make_float2(stage[i].x, stage[i].y);
             cols[(2 * q + 1) * CS + x] = make_float2(stage[i].z, stage[i].w);
+            if constexpr (HERM) {
+                if (x > 0) {                                  // rows N/2 + 1 .. N - 1 from their mirror images
+                    cols[(2 * q) * CS + N - x] = make_float2(stage[i].x, -stage[i].y);
+                    cols[(2 * q + 1) * CS + N - x] = make_float2(stage[i].z, -stage[i].w);
+                }
+            }
+        }
+        if constexpr (HERM) {
+            if (r0 == 0) {
+                cols[(2 * q) * CS + N / 2] = make_float2(stage_ny.x, stage_ny.y);
+                cols[(2 * q + 1) * CS + N / 2] = make_float2(stage_ny.z, stage_ny.w);
+            }
         }
         lds_barrier();
         // ---- next tile's loads go out now and fly during the transform
         const long long nxt = tile + gridDim.x;
-        if (nxt < n_tiles) {
-            const long long p = nxt / tiles_per_image, c0 = tile_col(nxt % tiles_per_image);
-            const float2* src = job.in + p * job.in_image_stride + c0 + 2 * q;
-#pragma unroll
-            for (int i = 0; i < NIT; ++i)
-                stage[i] = *reinterpret_cast<const float4*>(src + (long long)(r0 + ROWS_PER_IT * i) * job.in_pitch);
-        }
+        if (nxt < n_tiles) load_tile(nxt);
         // ---- transform my column
         bool tstore = false;
         {

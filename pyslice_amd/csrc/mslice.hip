@@ -495,6 +495,23 @@ int launch_col_fast_r(msl_handle* h, const ColJob& job, int kind) {
     return mark_launch(h, kind);
 }
 
+// column pass of the potential build on the rows kx <= nx/2 of a Hermitian spectrum
+template <int R>
+int launch_col_herm_r(msl_handle* h, const ColJob& job, int kind) {
+    constexpr int N = R * R, CS = R * (R + 1) + 1;
+    const size_t lds = ((size_t)2 * N + (size_t)16 * CS) * 8;
+    const long long tiles = (long long)(job.ny / 16) * job.n_images;
+    const int per_cu = std::max(1, (int)((size_t)h->lds_limit / lds));
+    const int grid = (int)std::min<long long>(tiles, (long long)h->n_cus * std::min(per_cu, 2));
+    (void)hipFuncSetAttribute((const void*)col_pass_kernel<R, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
+    hipLaunchKernelGGL((col_pass_kernel<R, 16, true>), dim3(grid), dim3(16 * R), lds, h->stream, job);
+    HIPCHK(h, hipGetLastError());
+    return mark_launch(h, kind);
+}
+int launch_col_herm(msl_handle* h, const ColJob& job, int kind) {
+    return h->Rx == 32 ? launch_col_herm_r<32>(h, job, kind) : launch_col_herm_r<16>(h, job, kind);
+}
+
 // TACAW time transform of 256 frames on 32-column tiles (COL_FWD | COL_INTENSITY only)
 template <int COLS>
 int launch_col_time(msl_handle* h, const ColJob& job, int kind) {
@@ -1521,6 +1538,9 @@ int msl_build_potential(msl_handle* h, const double* pos, const int32_t* Z, int6
     if ((rc = ensure_atoms(h, (size_t)n))) return rc;
     HIPCHK(h, hipMemsetAsync(h->d_counts, 0, ((size_t)nkeys + 1) * sizeof(int), h->stream));
     bool recip_written = false;     // the structure-factor kernels write every bin of R_s; zero-fill only when none runs
+    // R_s is Hermitian (real V): with the quadrant kernel and four-step transforms on both axes only the rows kx <= nx/2 are
+    // written and row-transformed, and the column pass mirrors them while staging (col_pass_kernel<.., HERM>)
+    bool herm_ifft = false;
     if (n > 0 && nsp > 0) {
         {
             msl_handle::HostStage& st = h->stage[h->stage_pos++ & 1];
@@ -1582,8 +1602,9 @@ int msl_build_potential(msl_handle* h, const double* pos, const int32_t* Z, int6
             const bool use_mfma = hermitian && (c.ny % 32 == 0) && !getenv("MSL_NO_MFMA");
             if (quad) {
                 const int qy = (c.ny / 2 + 32) / 32, n_tiles = ((c.nx / 2 + 32) / 32) * qy;      // ceil((n/2 + 1) / 32) per axis
+                herm_ifft = h->Rx && h->Ry && !getenv("MSL_NO_HERM_IFFT");       // four-step kernels on both axes (256 / 1024)
                 hipLaunchKernelGGL(structure_factor_quad_kernel, dim3((n_tiles + 3) / 4, c.nz), dim3(256), 0, h->stream, TR,
-                                   h->d_ex, h->d_ey, h->d_ff, h->d_start, nsp, c.nx, c.ny, qy, n_tiles, (int)n);
+                                   h->d_ex, h->d_ey, h->d_ff, h->d_start, nsp, c.nx, c.ny, qy, n_tiles, (int)n, herm_ifft ? 0 : 1);
             } else if (use_mfma) {
                 const int ty32 = c.ny / 32, n_tiles = (c.nx / 2 / 32) * ty32;
                 hipLaunchKernelGGL(structure_factor_mfma_kernel, dim3((n_tiles + 3) / 4, c.nz), dim3(256), 0, h->stream, TR,
@@ -1642,6 +1663,7 @@ int msl_build_potential(msl_handle* h, const double* pos, const int32_t* Z, int6
     } else if (h->Ry) {
         RowJob r = row_job(h, TR, c.nz, c.ny);
         r.do_ifft = 1;
+        if (herm_ifft) { const int G = 256 / h->Ry; r.nx = (c.nx / 2 + 1 + G - 1) / G * G; }     // whole row groups (the surplus rows are never read)
         if ((rc = launch_row_fast(h, r, K_OTHER))) return rc;
     } else {
         LineArgs r = row_args(h, TR, TR, c.nz, c.ny);
@@ -1655,7 +1677,7 @@ int msl_build_potential(msl_handle* h, const double* pos, const int32_t* Z, int6
         k.flags = COL_INV | COL_POTENTIAL; k.scale = vscale; k.sigma = (float)c.sigma; k.out_real = h->V;
         // (a kept V is written by the untransposed store only: with keep_potential the x-pass slices are transposed afterwards)
         if (h->onepass && !h->V) { k.flags |= COL_TPOT; k.tparity = h->scheme_b ? 0 : ((c.nz - 1) & 1); k.out_t = TRT; }
-        if ((rc = launch_col_fast(h, k, K_OTHER))) return rc;
+        if ((rc = herm_ifft ? launch_col_herm(h, k, K_OTHER) : launch_col_fast(h, k, K_OTHER))) return rc;
         if (h->onepass && h->V && (rc = transpose_odd_slices(h))) return rc;
     } else {
         LineArgs k = col_args(h, TR, TR, c.nz, c.ny, c.ny);

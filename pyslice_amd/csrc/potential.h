@@ -286,7 +286,8 @@ __global__ void __launch_bounds__(256) structure_factor_quad_kernel(float2* __re
                                                                     const float2* __restrict__ ey,
                                                                     const float* __restrict__ ff,
                                                                     const int* __restrict__ start, int n_species,
-                                                                    int nx, int ny, int tiles_y, int n_tiles, int n_rows) {
+                                                                    int nx, int ny, int tiles_y, int n_tiles, int n_rows,
+                                                                    int write_mx) {
     const int s = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -346,9 +347,13 @@ __global__ void __launch_bounds__(256) structure_factor_quad_kernel(float2* __re
     for (int r = 0; r < 16; ++r) {
         const int mx = kx0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
         if (mx > hx) continue;
-        const bool mir_x = mx > 0 && 2 * mx != nx;
+        const bool mir_x = write_mx && mx > 0 && 2 * mx != nx;    // write_mx == 0: the inverse transform takes rows 0 .. nx/2 only
         const float dre = tA[r] - tB[r], sre = tA[r] + tB[r], sim = tC[r] + tD[r], dim = tC[r] - tD[r];
-        out[(size_t)mx * ny + my] = make_float2(dre, sim);
+        // Rows 0 .. nx/2 only (write_mx == 0): the column pass rebuilds row nx - mx as the conjugate of row mx, which is exact
+        // for every bin but the Nyquist column, where the grid's one frequency -ny/2 serves both signs and R[-mx] is NOT conj
+        // R[mx].  Re(ifft2) keeps the Hermitian part, (R[mx, ny/2] + conj R[-mx, ny/2]) / 2 = (A, D): store that.
+        const bool herm_col = !write_mx && 2 * my == ny && 2 * mx != nx;
+        out[(size_t)mx * ny + my] = herm_col ? make_float2(tA[r], tD[r]) : make_float2(dre, sim);
         if (mir_x) out[(size_t)(nx - mx) * ny + my] = make_float2(sre, dim);
         if (mir_y) out[(size_t)mx * ny + (ny - my)] = make_float2(sre, -dim);
         if (mir_x && mir_y) out[(size_t)(nx - mx) * ny + (ny - my)] = make_float2(dre, -sim);
