@@ -56,6 +56,8 @@ def parse():
                     help="--scaling strong: MD frames per step, sharded over the ranks (fixed total work)")
     ap.add_argument("--frame-batch", type=int, default=0,
                     help="MD frames sharing every slice-loop launch (0 = the calculator's rule, calculators.default_frame_batch: about 256 images per launch)")
+    ap.add_argument("--exchange-timeout", type=float, default=240.0,
+                    help="N>1: seconds the end-of-run exchanges may take before the line is printed without them")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-slices", type=int, default=100,
                     help="slices of the bounded CPU sample (100 of 200 at 1024^2: about 12 s of single-thread work)")
@@ -301,9 +303,12 @@ def run(a):
                  "algorithmic_bytes": 12.0 * P * tacaw_T * npix, "frac_of_hbm_peak": round(12.0 * P * tacaw_T * npix / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                  "note": f"{n_local} computed frames, remaining slots filled with copies (timing is data-independent)"}
 
-    # ---- end-of-run exchanges of the sharded path (N>1), on the frames just computed
-    exchange = None
-    if world > 1 and not a.no_exchange:
+    # ---- end-of-run exchanges of the sharded path (N>1), on the frames just computed (run AFTER the bench line is assembled,
+    # under a watchdog: see below)
+    def run_exchange():
+        if os.environ.get("MSL_BENCH_TEST_STALL") == str(rank):      # test hook: this rank never reaches the exchange
+            time.sleep(3600)
+
         def sync():
             torch.cuda.synchronize()
             dist.barrier()
@@ -334,12 +339,12 @@ def run(a):
         inten, ms_gp = timed(lambda: D.gather_probes(out, P, dst=0))
         del inten, mine, out
         shard_b = 8.0 * P * per_rank * npix
-        exchange = {"backend": backend, "frames": T_x, "frames_per_rank": per_rank,
-                    "gather_frames": round(ms_gather, 3), "frames_to_probes": round(ms_a2a, 3), "tacaw": round(ms_t, 3),
-                    "gather_probes": round(ms_gp, 3),
-                    "gather_frames_GBps_into_rank0": round(shard_b * (world - 1) / (ms_gather * 1e-3) / 1e9, 1),
-                    "frames_to_probes_GBps_out_per_rank": round(shard_b * (world - 1) / world / (ms_a2a * 1e-3) / 1e9, 1),
-                    "bytes_per_rank_shard": shard_b}
+        return {"backend": backend, "frames": T_x, "frames_per_rank": per_rank,
+                "gather_frames": round(ms_gather, 3), "frames_to_probes": round(ms_a2a, 3), "tacaw": round(ms_t, 3),
+                "gather_probes": round(ms_gp, 3),
+                "gather_frames_GBps_into_rank0": round(shard_b * (world - 1) / (ms_gather * 1e-3) / 1e9, 1),
+                "frames_to_probes_GBps_out_per_rank": round(shard_b * (world - 1) / world / (ms_a2a * 1e-3) / 1e9, 1),
+                "bytes_per_rank_shard": shard_b}
 
     if rank == 0:
         steps_total = frames_timed * P * nz
@@ -391,20 +396,50 @@ def run(a):
         }
         if tacaw is not None:
             out["tacaw"] = tacaw
-        if exchange is not None:
-            out["exchange_ms"] = exchange
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"], V = cpu_baseline(n, nz, P, a.aperture, a.cpu_slices)
             try:
                 out["cpu_baseline_allcores"] = cpu_baseline_allcores(n, nz, P, a.aperture, a.cpu_slices, V)
             except Exception as exc:  # pragma: no cover  (scipy missing: the single-thread leg stands alone)
                 out["cpu_baseline_allcores"] = {"error": repr(exc)}
+    else:
+        out = None
+    if world > 1 and not a.no_exchange:
+        # The timed region is over and its line is complete.  The exchanges move tens of GB between the ranks over a backend
+        # this build could not exercise on real multi-GPU hardware: if they stall, every rank's watchdog ends its process after
+        # `--exchange-timeout` seconds and rank 0 still prints the line, with the failure recorded instead of the timings.
+        import threading
+        finished = threading.Event()
+
+        def watchdog():
+            if not finished.wait(a.exchange_timeout):
+                if rank == 0:
+                    out["exchange_ms"] = {"error": f"end-of-run exchanges did not finish within {a.exchange_timeout} s"}
+                    print(json.dumps(out), flush=True)
+                os._exit(0)
+        threading.Thread(target=watchdog, daemon=True).start()
+        try:
+            ex = run_exchange()
+        except Exception as exc:                     # a failing exchange must not cost the measured line
+            ex = {"error": repr(exc)}
+        finished.set()
+        if rank == 0:
+            out["exchange_ms"] = ex
+    if rank == 0:
         print(json.dumps(out), flush=True)
     del wf_view
     eng.close()
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        import threading
+        t = threading.Timer(60.0, lambda: os._exit(0))      # the line is out: a peer that died must not keep this rank in the barrier
+        t.daemon = True
+        t.start()
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception:
+            pass
+        t.cancel()
 
 
 def main():

@@ -129,3 +129,25 @@ def test_bench_two_ranks_gloo_rehearsal(tmp_path):
         assert ex["backend"] == "gloo" and ex["gather_frames"] > 0 and ex["frames_to_probes"] > 0 and ex["gather_probes"] > 0
         assert j["config"]["frames_timed"] == (8 if extra else 4)
         assert j["value"] > 0 and j["roofline"]["launches"] > 0
+
+
+def test_bench_line_survives_a_stalled_exchange():
+    """the end-of-run exchanges run after the bench line is assembled, under a watchdog: a rank that never arrives costs the
+    exchange timings, not the measurement, and every rank still exits"""
+    import json
+    import subprocess
+    import sys
+    import time
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["MSL_BENCH_BACKEND"] = "gloo"
+    env["MSL_BENCH_TEST_STALL"] = "1"
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--grid", "256", "--slices", "6", "--probes", "4",
+                        "--steps", "2", "--warmup", "1", "--exchange-timeout", "8"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert time.time() - t0 < 200
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1, r.stdout
+    j = json.loads(line[0])
+    assert j["n_gpus"] == 2 and j["value"] > 0 and "did not finish" in j["exchange_ms"]["error"]
