@@ -1221,7 +1221,7 @@ __global__ void __launch_bounds__(256, 3) rowT3_pass_kernel(RowTJob job) {
 // a chunk of probes, 16-line tile, 128-byte transposed segments -- is rowT_pass_kernel's.  The number of lines need not be a
 // multiple of 16: the last tile re-reads the last line and its surplus columns land in the row padding of the output
 // (pitch >= n_lines rounded up to 16), which no pass reads.
-template <int R>
+template <int R, bool CONV>
 __global__ void __launch_bounds__(16 * R, (R == 32) ? 2 : 4) rowTB_pass_kernel(RowTJob job) {
     constexpr int M = R * R, H = R / 2, NH = M / 2, LINES = 16, NT = LINES * R, TCH = 8;
     constexpr int CS = R * (R + 1) + 2;               // even (16-byte aligned rows for the wide exchange), conflict-free staging
@@ -1229,14 +1229,14 @@ __global__ void __launch_bounds__(16 * R, (R == 32) ? 2 : 4) rowTB_pass_kernel(R
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float2* tw = reinterpret_cast<float2*>(smem_raw);         // M: four-step twiddles
     float2* bf = tw + M;                                      // NH + 2: filter, first half
-    float2* bp = bf + NH + 2;                                 // NH: Fresnel factor (1/N folded in), zero beyond N
-    float2* bw = bp + NH;                                     // NH: chirp, zero beyond N
-    float2* tile = bw + NH;                                   // LINES * CS
+    float2* bp = bf + NH + 2;                                 // NH: Fresnel factor (1/N folded in), zero beyond N   (chirp-z form only)
+    float2* bw = bp + NH;                                     // NH: chirp, zero beyond N                           (chirp-z form only)
+    float2* tile = CONV ? bp : bw + NH;                       // LINES * CS
     const int tid = threadIdx.x;
     const int N = job.n_line;
     for (int i = tid; i < M; i += NT) tw[i] = job.tw[i];
     for (int i = tid; i <= NH; i += NT) bf[i] = job.bf[i];
-    for (int i = tid; i < NH; i += NT) { bp[i] = job.pl[i]; bw[i] = job.bw[i]; }
+    if constexpr (!CONV) { for (int i = tid; i < NH; i += NT) { bp[i] = job.pl[i]; bw[i] = job.bw[i]; } }
     __syncthreads();
     const int grp = tid / R, ln = tid % R;
     const int q = tid % TPS, r0 = tid / TPS;
@@ -1333,6 +1333,27 @@ __global__ void __launch_bounds__(16 * R, (R == 32) ? 2 : 4) rowTB_pass_kernel(R
             fourstep_split_addtid<R, true, TCH>(v, wscr, wscr_lds, tw, ln, tid & 63);
             mul_half(v, bw, std::true_type{});
         };
+        // CONV: A = ifft_N . P . fft_N is a circular convolution of length N with the fixed kernel a = ifft_N(P); on the
+        // zero-padded line it is ONE cyclic convolution of length M >= 2N - 1 with q[j] = a[j], q[M - j] = a[N - j] (0 < j < N):
+        // two M-point FFTs and one filter product (bf = FFT_M(q) / M, symmetric like the chirp filter) instead of the chirp-z
+        // form's four FFTs and five products.  The N-point spectrum itself is never needed inside the slice loop.
+        auto a_conv = [&]() {
+            fourstep_split_addtid<R, false, TCH>(v, wscr, wscr_lds, tw, ln, tid & 63);
+            mul_filter(v, std::false_type{});
+            fourstep_split_addtid<R, true, TCH>(v, wscr, wscr_lds, tw, ln, tid & 63);
+#pragma unroll
+            for (int j = 0; j < H; ++j) if (j * R + ln >= N) v[j] = make_float2(0.f, 0.f);    // keep outputs 0 .. N-1: the padding stays zero
+#pragma unroll
+            for (int j = H; j < R; ++j) v[j] = make_float2(0.f, 0.f);
+        };
+        if constexpr (CONV) {
+            if (job.flags & P2_PRE_A) a_conv();
+            prefetch_part(MSL_IC(0), MSL_IC(H / 2));
+#pragma unroll
+            for (int j = 0; j < H; ++j) v[j] = cmulf(v[j], tv[j]);
+            if (job.flags & P2_POST_A) a_conv();
+            prefetch_part(MSL_IC(H / 2), MSL_IC(H));
+        } else {
         if (job.flags & P2_PRE_A) a_first();
         prefetch_part(MSL_IC(0), MSL_IC(H / 4));
         if (job.flags & P2_PRE_A) a_second();
@@ -1343,6 +1364,7 @@ __global__ void __launch_bounds__(16 * R, (R == 32) ? 2 : 4) rowTB_pass_kernel(R
         prefetch_part(MSL_IC(H / 2), MSL_IC(3 * H / 4));
         if (job.flags & P2_POST_A) a_second();
         prefetch_part(MSL_IC(3 * H / 4), MSL_IC(H));
+        }
         wave_lds_fence();
 #pragma unroll
         for (int j = 0; j < H; ++j) myrow[j * R + ln] = v[j];
@@ -1452,7 +1474,7 @@ __device__ __forceinline__ void fft2048_wave(float2 (&v)[32], float* scr, const 
 // Transposing pass A . t_k . A for lines of any length 513 <= N <= 1024: rowTB_pass_kernel's chirp-z scheme on fft2048_wave.
 // One wave per line, 8 lines per workgroup; between two of these passes the work buffers are in the paired-lines layout (see
 // rowTP_pass_kernel), so that a transposed 128-byte segment is two positions of the tile's eight lines.
-template <bool IN_P, bool OUT_P>
+template <bool IN_P, bool OUT_P, bool CONV>
 __global__ void __launch_bounds__(512, 2) rowTB2_pass_kernel(RowTJob job) {
     constexpr int R = 32, M = 2048, H = 16, NH = M / 2, LINES = 8, NT = 512, TCH = 8;
     constexpr int RS = (R * W2K_PITCH) / 2 + 1;        // tile row in float2 (1553: the transpose scratch; >= NH positions; = 17 mod 32)
@@ -1462,13 +1484,13 @@ __global__ void __launch_bounds__(512, 2) rowTB2_pass_kernel(RowTJob job) {
     float2* bf = w64 + 64;                                    // NH + 2
     float2* bp = bf + NH + 2;                                 // NH
     float2* bw = bp + NH;                                     // NH
-    float2* tile = bw + NH;                                   // LINES * RS
+    float2* tile = CONV ? bp : bw + NH;                       // LINES * RS  (the convolution form needs neither P nor the chirp)
     const int tid = threadIdx.x;
     const int N = job.n_line;
     for (int i = tid; i < M; i += NT) tw[lds_pos64(i)] = job.tw[i];
     if (tid < 64) w64[tid] = job.tw2[tid];
     for (int i = tid; i <= NH; i += NT) bf[i] = job.bf[i];
-    for (int i = tid; i < NH; i += NT) { bp[i] = job.pl[i]; bw[i] = job.bw[i]; }
+    if constexpr (!CONV) { for (int i = tid; i < NH; i += NT) { bp[i] = job.pl[i]; bw[i] = job.bw[i]; } }
     __syncthreads();
     const int wv = tid >> 6, L = tid & 63, la = lam64(L);
     const float sgn = (L & 1) ? -1.f : 1.f;
@@ -1563,6 +1585,23 @@ __global__ void __launch_bounds__(512, 2) rowTB2_pass_kernel(RowTJob job) {
             fft2048_wave<true, TCH>(v, scr, tw, w64, L, la, sgn);
             mul_half(v, bw, std::true_type{});
         };
+        auto a_conv = [&]() {                                   // see rowTB_pass_kernel
+            fft2048_wave<false, TCH>(v, scr, tw, w64, L, la, sgn);
+            mul_filter(v, std::false_type{});
+            fft2048_wave<true, TCH>(v, scr, tw, w64, L, la, sgn);
+#pragma unroll
+            for (int j = 0; j < H; ++j) if (j * 64 + la >= N) v[j] = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int j = H; j < R; ++j) v[j] = make_float2(0.f, 0.f);
+        };
+        if constexpr (CONV) {
+            if (job.flags & P2_PRE_A) a_conv();
+            prefetch_part(MSL_IC(0), MSL_IC(8));
+#pragma unroll
+            for (int j = 0; j < H; ++j) v[j] = cmulf(v[j], tv[j]);
+            if (job.flags & P2_POST_A) a_conv();
+            prefetch_part(MSL_IC(8), MSL_IC(16));
+        } else {
         if (job.flags & P2_PRE_A) a_first();
         prefetch_part(MSL_IC(0), MSL_IC(4));
         if (job.flags & P2_PRE_A) a_second();
@@ -1573,6 +1612,7 @@ __global__ void __launch_bounds__(512, 2) rowTB2_pass_kernel(RowTJob job) {
         prefetch_part(MSL_IC(8), MSL_IC(12));
         if (job.flags & P2_POST_A) a_second();
         prefetch_part(MSL_IC(12), MSL_IC(16));
+        }
         wave_lds_fence();
 #pragma unroll
         for (int j = 0; j < H; ++j) myrow[j * 64 + la] = v[j];

@@ -70,11 +70,12 @@ struct msl_handle {
     char* scratch = nullptr;       // reductions: partial sums / masks / index lists
     size_t scratch_bytes = 0;
     bool onepass = false;
+    bool conv_form = true;          // any-length register kernels: propagation as a cyclic convolution (MSL_CHIRPZ=1: chirp-z DFTs)
     bool scheme_b = false;         // a direction of 2R^2 points: every pass transposes, first pass along y, final transpose if nz is odd
     // one-pass kernel per direction: R^2 register kernel, 2 R^2 (two) register kernel with its tables, or the generic LDS kernel
     // (breg: any length <= R^2/2 by Bluestein's chirp-z on the R^2 register FFTs, with its filter bf and chirp bw)
     // (breg2: lengths 513..1024 by the same scheme on the wave-per-line 2048-point FFT; tw = T[k1*64+n2], tw2 = W_64 table)
-    struct OpDir { int R = 0; bool two = false; bool generic = false; bool breg = false; bool breg2 = false; bool wave2k = false; float2* tw = nullptr; float2* tw2 = nullptr;
+    struct OpDir { int R = 0; bool two = false; bool generic = false; bool breg = false; bool breg2 = false; bool wave2k = false; float2* tw = nullptr; float2* tw2 = nullptr; float2* qf = nullptr;
                    float2* ptab = nullptr; float2* bf = nullptr; float2* bw = nullptr; } opx, opy;
     float2* psiT = nullptr;
     float2* psi0T = nullptr;
@@ -755,10 +756,10 @@ int launch_rowT2_r(msl_handle* h, RowTJob job, int kind) {
 }
 
 // lines of any length <= R^2/2: Bluestein on the register FFTs
-template <int R>
+template <int R, bool CONV>
 int launch_rowTB_r(msl_handle* h, RowTJob job, int kind) {
     constexpr int M = R * R, NH = M / 2, CS = R * (R + 1) + 2;
-    const size_t lds = ((size_t)M + NH + 2 + NH + NH + (size_t)16 * CS) * 8;
+    const size_t lds = ((size_t)M + NH + 2 + (CONV ? 0 : NH + NH) + (size_t)16 * CS) * 8;
     const int per_cu = std::max(1, std::min(R == 16 ? 4 : 1, (int)((size_t)h->lds_limit / lds)));
     const long long slots = (long long)h->n_cus * per_cu;
     const long long lb = (job.n_lines + 15) / 16;
@@ -767,17 +768,17 @@ int launch_rowTB_r(msl_handle* h, RowTJob job, int kind) {
     job.pchunk = pc;
     const long long items = lb * ((job.n_images + pc - 1) / pc);
     const int grid = (int)std::min<long long>(items, slots);
-    (void)hipFuncSetAttribute((const void*)rowTB_pass_kernel<R>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
-    hipLaunchKernelGGL(rowTB_pass_kernel<R>, dim3(grid), dim3(16 * R), lds, h->stream, job);
+    (void)hipFuncSetAttribute((const void*)rowTB_pass_kernel<R, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
+    hipLaunchKernelGGL((rowTB_pass_kernel<R, CONV>), dim3(grid), dim3(16 * R), lds, h->stream, job);
     HIPCHK(h, hipGetLastError());
     return mark_launch(h, kind);
 }
 
 // lines of 513..1024 points: Bluestein on the wave-per-line 2048-point register FFT
-template <bool IN_P, bool OUT_P>
+template <bool IN_P, bool OUT_P, bool CONV>
 int launch_rowTB2_io(msl_handle* h, RowTJob job, int kind) {
     constexpr int M = 2048, NH = M / 2, RS = (32 * W2K_PITCH) / 2 + 1;
-    const size_t lds = ((size_t)M + 64 + NH + 2 + NH + NH + (size_t)8 * RS) * 8;
+    const size_t lds = ((size_t)M + 64 + NH + 2 + (CONV ? 0 : NH + NH) + (size_t)8 * RS) * 8;
     const long long slots = h->n_cus;
     const long long lb = (job.n_lines + 7) / 8;
     int pc = choose_pchunk(lb, job.n_images, slots, job.t_group);
@@ -785,8 +786,8 @@ int launch_rowTB2_io(msl_handle* h, RowTJob job, int kind) {
     job.pchunk = pc;
     const long long items = lb * ((job.n_images + pc - 1) / pc);
     const int grid = (int)std::min<long long>(items, slots);
-    (void)hipFuncSetAttribute((const void*)rowTB2_pass_kernel<IN_P, OUT_P>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
-    hipLaunchKernelGGL((rowTB2_pass_kernel<IN_P, OUT_P>), dim3(grid), dim3(512), lds, h->stream, job);
+    (void)hipFuncSetAttribute((const void*)rowTB2_pass_kernel<IN_P, OUT_P, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
+    hipLaunchKernelGGL((rowTB2_pass_kernel<IN_P, OUT_P, CONV>), dim3(grid), dim3(512), lds, h->stream, job);
     HIPCHK(h, hipGetLastError());
     return mark_launch(h, kind);
 }
@@ -845,10 +846,15 @@ int launch_rowT_dir(msl_handle* h, const msl_handle::OpDir& o, RowTJob job, int 
     if (o.wave2k) { job.tw2 = o.tw2; return launch_rowTW(h, job, kind); }
     job.flags &= ~(P2_IN_PAIRED | P2_OUT_PAIRED);
     if (o.breg || o.breg2) {
-        job.pl = o.ptab; job.bf = o.bf; job.bw = o.bw;
         job.n_line = (&o == &h->opx) ? h->cfg.nx : h->cfg.ny;
-        if (o.breg2) { job.tw2 = o.tw2; return launch_rowTB2_io<false, false>(h, job, kind); }
-        return o.R == 32 ? launch_rowTB_r<32>(h, job, kind) : launch_rowTB_r<16>(h, job, kind);
+        if (h->conv_form) {                 // A as one cyclic convolution of length M (two FFTs); bf = its filter
+            job.pl = nullptr; job.bf = o.qf; job.bw = nullptr;
+            if (o.breg2) { job.tw2 = o.tw2; return launch_rowTB2_io<false, false, true>(h, job, kind); }
+            return o.R == 32 ? launch_rowTB_r<32, true>(h, job, kind) : launch_rowTB_r<16, true>(h, job, kind);
+        }
+        job.pl = o.ptab; job.bf = o.bf; job.bw = o.bw;       // MSL_CHIRPZ=1: every N-point DFT by chirp-z (four FFTs per A)
+        if (o.breg2) { job.tw2 = o.tw2; return launch_rowTB2_io<false, false, false>(h, job, kind); }
+        return o.R == 32 ? launch_rowTB_r<32, false>(h, job, kind) : launch_rowTB_r<16, false>(h, job, kind);
     }
     if (o.two) {
         job.tw2 = o.tw2; job.pl = o.ptab;
@@ -1104,6 +1110,36 @@ int fill_propagator(msl_handle* h) {
         }
         HIPCHK(h, hipMemcpyAsync(o.ptab, v.data(), NH * sizeof(float2), hipMemcpyHostToDevice, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
+        // convolution form: a = ifft_n(P) (float64), wrapped to the cyclic length M = 2 NH, filter = FFT_M(q) / M, first half + 1
+        {
+            const int M = 2 * NH;
+            std::vector<double> pr(n), pi(n), er(n), ei(n), qr(M, 0.0), qi(M, 0.0);
+            for (int m = 0; m < n; ++m) {
+                const int f = (m < (n + 1) / 2) ? m : m - n;
+                const double k = f * (1.0 / (n * d));
+                const double ph = -M_PI * c.wavelength * c.dz * k * k;
+                pr[m] = cos(ph); pi[m] = sin(ph);
+                const double a = 2.0 * M_PI * (double)m / (double)n;
+                er[m] = cos(a); ei[m] = sin(a);
+            }
+            for (int j = 0; j < n; ++j) {                      // a[j] = (1/n) sum_m P[m] e^{+2 pi i m j / n}
+                double sr = 0.0, si = 0.0;
+                long long t = 0;
+                for (int m = 0; m < n; ++m) {
+                    sr += pr[m] * er[t] - pi[m] * ei[t];
+                    si += pr[m] * ei[t] + pi[m] * er[t];
+                    t += j; if (t >= n) t -= n;
+                }
+                sr /= n; si /= n;
+                qr[j] = sr; qi[j] = si;                         // lag +j
+                if (j) { qr[M - n + j] = sr; qi[M - n + j] = si; }   // lag j - n  (M - (n - j))
+            }
+            host_fft_pow2(qr, qi);
+            std::vector<float2> qf(NH + 2, make_float2(0.f, 0.f));
+            for (int j = 0; j <= NH; ++j) qf[j] = make_float2((float)(qr[j] / M), (float)(qi[j] / M));
+            HIPCHK(h, hipMemcpyAsync(o.qf, qf.data(), (NH + 2) * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+        }
         return MSL_OK;
     };
     if ((h->opx.breg || h->opx.breg2) && (rc = fill_padded(h->opx, c.nx, c.dx))) return rc;
@@ -1219,11 +1255,12 @@ int msl_create(const msl_config* cfg, msl_handle** out) {
                     return fail(h, MSL_ERR_HIP, "twiddle upload failed");
                 return MSL_OK;
             }
-            // chirp-z on the register FFTs of length M = R^2 >= 2n - 1.  A line costs the same whatever n is, so against the
-            // generic Stockham kernel (cost ~ n log n) it wins for n <= 128 (M = 256) and from n ~ 270 up (M = 1024), and everywhere
-            // the generic kernel would need its own, LDS-resident Bluestein transform (a prime factor above 13)
+            // zero-padded cyclic convolution (or, MSL_CHIRPZ=1, chirp-z) on the register FFTs of length M = R^2 >= 2n - 1.  A line
+            // costs the same whatever n is, so against the generic Stockham kernel (cost ~ n log n) it wins for n <= 128 (M = 256)
+            // and from n ~ 190 up (M = 1024; 64 probes x 50 slices: 160^2 1.83 M vs 1.72 M slice-steps/s, 200^2 1.23 vs 1.31 M,
+            // 240^2 0.84 vs 1.13 M), and everywhere the generic kernel would need its own LDS-resident Bluestein transform
             const bool smooth = ((&o == &h->opx) ? h->plan_x : h->plan_y).M == n;
-            if (!two_ok && want && n >= 33 && n <= 512 && (n <= 128 || n >= 272 || !smooth) && !getenv("MSL_NO_BLUESTEIN_REG")) {
+            if (!two_ok && want && n >= 33 && n <= 512 && (n <= 128 || n >= 192 || !smooth) && !getenv("MSL_NO_BLUESTEIN_REG")) {
                 const int Rb = (n <= 128) ? 16 : 32, M = Rb * Rb, NH = M / 2;
                 o.R = Rb; o.breg = true;
                 int r = make_tw4(h, &o.tw, Rb);
@@ -1242,14 +1279,15 @@ int msl_create(const msl_config* cfg, msl_handle** out) {
                 if ((r = dalloc(h, &o.bw, (size_t)NH))) return r;
                 if ((r = dalloc(h, &o.bf, (size_t)NH + 2))) return r;
                 if ((r = dalloc(h, &o.ptab, (size_t)NH))) return r;
+                if ((r = dalloc(h, &o.qf, (size_t)NH + 2))) return r;
                 if (hipMemcpy(o.bw, bw.data(), NH * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess ||
                     hipMemcpy(o.bf, bf.data(), (NH + 2) * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess)
                     return fail(h, MSL_ERR_HIP, "chirp table upload failed");
                 return MSL_OK;
             }
-            if (!two_ok && want && n >= 513 && n <= 1024 && (!smooth || (n >= 640 && n != 768)) && !getenv("MSL_NO_BLUESTEIN_REG")) {
-                // 513..1024: chirp-z on the wave-per-line 2048-point register FFT (every non-smooth length; smooth ones where the
-                // Stockham kernel measured slower: 700: 930 -> 832 us per pass, 1000: 1450 -> 1210; 600 and 768 stay generic)
+            if (!two_ok && want && n >= 513 && n <= 1024 && !getenv("MSL_NO_BLUESTEIN_REG")) {
+                // 513..1024: the same on the wave-per-line 2048-point register FFT, every length (convolution form against the
+                // Stockham kernel: 540^2 102 k -> 186 k slice-steps/s, 600^2 85 k -> 160 k, 768^2 73 k -> 130 k)
                 constexpr int M = 2048, NH = 1024;
                 o.R = 32; o.breg2 = true;
                 std::vector<float2> T(M), W(64), bw(NH, make_float2(0.f, 0.f)), bf(NH + 2, make_float2(0.f, 0.f));
@@ -1279,6 +1317,7 @@ int msl_create(const msl_config* cfg, msl_handle** out) {
                 if ((r = dalloc(h, &o.bw, (size_t)NH))) return r;
                 if ((r = dalloc(h, &o.bf, (size_t)NH + 2))) return r;
                 if ((r = dalloc(h, &o.ptab, (size_t)NH))) return r;
+                if ((r = dalloc(h, &o.qf, (size_t)NH + 2))) return r;
                 if (hipMemcpy(o.tw, T.data(), M * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess ||
                     hipMemcpy(o.tw2, W.data(), 64 * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess ||
                     hipMemcpy(o.bw, bw.data(), NH * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess ||
@@ -1324,6 +1363,7 @@ int msl_create(const msl_config* cfg, msl_handle** out) {
             if (h->need_psi0T && (rc = dalloc(h, &h->psi0T, (size_t)cfg->ny * h->pitchT * images))) return bail(rc);
             if ((rc = dalloc(h, &h->transT, npix * cfg->nz * h->FB))) return bail(rc);
             { const char* ev = getenv("MSL_ROWT_VARIANT"); if (ev) h->rowT_variant = atoi(ev); }
+            h->conv_form = !getenv("MSL_CHIRPZ");
             { const char* ev = getenv("MSL_ROWT_PAIRED"); if (ev) h->rowT_paired = atoi(ev); }
             { const char* ev = getenv("MSL_DEBUG_FLAGS_MASK"); if (ev) h->debug_flags_mask = atoi(ev); }
             (void)hipFuncSetAttribute((const void*)row_pass2_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
@@ -1362,7 +1402,7 @@ int msl_destroy(msl_handle* h) {
                     h->d_z2s, h->d_species, h->d_ff, h->d_xy, h->plan_x.tw, h->plan_y.tw, h->plan_t.tw, h->tw4_x, h->tw4_y,
                     h->scratch, h->psiT, h->psi0T, h->transT, h->bin_stage, h->st_acc, h->st_s1, h->st_s2, h->st_tw, h->st_bins, h->opx.tw2, h->opx.ptab, h->opy.tw2, h->opy.ptab,
                     ((h->opx.two || h->opx.breg || h->opx.breg2 || h->opx.wave2k) ? h->opx.tw : nullptr), ((h->opy.two || h->opy.breg || h->opy.breg2 || h->opy.wave2k) ? h->opy.tw : nullptr),
-                    h->opx.bf, h->opx.bw, h->opy.bf, h->opy.bw, h->plan_x.chirp, h->plan_x.bfilt, h->plan_y.chirp, h->plan_y.bfilt, h->plan_t.chirp, h->plan_t.bfilt};
+                    h->opx.bf, h->opx.bw, h->opy.bf, h->opy.bw, h->opx.qf, h->opy.qf, h->plan_x.chirp, h->plan_x.bfilt, h->plan_y.chirp, h->plan_y.bfilt, h->plan_t.chirp, h->plan_t.bfilt};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;

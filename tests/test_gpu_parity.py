@@ -713,14 +713,19 @@ def test_streaming_tacaw_c5_grid_window_and_bin(ps, orc):
     assert rel_l2(tac.total_diffraction, inten.sum(axis=1)) < TACAW_TOL
 
 
-@pytest.mark.parametrize("nx,ny,nz,P", [(501, 491, 5, 3), (500, 500, 4, 2), (33, 128, 3, 2), (129, 272, 4, 2), (100, 400, 3, 3),
-                                        (512, 300, 4, 2), (349, 1024, 3, 1), (271, 257, 2, 2), (491, 501, 1, 2), (360, 448, 2, 70)])
-def test_any_length_register_kernel_matches_oracle(ps, orc, nx, ny, nz, P):
-    """Lines of any length up to 512 run as Bluestein chirp-z transforms on the register FFTs (rowTB_pass_kernel: M = 256 for
-    n <= 128, M = 1024 for 272 <= n <= 512 and for every non-smooth n in between): the reference's own 501 x 491 grid
-    (src/unittests/00_probe.py:7-8) in both orientations, the boundaries of the length ranges, line counts that are not
-    multiples of 16, mixes with the power-of-two and generic kernels, many probes, odd and even depths."""
+@pytest.mark.parametrize("nx,ny,nz,P,chirpz", [(501, 491, 5, 3, 0), (500, 500, 4, 2, 0), (33, 128, 3, 2, 0), (129, 272, 4, 2, 0),
+                                               (100, 400, 3, 3, 0), (512, 300, 4, 2, 0), (349, 1024, 3, 1, 0), (271, 257, 2, 2, 0),
+                                               (491, 501, 1, 2, 0), (360, 448, 2, 70, 0), (192, 180, 3, 2, 0), (200, 191, 4, 2, 0),
+                                               (501, 491, 4, 2, 1), (100, 400, 3, 2, 1)])
+def test_any_length_register_kernel_matches_oracle(ps, orc, nx, ny, nz, P, chirpz, monkeypatch):
+    """Lines of any length up to 512 run on the register FFTs (rowTB_pass_kernel: M = 256 for n <= 128, M = 1024 for
+    192 <= n <= 512 and for every non-smooth n in between), the propagation A = ifft.P.fft as ONE zero-padded cyclic convolution
+    of length M (two FFTs) -- or, MSL_CHIRPZ=1, every N-point DFT as a chirp-z transform (four): the reference's own
+    501 x 491 grid (src/unittests/00_probe.py:7-8) in both orientations, the boundaries of the length ranges, line counts that
+    are not multiples of 16, mixes with the power-of-two and generic kernels, many probes, odd and even depths."""
     from pyslice_amd.synthetic import synthetic_trajectory
+    if chirpz:
+        monkeypatch.setenv("MSL_CHIRPZ", "1")
     tr = synthetic_trajectory(nx, nz, 2, ny=ny, density=0.04, seed=nx + ny)
     lx, ly = tr.box_matrix[0, 0], tr.box_matrix[1, 1]
     pp = [tuple(v) for v in np.random.default_rng(9).random((P, 2)) * [lx, ly]]
@@ -733,13 +738,15 @@ def test_any_length_register_kernel_matches_oracle(ps, orc, nx, ny, nz, P):
     assert ref_residual(got[chk], want) < RESID_TOL
 
 
-@pytest.mark.parametrize("nx,ny,nz,P", [(997, 600, 3, 2), (700, 700, 4, 1), (513, 1000, 2, 2), (1021, 576, 3, 1), (641, 333, 3, 2),
-                                        (768, 1024, 2, 1)])
-def test_lengths_513_to_1024_on_the_2048_point_wave_fft(ps, orc, nx, ny, nz, P):
-    """Lines of 513..1024 points (every non-smooth length, and smooth ones from 576) are chirp-z transforms on the wave-per-line
-    2048-point register FFT (rowTB2_pass_kernel): primes, range ends, line counts that are not multiples of 8, mixes with the
-    1024-point chirp-z kernel, the generic kernel and a power-of-two direction."""
+@pytest.mark.parametrize("nx,ny,nz,P,chirpz", [(997, 600, 3, 2, 0), (700, 700, 4, 1, 0), (513, 1000, 2, 2, 0), (1021, 576, 3, 1, 0),
+                                               (641, 333, 3, 2, 0), (768, 1024, 2, 1, 0), (997, 600, 3, 1, 1)])
+def test_lengths_513_to_1024_on_the_2048_point_wave_fft(ps, orc, nx, ny, nz, P, chirpz, monkeypatch):
+    """Lines of 513..1024 points run on the wave-per-line 2048-point register FFT (rowTB2_pass_kernel; convolution form, and
+    the chirp-z form behind MSL_CHIRPZ=1): primes, range ends, smooth lengths (600, 768), line counts that are not multiples of
+    8, mixes with the 1024-point kernel and a power-of-two direction."""
     from pyslice_amd.synthetic import synthetic_trajectory
+    if chirpz:
+        monkeypatch.setenv("MSL_CHIRPZ", "1")
     tr = synthetic_trajectory(nx, nz, 1, ny=ny, density=0.02, seed=nx + 3 * ny)
     lx, ly = tr.box_matrix[0, 0], tr.box_matrix[1, 1]
     pp = [tuple(v) for v in np.random.default_rng(10).random((P, 2)) * [lx, ly]]
