@@ -2094,6 +2094,120 @@ __global__ void __launch_bounds__(16 * R, 2) ifftT2_kernel(IfftT2Job job) {
     }
 }
 
+// Inverse transform of the potential build for grid lengths that are not powers of two (N <= R^2 / 2): every line an inverse
+// N-point DFT by chirp-z on the register FFTs, x = conj(w) . IFFT_M(FFT_M(pad(X conj(w))) conj(Bf)) (the inverse of
+// rowTB_pass_kernel's chirp-z form: same tables), stored TRANSPOSED through a 16-line tile -- two such passes give ifft2 with
+// the data back in its natural layout, the second one with the potential epilogue like ifftT2_kernel.  Replaces the generic
+// LDS-resident Bluestein kernel in that role (501^2 x 100 slices: 2 x 500 us -> 2 x ~90 us per frame: for the reference's
+// default single-probe runs the inverse transform of the potential WAS the frame).  The buffers are dense (pitch = line count,
+// any parity): stores are 8 bytes per line and guarded, a tile row still lands as one 128-byte run.
+struct IfftTBJob {
+    const float2* in;           // (n_images, n_lines, in_pitch): lines of n_line points in natural frequency order
+    float2* out_t;              // transposed store: out_t[img][pos][line]
+    float2* out_rows;           // row store (potential epilogue only): out_rows[img][line][pos]
+    const float2* tw;           // four-step twiddles of length M = R^2
+    const float2* bf;           // chirp filter, first half + 1
+    const float2* bw;           // chirp, zero beyond n_line
+    long long in_is, out_t_is, out_rows_is;
+    int in_pitch, out_t_pitch, out_rows_pitch, n_lines, n_line, n_images;
+    int potential;              // 1: V = Re(.) * scale, out = exp(i sigma V)
+    int rows_parity;            // potential: images with (img & 1) == rows_parity are stored as rows, the others transposed; -1: none
+    float scale, sigma_over_pi;
+};
+
+template <int R>
+__global__ void __launch_bounds__(16 * R, (R == 32) ? 2 : 4) ifftTB_kernel(IfftTBJob job) {
+    constexpr int M = R * R, H = R / 2, NH = M / 2, LINES = 16, NT = LINES * R, TCH = 8;
+    constexpr int CS = R * (R + 1) + 2;
+    constexpr int POS_PER_IT = NT / LINES, NIT = NH / POS_PER_IT;       // one thread per (position, line) of a tile row
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float2* tw = reinterpret_cast<float2*>(smem_raw);         // M
+    float2* bf = tw + M;                                      // NH + 2
+    float2* bw = bf + NH + 2;                                 // NH
+    float2* tile = bw + NH;                                   // LINES * CS
+    const int tid = threadIdx.x;
+    const int N = job.n_line;
+    for (int i = tid; i < M; i += NT) tw[i] = job.tw[i];
+    for (int i = tid; i <= NH; i += NT) bf[i] = job.bf[i];
+    for (int i = tid; i < NH; i += NT) bw[i] = job.bw[i];
+    __syncthreads();
+    const int grp = tid / R, ln = tid % R;
+    const int li = tid % LINES, r0 = tid / LINES;             // store role: line li of the tile, positions r0 + POS_PER_IT * i
+    float2* myrow = tile + grp * CS;
+    const float* wscr = reinterpret_cast<const float*>(tile + (grp - grp % (64 / R)) * CS);
+    const unsigned wscr_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(tile + (grp - grp % (64 / R)) * CS));
+    const float2* fa = bf + ln;
+    const float2* fb = bf - ln;
+    const int lblocks = (job.n_lines + LINES - 1) / LINES;
+    const int n_items = lblocks * job.n_images;
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int img = item / lblocks, lb = item - img * lblocks;
+        const int L = min(lb * LINES + grp, job.n_lines - 1);                 // surplus lines of the last block repeat the last one
+        const float2* src = job.in + (long long)img * job.in_is + (long long)L * job.in_pitch;
+        float2 v[R];
+#pragma unroll
+        for (int j = 0; j < H; ++j) v[j] = (j * R + ln < N) ? src[j * R + ln] : make_float2(0.f, 0.f);
+        // x conj(w); the chirp table is zero beyond N, the upper half of the registers is padding
+        auto mul_chirp = [&]() {
+#pragma unroll
+            for (int c = 0; c < H; c += TCH) {
+                float2 w[TCH];
+#pragma unroll
+                for (int j = 0; j < TCH; ++j) w[j] = bw[(c + j) * R + ln];
+#pragma unroll
+                for (int j = 0; j < TCH; ++j) v[c + j] = cmulf_conj(v[c + j], w[j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int j = H; j < R; ++j) v[j] = make_float2(0.f, 0.f);
+        };
+        mul_chirp();
+        fourstep_split_addtid<R, false, TCH>(v, wscr, wscr_lds, tw, ln, tid & 63);
+#pragma unroll
+        for (int c = 0; c < R; c += TCH) {
+            float2 w[TCH];
+#pragma unroll
+            for (int j = 0; j < TCH; ++j) w[j] = (c + j < H) ? fa[(c + j) * R] : fb[(R - (c + j)) * R];
+#pragma unroll
+            for (int j = 0; j < TCH; ++j) v[c + j] = cmulf_conj(v[c + j], w[j]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        fourstep_split_addtid<R, true, TCH>(v, wscr, wscr_lds, tw, ln, tid & 63);
+        mul_chirp();
+        if (job.potential) {
+#pragma unroll
+            for (int j = 0; j < H; ++j) {
+                if (j % 4 == 0) __builtin_amdgcn_sched_barrier(0);
+                float sn, cs;
+                sincospif(job.sigma_over_pi * (v[j].x * job.scale), &sn, &cs);
+                v[j] = make_float2(cs, sn);
+            }
+        }
+        if (job.potential && (img & 1) == job.rows_parity) {       // workgroup-uniform: this slice is kept as rows
+            if (lb * LINES + grp < job.n_lines) {
+                float2* dst = job.out_rows + (long long)img * job.out_rows_is + (long long)L * job.out_rows_pitch;
+#pragma unroll
+                for (int j = 0; j < H; ++j) if (j * R + ln < N) dst[j * R + ln] = v[j];
+            }
+            continue;
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int j = 0; j < H; ++j) myrow[j * R + ln] = v[j];
+        lds_barrier();
+        const int col = lb * LINES + li;
+        if (col < job.n_lines) {
+            float2* dst = job.out_t + (long long)img * job.out_t_is + col;
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) {
+                const int pos = r0 + POS_PER_IT * i;
+                if (pos < N) dst[(long long)pos * job.out_t_pitch] = tile[li * CS + pos];
+            }
+        }
+        lds_barrier();
+    }
+}
+
 // out[img][c][r] = in[img][r][c]  (rows x cols -> cols x rows), 32x32 tiles through LDS
 __global__ void __launch_bounds__(256) transpose_kernel(const float2* __restrict__ in, float2* __restrict__ out, int rows,
                                                         int cols, int in_pitch, int out_pitch, long long in_is,

@@ -1670,7 +1670,39 @@ int msl_build_potential(msl_handle* h, const double* pos, const int32_t* Z, int6
     h->cur = nullptr;
     // (512-point lines only: with 64 complex values per lane the 2048-point instantiation spills and is slower than the generic kernel)
     const bool ifft_t2 = h->onepass && h->opx.two && h->opy.two && h->opx.R == 16 && h->opy.R == 16 && !h->V && !getenv("MSL_NO_IFFT_T2");
-    if (ifft_t2) {
+    // any length up to 512 on both axes (the register chirp-z tables exist): two transposing chirp-z passes, see ifftTB_kernel
+    const bool ifft_tb = h->onepass && h->opx.breg && h->opy.breg && !h->V && TRT && !getenv("MSL_NO_IFFT_TB");
+    if (ifft_tb) {
+        auto pass = [&](const msl_handle::OpDir& o, IfftTBJob j) -> int {
+            const int R = o.R, M = R * R, NH = M / 2, CS = R * (R + 1) + 2;
+            const size_t lds = ((size_t)M + NH + 2 + NH + (size_t)16 * CS) * 8;
+            const int per_cu = std::max(1, std::min(R == 16 ? 4 : 1, (int)((size_t)h->lds_limit / lds)));
+            const long long items = (long long)((j.n_lines + 15) / 16) * j.n_images;
+            const int grid = (int)std::min<long long>(items, (long long)h->n_cus * per_cu);
+            j.tw = o.tw; j.bf = o.bf; j.bw = o.bw;
+            if (R == 32) {
+                (void)hipFuncSetAttribute((const void*)ifftTB_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
+                hipLaunchKernelGGL(ifftTB_kernel<32>, dim3(grid), dim3(512), lds, h->stream, j);
+            } else {
+                (void)hipFuncSetAttribute((const void*)ifftTB_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
+                hipLaunchKernelGGL(ifftTB_kernel<16>, dim3(grid), dim3(256), lds, h->stream, j);
+            }
+            HIPCHK(h, hipGetLastError());
+            return mark_launch(h, K_OTHER);
+        };
+        IfftTBJob a{};
+        a.in = TR; a.out_t = TRT; a.out_rows = nullptr;
+        a.in_is = a.out_t_is = (long long)npix; a.in_pitch = c.ny; a.out_t_pitch = c.nx; a.n_lines = c.nx; a.n_line = c.ny; a.n_images = c.nz;
+        a.potential = 0; a.rows_parity = -1;
+        if ((rc = pass(h->opy, a))) return rc;
+        IfftTBJob b{};
+        b.in = TRT; b.out_t = TR; b.out_rows = TRT;
+        b.in_is = b.out_t_is = b.out_rows_is = (long long)npix; b.in_pitch = c.nx; b.out_t_pitch = c.ny; b.out_rows_pitch = c.nx;
+        b.n_lines = c.ny; b.n_line = c.nx; b.n_images = c.nz; b.potential = 1;
+        b.rows_parity = slice_is_transposed(h, 1) ? 1 : 0;       // the slices a pass along x reads stay in TRT as rows
+        b.scale = vscale; b.sigma_over_pi = (float)(c.sigma / M_PI);
+        if ((rc = pass(h->opx, b))) return rc;
+    } else if (ifft_t2) {
         // 512 / 2048 grids: two transposing inverse-FFT passes on the register kernels (TR -> TRT along y, TRT -> TR / TRT along
         // x with the potential epilogue; slices a pass along x reads stay in TRT as rows)
         auto pass = [&](int R, const IfftT2Job& j) -> int {
@@ -1710,7 +1742,7 @@ int msl_build_potential(msl_handle* h, const double* pos, const int32_t* Z, int6
         r.fft1 = -1;
         if ((rc = launch_lines(h, h->plan_y, r, K_OTHER))) return rc;
     }
-    if (ifft_t2) {
+    if (ifft_t2 || ifft_tb) {
         // (both passes done above)
     } else if (h->Rx) {
         ColJob k = col_job(h, TR, TR, c.nz, c.ny, c.ny);
