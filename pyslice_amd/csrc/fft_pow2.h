@@ -2140,13 +2140,25 @@ __global__ void __launch_bounds__(16 * R, (R == 32) ? 2 : 4) ifftTB_kernel(IfftT
     const float2* fb = bf - ln;
     const int lblocks = (job.n_lines + LINES - 1) / LINES;
     const int n_items = lblocks * job.n_images;
-    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-        const int img = item / lblocks, lb = item - img * lblocks;
+    // the next item's line is loaded into registers while the current one is transformed
+    float2 vn[H];
+    auto load_line = [&](int it) {
+        const int img = it / lblocks, lb = it - img * lblocks;
         const int L = min(lb * LINES + grp, job.n_lines - 1);                 // surplus lines of the last block repeat the last one
         const float2* src = job.in + (long long)img * job.in_is + (long long)L * job.in_pitch;
+#pragma unroll
+        for (int j = 0; j < H; ++j) vn[j] = (j * R + ln < N) ? src[j * R + ln] : make_float2(0.f, 0.f);
+    };
+    if ((int)blockIdx.x < n_items) load_line(blockIdx.x);
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int img = item / lblocks, lb = item - img * lblocks;
+        const int L = min(lb * LINES + grp, job.n_lines - 1);
         float2 v[R];
 #pragma unroll
-        for (int j = 0; j < H; ++j) v[j] = (j * R + ln < N) ? src[j * R + ln] : make_float2(0.f, 0.f);
+        for (int j = 0; j < H; ++j) v[j] = vn[j];
+        __builtin_amdgcn_sched_barrier(0);
+        if (item + (int)gridDim.x < n_items) load_line(item + (int)gridDim.x);
+        __builtin_amdgcn_sched_barrier(0);
         // x conj(w); the chirp table is zero beyond N, the upper half of the registers is padding
         auto mul_chirp = [&]() {
 #pragma unroll
