@@ -2105,7 +2105,8 @@ struct IfftTBJob {
     const float2* in;           // (n_images, n_lines, in_pitch): lines of n_line points in natural frequency order
     float2* out_t;              // transposed store: out_t[img][pos][line]
     float2* out_rows;           // row store (potential epilogue only): out_rows[img][line][pos]
-    const float2* tw;           // four-step twiddles of length M = R^2
+    const float2* tw;           // four-step twiddles of length M = R^2 (ifftTB2_kernel: the 2048-point wave FFT's T table)
+    const float2* tw2;          // ifftTB2_kernel: W_64 table
     const float2* bf;           // chirp filter, first half + 1
     const float2* bw;           // chirp, zero beyond n_line
     long long in_is, out_t_is, out_rows_is;
@@ -2214,6 +2215,112 @@ __global__ void __launch_bounds__(16 * R, (R == 32) ? 2 : 4) ifftTB_kernel(IfftT
             for (int i = 0; i < NIT; ++i) {
                 const int pos = r0 + POS_PER_IT * i;
                 if (pos < N) dst[(long long)pos * job.out_t_pitch] = tile[li * CS + pos];
+            }
+        }
+        lds_barrier();
+    }
+}
+
+// The same for lines of 513..1024 points on the 2048-point wave-per-line FFT (tables of rowTB2_pass_kernel): one wave per line,
+// 8 lines per workgroup, 64-byte runs in the transposed store.
+__global__ void __launch_bounds__(512, 2) ifftTB2_kernel(IfftTBJob job) {
+    constexpr int R = 32, M = 2048, H = 16, NH = M / 2, LINES = 8, NT = 512, TCH = 8;
+    constexpr int RS = (R * W2K_PITCH) / 2 + 1;
+    constexpr int POS_PER_IT = NT / LINES, NIT = NH / POS_PER_IT;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float2* tw = reinterpret_cast<float2*>(smem_raw);         // 2048, lane order (lds_pos64)
+    float2* w64 = tw + M;                                     // 64
+    float2* bf = w64 + 64;                                    // NH + 2
+    float2* bw = bf + NH + 2;                                 // NH
+    float2* tile = bw + NH;                                   // LINES * RS
+    const int tid = threadIdx.x;
+    const int N = job.n_line;
+    for (int i = tid; i < M; i += NT) tw[lds_pos64(i)] = job.tw[i];
+    if (tid < 64) w64[tid] = job.tw2[tid];
+    for (int i = tid; i <= NH; i += NT) bf[i] = job.bf[i];
+    for (int i = tid; i < NH; i += NT) bw[i] = job.bw[i];
+    __syncthreads();
+    const int wv = tid >> 6, L = tid & 63, la = lam64(L);
+    const float sgn = (L & 1) ? -1.f : 1.f;
+    const int li = tid % LINES, r0 = tid / LINES;
+    float2* myrow = tile + wv * RS;
+    float* scr = reinterpret_cast<float*>(myrow);
+    const float2* fa = bf + la;
+    const float2* fb = bf - la;
+    const int lblocks = (job.n_lines + LINES - 1) / LINES;
+    const int n_items = lblocks * job.n_images;
+    float2 vn[H];
+    auto load_line = [&](int it) {
+        const int img = it / lblocks, lb = it - img * lblocks;
+        const int Lc = min(lb * LINES + wv, job.n_lines - 1);
+        const float2* src = job.in + (long long)img * job.in_is + (long long)Lc * job.in_pitch;
+#pragma unroll
+        for (int j = 0; j < H; ++j) vn[j] = (j * 64 + la < N) ? src[j * 64 + la] : make_float2(0.f, 0.f);
+    };
+    if ((int)blockIdx.x < n_items) load_line(blockIdx.x);
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int img = item / lblocks, lb = item - img * lblocks;
+        const int Lc = min(lb * LINES + wv, job.n_lines - 1);
+        float2 v[R];
+#pragma unroll
+        for (int j = 0; j < H; ++j) v[j] = vn[j];
+        __builtin_amdgcn_sched_barrier(0);
+        if (item + (int)gridDim.x < n_items) load_line(item + (int)gridDim.x);
+        __builtin_amdgcn_sched_barrier(0);
+        auto mul_chirp = [&]() {
+#pragma unroll
+            for (int c = 0; c < H; c += TCH) {
+                float2 w[TCH];
+#pragma unroll
+                for (int j = 0; j < TCH; ++j) w[j] = bw[(c + j) * 64 + la];
+#pragma unroll
+                for (int j = 0; j < TCH; ++j) v[c + j] = cmulf_conj(v[c + j], w[j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int j = H; j < R; ++j) v[j] = make_float2(0.f, 0.f);
+        };
+        mul_chirp();
+        fft2048_wave<false, TCH>(v, scr, tw, w64, L, la, sgn);
+#pragma unroll
+        for (int c = 0; c < R; c += TCH) {
+            float2 w[TCH];
+#pragma unroll
+            for (int j = 0; j < TCH; ++j) w[j] = (c + j < H) ? fa[(c + j) * 64] : fb[(R - (c + j)) * 64];
+#pragma unroll
+            for (int j = 0; j < TCH; ++j) v[c + j] = cmulf_conj(v[c + j], w[j]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        fft2048_wave<true, TCH>(v, scr, tw, w64, L, la, sgn);
+        mul_chirp();
+        if (job.potential) {
+#pragma unroll
+            for (int j = 0; j < H; ++j) {
+                if (j % 4 == 0) __builtin_amdgcn_sched_barrier(0);
+                float sn, cs;
+                sincospif(job.sigma_over_pi * (v[j].x * job.scale), &sn, &cs);
+                v[j] = make_float2(cs, sn);
+            }
+        }
+        if (job.potential && (img & 1) == job.rows_parity) {
+            if (lb * LINES + wv < job.n_lines) {
+                float2* dst = job.out_rows + (long long)img * job.out_rows_is + (long long)Lc * job.out_rows_pitch;
+#pragma unroll
+                for (int j = 0; j < H; ++j) if (j * 64 + la < N) dst[j * 64 + la] = v[j];
+            }
+            continue;
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int j = 0; j < H; ++j) myrow[j * 64 + la] = v[j];
+        lds_barrier();
+        const int col = lb * LINES + li;
+        if (col < job.n_lines) {
+            float2* dst = job.out_t + (long long)img * job.out_t_is + col;
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) {
+                const int pos = r0 + POS_PER_IT * i;
+                if (pos < N) dst[(long long)pos * job.out_t_pitch] = tile[li * RS + pos];
             }
         }
         lds_barrier();

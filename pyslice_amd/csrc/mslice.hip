@@ -1671,9 +1671,20 @@ int msl_build_potential(msl_handle* h, const double* pos, const int32_t* Z, int6
     // (512-point lines only: with 64 complex values per lane the 2048-point instantiation spills and is slower than the generic kernel)
     const bool ifft_t2 = h->onepass && h->opx.two && h->opy.two && h->opx.R == 16 && h->opy.R == 16 && !h->V && !getenv("MSL_NO_IFFT_T2");
     // any length up to 512 on both axes (the register chirp-z tables exist): two transposing chirp-z passes, see ifftTB_kernel
-    const bool ifft_tb = h->onepass && h->opx.breg && h->opy.breg && !h->V && TRT && !getenv("MSL_NO_IFFT_TB");
+    const bool ifft_tb = h->onepass && (h->opx.breg || h->opx.breg2) && (h->opy.breg || h->opy.breg2) && !h->V && TRT && !getenv("MSL_NO_IFFT_TB");
     if (ifft_tb) {
         auto pass = [&](const msl_handle::OpDir& o, IfftTBJob j) -> int {
+            if (o.breg2) {                                  // 513 .. 1024 points: the wave-per-line 2048-point FFT
+                constexpr int M2 = 2048, NH2 = 1024, RS = (32 * W2K_PITCH) / 2 + 1;
+                const size_t lds2 = ((size_t)M2 + 64 + NH2 + 2 + NH2 + (size_t)8 * RS) * 8;
+                const long long items2 = (long long)((j.n_lines + 7) / 8) * j.n_images;
+                const int grid2 = (int)std::min<long long>(items2, (long long)h->n_cus);
+                j.tw = o.tw; j.tw2 = o.tw2; j.bf = o.bf; j.bw = o.bw;
+                (void)hipFuncSetAttribute((const void*)ifftTB2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
+                hipLaunchKernelGGL(ifftTB2_kernel, dim3(grid2), dim3(512), lds2, h->stream, j);
+                HIPCHK(h, hipGetLastError());
+                return mark_launch(h, K_OTHER);
+            }
             const int R = o.R, M = R * R, NH = M / 2, CS = R * (R + 1) + 2;
             const size_t lds = ((size_t)M + NH + 2 + NH + (size_t)16 * CS) * 8;
             const int per_cu = std::max(1, std::min(R == 16 ? 4 : 1, (int)((size_t)h->lds_limit / lds)));
