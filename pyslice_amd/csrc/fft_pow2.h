@@ -1654,6 +1654,123 @@ __global__ void __launch_bounds__(512, 2) rowTB2_pass_kernel(RowTJob job) {
     }
 }
 
+// Transposing pass A . t_k . A for lines of 1025 .. 2047 points (and 2048-point lines next to such an axis never use it): the
+// convolution form of rowTB2_pass_kernel with the cyclic length M = 4096, the 4096-point transforms built from fft2048_wave
+// by one radix-2 step that the zero padding makes half trivial.  A wave holds the line in two register sets lo / hi:
+//   forward  (x[n + 2048] = 0):  X[2k] = FFT_2048(x)[k],  X[2k+1] = FFT_2048(x W_4096^n)[k]        -> lo, hi
+//   filter in that split order:   lo *= Q[2k], hi *= Q[2k+1]   (both halves symmetric: Q[2k] about k = 1024, Q[2k+1] about 1023.5)
+//   inverse, outputs n < 2048 only:  y[n] = IFFT_2048(lo)[n] + conj(W_4096^n) IFFT_2048(hi)[n]
+// i.e. four 2048-point transforms per propagation, eight per pass -- per point the cost of the 513..1024 kernel.  No register is
+// left for a prefetch or for t_k (64 complex per lane): lines and t_k are loaded when needed, t_k into the idle hi set.  The tile
+// rows are the waves' transpose scratch (1553 float2): the transposed store goes in two halves of 1024 positions.
+// job.bf: Q[2k] (k = 0..1024, padded to 1026) followed by Q[2k+1] (k = 0..1023); job.bw: W_4096^n, n < 2048; job.n_line = N.
+__global__ void __launch_bounds__(512, 2) rowTC_pass_kernel(RowTJob job) {
+    constexpr int R = 32, M2 = 2048, LINES = 8, NT = 512, TCH = 8;
+    constexpr int RS = (R * W2K_PITCH) / 2 + 1;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float2* tw = reinterpret_cast<float2*>(smem_raw);         // 2048, lane order
+    float2* w64 = tw + M2;                                    // 64
+    float2* wq = w64 + 64;                                    // 2048: W_4096^n, lane order
+    float2* qe = wq + M2;                                     // 1026
+    float2* qo = qe + 1026;                                   // 1024 (+2)
+    float2* tile = qo + 1026;                                 // LINES * RS
+    const int tid = threadIdx.x;
+    const int N = job.n_line;
+    for (int i = tid; i < M2; i += NT) { tw[lds_pos64(i)] = job.tw[i]; wq[lds_pos64(i)] = job.bw[i]; }
+    if (tid < 64) w64[tid] = job.tw2[tid];
+    for (int i = tid; i < 2052; i += NT) qe[i] = job.bf[i];
+    __syncthreads();
+    const int wv = tid >> 6, L = tid & 63, la = lam64(L);
+    const float sgn = (L & 1) ? -1.f : 1.f;
+    const int li = tid % LINES, r0 = tid / LINES;
+    float2* myrow = tile + wv * RS;
+    float* scr = reinterpret_cast<float*>(myrow);
+    const float2* ea = qe + la;                               // Q[2 (64 j + la)],                      j < 16
+    const float2* eb = qe - la;                               // Q[2 (2048 - (64 j + la))] = qe[64 (32 - j) - la],  j >= 16
+    const float2* oa = qo + la;                               // Q[2 (64 j + la) + 1],                  j < 16
+    const float2* ob = qo + 63 - la;                          // Q[2 (2047 - (64 j + la)) + 1] = qo[64 (31 - j) + 63 - la],  j >= 16
+    const int lblocks = (job.n_lines + LINES - 1) / LINES;
+    const int n_items = lblocks * job.n_images;
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int p = item / lblocks, lb = item - p * lblocks;
+        const int Lc = min(lb * LINES + wv, job.n_lines - 1);
+        float2 lo[R], hi[R];
+        {
+            const float2* r = job.in + (long long)p * job.in_image_stride + (long long)Lc * job.in_pitch;
+#pragma unroll
+            for (int j = 0; j < R; ++j) lo[j] = (j * 64 + la < N) ? ld_stream(r + (j * 64 + la)) : make_float2(0.f, 0.f);
+        }
+        auto conv = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int c = 0; c < R; c += TCH) {                 // hi = x W_4096^n
+                float2 w[TCH];
+#pragma unroll
+                for (int j = 0; j < TCH; ++j) w[j] = wq[(c + j) * 64 + L];
+#pragma unroll
+                for (int j = 0; j < TCH; ++j) hi[c + j] = cmulf(lo[c + j], w[j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            fft2048_wave<false, TCH>(lo, scr, tw, w64, L, la, sgn);
+            __builtin_amdgcn_sched_barrier(0);              // one transform at a time: their temporaries do not fit side by side
+            fft2048_wave<false, TCH>(hi, scr, tw, w64, L, la, sgn);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c = 0; c < R; c += TCH) {
+                float2 w[TCH];
+#pragma unroll
+                for (int j = 0; j < TCH; ++j) w[j] = (c + j < 16) ? ea[(c + j) * 64] : eb[(R - (c + j)) * 64];
+#pragma unroll
+                for (int j = 0; j < TCH; ++j) lo[c + j] = cmulf(lo[c + j], w[j]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < TCH; ++j) w[j] = (c + j < 16) ? oa[(c + j) * 64] : ob[(R - 1 - (c + j)) * 64];
+#pragma unroll
+                for (int j = 0; j < TCH; ++j) hi[c + j] = cmulf(hi[c + j], w[j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            fft2048_wave<true, TCH>(lo, scr, tw, w64, L, la, sgn);
+            __builtin_amdgcn_sched_barrier(0);
+            fft2048_wave<true, TCH>(hi, scr, tw, w64, L, la, sgn);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c = 0; c < R; c += TCH) {                 // y = lo + conj(W_4096^n) hi, outputs beyond N dropped
+                float2 w[TCH];
+#pragma unroll
+                for (int j = 0; j < TCH; ++j) w[j] = wq[(c + j) * 64 + L];
+#pragma unroll
+                for (int j = 0; j < TCH; ++j) {
+                    const float2 t = cmulf_conj(hi[c + j], w[j]);
+                    lo[c + j] = ((c + j) * 64 + la < N) ? make_float2(lo[c + j].x + t.x, lo[c + j].y + t.y) : make_float2(0.f, 0.f);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        if (job.flags & P2_PRE_A) conv();
+        {
+            const float2* trow = job.trans + frame_off(job, p) + (long long)Lc * N;       // t_k into the idle hi set
+#pragma unroll
+            for (int j = 0; j < R; ++j) hi[j] = (j * 64 + la < N) ? trow[j * 64 + la] : make_float2(0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < R; ++j) lo[j] = cmulf(lo[j], hi[j]);
+        }
+        if (job.flags & P2_POST_A) conv();
+        float2* dst = job.out + (long long)p * job.out_image_stride + lb * LINES + li;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            wave_lds_fence();
+#pragma unroll
+            for (int j = 0; j < 16; ++j) myrow[j * 64 + la] = lo[c * 16 + j];
+            lds_barrier();
+#pragma unroll
+            for (int i = 0; i < 1024 / (NT / LINES); ++i) {
+                const int pos = r0 + (NT / LINES) * i;
+                if (c * 1024 + pos < N) dst[(long long)(c * 1024 + pos) * job.out_pitch] = tile[li * RS + pos];
+            }
+            lds_barrier();
+        }
+    }
+}
+
 // Transposing pass A . t_k . A for 2048-point lines on fft2048_wave: one wave per line, 8 lines per workgroup, the next line
 // prefetched in registers, t_k in registers across a chunk of probes (rowT_pass_kernel's scheme; the 2 R^2 layout of
 // rowT2_pass_kernel<32> has room for neither).  IN_P / OUT_P: paired-lines layout of the work buffers between two passes.

@@ -75,7 +75,7 @@ struct msl_handle {
     // one-pass kernel per direction: R^2 register kernel, 2 R^2 (two) register kernel with its tables, or the generic LDS kernel
     // (breg: any length <= R^2/2 by Bluestein's chirp-z on the R^2 register FFTs, with its filter bf and chirp bw)
     // (breg2: lengths 513..1024 by the same scheme on the wave-per-line 2048-point FFT; tw = T[k1*64+n2], tw2 = W_64 table)
-    struct OpDir { int R = 0; bool two = false; bool generic = false; bool breg = false; bool breg2 = false; bool wave2k = false; float2* tw = nullptr; float2* tw2 = nullptr; float2* qf = nullptr;
+    struct OpDir { int R = 0; bool two = false; bool generic = false; bool breg = false; bool breg2 = false; bool breg4 = false; bool wave2k = false; float2* tw = nullptr; float2* tw2 = nullptr; float2* qf = nullptr;
                    float2* ptab = nullptr; float2* bf = nullptr; float2* bw = nullptr; } opx, opy;
     float2* psiT = nullptr;
     float2* psi0T = nullptr;
@@ -845,6 +845,19 @@ int launch_rowT_dir(msl_handle* h, const msl_handle::OpDir& o, RowTJob job, int 
     job.tw = o.tw;
     if (o.wave2k) { job.tw2 = o.tw2; return launch_rowTW(h, job, kind); }
     job.flags &= ~(P2_IN_PAIRED | P2_OUT_PAIRED);
+    if (o.breg4) {
+        job.n_line = (&o == &h->opx) ? h->cfg.nx : h->cfg.ny;
+        job.tw2 = o.tw2; job.bf = o.qf; job.bw = o.bw; job.pl = nullptr;
+        constexpr int RS = (32 * W2K_PITCH) / 2 + 1;
+        const size_t lds = ((size_t)2048 + 64 + 2048 + 2052 + (size_t)8 * RS) * 8;
+        const long long items = (long long)((job.n_lines + 7) / 8) * job.n_images;
+        const int grid = (int)std::min<long long>(items, (long long)h->n_cus);
+        job.pchunk = 1;
+        (void)hipFuncSetAttribute((const void*)rowTC_pass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
+        hipLaunchKernelGGL(rowTC_pass_kernel, dim3(grid), dim3(512), lds, h->stream, job);
+        HIPCHK(h, hipGetLastError());
+        return mark_launch(h, kind);
+    }
     if (o.breg || o.breg2) {
         job.n_line = (&o == &h->opx) ? h->cfg.nx : h->cfg.ny;
         if (h->conv_form) {                 // A as one cyclic convolution of length M (two FFTs); bf = its filter
@@ -1144,6 +1157,40 @@ int fill_propagator(msl_handle* h) {
     };
     if ((h->opx.breg || h->opx.breg2) && (rc = fill_padded(h->opx, c.nx, c.dx))) return rc;
     if ((h->opy.breg || h->opy.breg2) && (rc = fill_padded(h->opy, c.ny, c.dy))) return rc;
+    // 1025..2047 points: filter of the cyclic convolution of length 4096 in the split order of rowTC_pass_kernel
+    auto fill_conv4 = [&](const msl_handle::OpDir& o, int n, double d) -> int {
+        const int M = 4096;
+        std::vector<double> pr(n), pi(n), er(n), ei(n), qr(M, 0.0), qi(M, 0.0);
+        for (int m = 0; m < n; ++m) {
+            const int f = (m < (n + 1) / 2) ? m : m - n;
+            const double k = f * (1.0 / (n * d));
+            const double ph = -M_PI * c.wavelength * c.dz * k * k;
+            pr[m] = cos(ph); pi[m] = sin(ph);
+            const double a = 2.0 * M_PI * (double)m / (double)n;
+            er[m] = cos(a); ei[m] = sin(a);
+        }
+        for (int j = 0; j < n; ++j) {
+            double sr = 0.0, si = 0.0;
+            long long t = 0;
+            for (int m = 0; m < n; ++m) {
+                sr += pr[m] * er[t] - pi[m] * ei[t];
+                si += pr[m] * ei[t] + pi[m] * er[t];
+                t += j; if (t >= n) t -= n;
+            }
+            sr /= n; si /= n;
+            qr[j] = sr; qi[j] = si;
+            if (j) { qr[M - n + j] = sr; qi[M - n + j] = si; }
+        }
+        host_fft_pow2(qr, qi);
+        std::vector<float2> qf(2052, make_float2(0.f, 0.f));
+        for (int k = 0; k <= 1024; ++k) qf[k] = make_float2((float)(qr[2 * k] / M), (float)(qi[2 * k] / M));
+        for (int k = 0; k < 1024; ++k) qf[1026 + k] = make_float2((float)(qr[2 * k + 1] / M), (float)(qi[2 * k + 1] / M));
+        HIPCHK(h, hipMemcpyAsync(o.qf, qf.data(), qf.size() * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        return MSL_OK;
+    };
+    if (h->opx.breg4 && (rc = fill_conv4(h->opx, c.nx, c.dx))) return rc;
+    if (h->opy.breg4 && (rc = fill_conv4(h->opy, c.ny, c.dy))) return rc;
     return MSL_OK;
 }
 
@@ -1325,6 +1372,39 @@ int msl_create(const msl_config* cfg, msl_handle** out) {
                     return fail(h, MSL_ERR_HIP, "chirp table upload failed");
                 return MSL_OK;
             }
+            if (!two_ok && want && n >= 1025 && n <= 2047 && getenv("MSL_CONV4096") && !getenv("MSL_NO_BLUESTEIN_REG")) {
+                // 1025..2047 (opt-in, MSL_CONV4096=1): cyclic convolution of length 4096 on pairs of 2048-point wave FFTs
+                // (rowTC_pass_kernel).  Parity-green, one pass per slice, but two 64-register line sets plus the transform's
+                // temporaries spill (916 B per lane) and nothing is prefetched: 1100^2 x 16 probes 20.0 k vs 19.6 k slice-steps/s for
+                // the generic two-pass loop, 2000^2 8.0 k vs 6.8 k -- not yet worth making the default.
+                constexpr int M = 2048;
+                o.R = 32; o.breg4 = true;
+                std::vector<float2> T(M), W(64), wq(M);
+                for (int k1 = 0; k1 < 32; ++k1)
+                    for (int n2 = 0; n2 < 64; ++n2) {
+                        const double a = -2.0 * M_PI * (double)(k1 * n2) / (double)M;
+                        T[k1 * 64 + n2] = make_float2((float)cos(a), (float)sin(a));
+                    }
+                for (int m = 0; m < 32; ++m) {
+                    const double a = -2.0 * M_PI * m / 64.0;
+                    W[m] = make_float2(1.f, 0.f);
+                    W[32 + m] = make_float2((float)cos(a), (float)sin(a));
+                }
+                for (int i = 0; i < M; ++i) {
+                    const double a = -2.0 * M_PI * (double)i / 4096.0;
+                    wq[i] = make_float2((float)cos(a), (float)sin(a));
+                }
+                int r;
+                if ((r = dalloc(h, &o.tw, (size_t)M))) return r;
+                if ((r = dalloc(h, &o.tw2, (size_t)64))) return r;
+                if ((r = dalloc(h, &o.bw, (size_t)M))) return r;
+                if ((r = dalloc(h, &o.qf, (size_t)2052))) return r;
+                if (hipMemcpy(o.tw, T.data(), M * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess ||
+                    hipMemcpy(o.tw2, W.data(), 64 * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess ||
+                    hipMemcpy(o.bw, wq.data(), M * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess)
+                    return fail(h, MSL_ERR_HIP, "twiddle upload failed");
+                return MSL_OK;
+            }
             if (!two_ok) {
                 // generic LDS kernel with a transposing store: tiles of >= 8 lines keep the stores at 64 bytes or more
                 const int M = (&o == &h->opx) ? h->plan_x.M : h->plan_y.M;
@@ -1348,7 +1428,7 @@ int msl_create(const msl_config* cfg, msl_handle** out) {
         if ((rc = setup_dir(h->opy, cfg->ny, cfg->nx, h->Ry, h->tw4_y))) return bail(rc);
         h->onepass = want && (h->opx.R || h->opx.generic) && (h->opy.R || h->opy.generic);
         h->scheme_b = h->onepass && (h->opx.two || h->opy.two || h->opx.generic || h->opy.generic || h->opx.breg || h->opy.breg ||
-                                     h->opx.breg2 || h->opy.breg2 || h->opx.wave2k || h->opy.wave2k);
+                                     h->opx.breg2 || h->opy.breg2 || h->opx.breg4 || h->opy.breg4 || h->opx.wave2k || h->opy.wave2k);
         if (h->pitch == cfg->ny && h->onepass) h->pitch = cfg->ny + 16;        // pad the work buffers of 2R^2 grids too
         if (h->onepass && (h->pitch & 1)) ++h->pitch;                          // even pitches: the transposed stores write two lines (16 bytes) at a time
         const size_t images = (size_t)cfg->n_probes * h->FB;
@@ -1401,7 +1481,7 @@ int msl_destroy(msl_handle* h) {
                     h->d_pos, h->d_Z, h->d_key, h->d_order, h->d_u1, h->d_u2, h->d_ex, h->d_ey, h->d_counts, h->d_start,
                     h->d_z2s, h->d_species, h->d_ff, h->d_xy, h->plan_x.tw, h->plan_y.tw, h->plan_t.tw, h->tw4_x, h->tw4_y,
                     h->scratch, h->psiT, h->psi0T, h->transT, h->bin_stage, h->st_acc, h->st_s1, h->st_s2, h->st_tw, h->st_bins, h->opx.tw2, h->opx.ptab, h->opy.tw2, h->opy.ptab,
-                    ((h->opx.two || h->opx.breg || h->opx.breg2 || h->opx.wave2k) ? h->opx.tw : nullptr), ((h->opy.two || h->opy.breg || h->opy.breg2 || h->opy.wave2k) ? h->opy.tw : nullptr),
+                    ((h->opx.two || h->opx.breg || h->opx.breg2 || h->opx.breg4 || h->opx.wave2k) ? h->opx.tw : nullptr), ((h->opy.two || h->opy.breg || h->opy.breg2 || h->opy.breg4 || h->opy.wave2k) ? h->opy.tw : nullptr),
                     h->opx.bf, h->opx.bw, h->opy.bf, h->opy.bw, h->opx.qf, h->opy.qf, h->plan_x.chirp, h->plan_x.bfilt, h->plan_y.chirp, h->plan_y.bfilt, h->plan_t.chirp, h->plan_t.bfilt};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->stream) (void)hipStreamDestroy(h->stream);

@@ -759,6 +759,24 @@ def test_lengths_513_to_1024_on_the_2048_point_wave_fft(ps, orc, nx, ny, nz, P, 
     assert ref_residual(got, want) < RESID_TOL
 
 
+@pytest.mark.parametrize("nx,ny,nz,P,conv4096", [(1100, 1030, 3, 2, 1), (1025, 512, 2, 1, 1), (1100, 1030, 2, 1, 0)])
+def test_lengths_1025_to_2047(ps, orc, nx, ny, nz, P, conv4096, monkeypatch):
+    """Lines of 1025..2047 points: the generic LDS kernels in the two-pass loop (default), and the opt-in cyclic convolution of
+    length 4096 on pairs of 2048-point wave FFTs (rowTC_pass_kernel, MSL_CONV4096=1), next to a 513..1024 and a 512-point axis."""
+    from pyslice_amd.synthetic import synthetic_trajectory
+    if conv4096:
+        monkeypatch.setenv("MSL_CONV4096", "1")
+    tr = synthetic_trajectory(nx, nz, 1, ny=ny, density=0.01, seed=nx + ny)
+    lx, ly = tr.box_matrix[0, 0], tr.box_matrix[1, 1]
+    pp = [tuple(v) for v in np.random.default_rng(3).random((P, 2)) * [lx, ly]]
+    calc = ps.MultisliceCalculator(progress=False, dtype="complex64")
+    calc.setup(tr, aperture=30.0, voltage_eV=100e3, probe_positions=pp)
+    got = npy(calc.run().wavefunction_data)
+    want = orc.run_frames(tr.box_matrix, tr.positions, tr.atom_types, 30.0, 100e3, pp)["wavefunction_data"]
+    assert rel_l2(got, want) < WAVE_TOL
+    assert ref_residual(got, want) < RESID_TOL
+
+
 @pytest.mark.parametrize("nx,ny,nz,P", [(2048, 2048, 3, 1), (2048, 2048, 4, 2), (2048, 512, 3, 2), (2048, 2048, 1, 1)])
 def test_2048_point_wave_per_line_kernel_matches_oracle(ps, orc, nx, ny, nz, P, monkeypatch):
     """2048-point lines on fft2048_wave (one wave per line, paired-lines layout between two such passes; a 2048 x 512 grid
