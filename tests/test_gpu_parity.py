@@ -372,7 +372,7 @@ def test_paired_lines_kernel_matches_oracle(ps, orc, nz, mode, monkeypatch):
 
 @pytest.mark.parametrize("nx,ny,nz,P,B", [(256, 256, 5, 1, 4), (256, 256, 4, 3, 2), (512, 512, 3, 1, 3), (512, 512, 4, 2, 4),
                                           (1024, 1024, 3, 1, 2), (1024, 256, 4, 1, 3), (96, 80, 3, 2, 4), (45, 63, 2, 1, 5),
-                                          (501, 64, 2, 1, 2), (2048, 512, 2, 1, 2), (256, 256, 1, 1, 4)])
+                                          (501, 64, 2, 1, 2), (2048, 512, 2, 1, 2), (256, 256, 1, 1, 4), (700, 300, 3, 2, 3)])
 def test_frame_batching_matches_oracle(ps, orc, nx, ny, nz, P, B):
     """frame_batch = B: B MD frames share every slice-loop launch (image = frame x probe, one transmission stack per
     frame).  5 frames, so the last batch is short; register kernels (256, 512, 1024, 2048 lines), the generic kernel and
