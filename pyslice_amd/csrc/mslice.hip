@@ -76,6 +76,9 @@ struct msl_handle {
     // (breg: any length <= R^2/2 by Bluestein's chirp-z on the R^2 register FFTs, with its filter bf and chirp bw)
     // (breg2: lengths 513..1024 by the same scheme on the wave-per-line 2048-point FFT; tw = T[k1*64+n2], tw2 = W_64 table)
     struct OpDir { int R = 0; bool two = false; bool generic = false; bool breg = false; bool breg2 = false; bool breg4 = false; bool wave2k = false; float2* tw = nullptr; float2* tw2 = nullptr; float2* qf = nullptr;
+        // chirp-z tables of an axis whose slice-loop kernel is not a chirp / convolution kernel (a power of two next to another length):
+        // only the potential's inverse transform uses them (ifftTB_kernel / ifftTB2_kernel).  cz_R: 16 / 32 (M = R^2) or 64 (the 2048-point wave FFT)
+        int cz_R = 0; float2* cz_tw = nullptr; float2* cz_tw2 = nullptr; float2* cz_bf = nullptr; float2* cz_bw = nullptr;
                    float2* ptab = nullptr; float2* bf = nullptr; float2* bw = nullptr; } opx, opy;
     float2* psiT = nullptr;
     float2* psi0T = nullptr;
@@ -438,6 +441,53 @@ int choose_pchunk(long long line_blocks, int n_images, long long slots, int t_gr
 
 // ---- four-step fast path ------------------------------------------------------------------------
 int fast_radix(int n) { return n == 1024 ? 32 : (n == 256 ? 16 : 0); }
+
+int make_tw4(msl_handle* h, float2** dst, int R);
+
+// chirp-z tables for inverse transforms of n points (33 <= n <= 1024) on the register FFTs, see OpDir::cz_*
+int make_cz_tables(msl_handle* h, msl_handle::OpDir& o, int n) {
+    const bool wave = n > 512;
+    const int R = wave ? 32 : (n <= 128 ? 16 : 32), M = wave ? 2048 : R * R, NH = M / 2;
+    int r;
+    if (wave) {
+        std::vector<float2> T(M), W(64);
+        for (int k1 = 0; k1 < 32; ++k1)
+            for (int n2 = 0; n2 < 64; ++n2) {
+                const double a = -2.0 * M_PI * (double)(k1 * n2) / (double)M;
+                T[k1 * 64 + n2] = make_float2((float)cos(a), (float)sin(a));
+            }
+        for (int m = 0; m < 32; ++m) {
+            const double a = -2.0 * M_PI * m / 64.0;
+            W[m] = make_float2(1.f, 0.f);
+            W[32 + m] = make_float2((float)cos(a), (float)sin(a));
+        }
+        if ((r = dalloc(h, &o.cz_tw, (size_t)M))) return r;
+        if ((r = dalloc(h, &o.cz_tw2, (size_t)64))) return r;
+        if (hipMemcpy(o.cz_tw, T.data(), M * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(o.cz_tw2, W.data(), 64 * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess)
+            return MSL_ERR_HIP;
+    } else if ((r = make_tw4(h, &o.cz_tw, R))) {
+        return r;
+    }
+    std::vector<float2> bw(NH, make_float2(0.f, 0.f)), bf(NH + 2, make_float2(0.f, 0.f));
+    std::vector<double> cr(M, 0.0), ci(M, 0.0);
+    for (int i = 0; i < n; ++i) {
+        const long long q = ((long long)i * i) % (2LL * n);
+        const double a = -M_PI * (double)q / (double)n;
+        bw[i] = make_float2((float)cos(a), (float)sin(a));
+        cr[i] = cos(a); ci[i] = -sin(a);
+        if (i) { cr[M - i] = cr[i]; ci[M - i] = ci[i]; }
+    }
+    host_fft_pow2(cr, ci);
+    for (int j = 0; j <= NH; ++j) bf[j] = make_float2((float)(cr[j] / M), (float)(ci[j] / M));
+    if ((r = dalloc(h, &o.cz_bw, (size_t)NH))) return r;
+    if ((r = dalloc(h, &o.cz_bf, (size_t)NH + 2))) return r;
+    if (hipMemcpy(o.cz_bw, bw.data(), NH * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(o.cz_bf, bf.data(), (NH + 2) * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess)
+        return MSL_ERR_HIP;
+    o.cz_R = wave ? 64 : R;
+    return MSL_OK;
+}
 
 int make_tw4(msl_handle* h, float2** dst, int R) {
     const int N = R * R;
@@ -1426,6 +1476,13 @@ int msl_create(const msl_config* cfg, msl_handle** out) {
         };
         if ((rc = setup_dir(h->opx, cfg->nx, cfg->ny, h->Rx, h->tw4_x))) return bail(rc);
         if ((rc = setup_dir(h->opy, cfg->ny, cfg->nx, h->Ry, h->tw4_y))) return bail(rc);
+        // a chirp / convolution axis next to another kind of axis of at most 1024 points: the other one gets chirp-z tables too, so
+        // that the potential's inverse transform runs on the register kernels along both (512 x 300, 349 x 1024 ...)
+        {
+            auto cz_axis = [](const msl_handle::OpDir& o) { return o.breg || o.breg2; };
+            if (want && cz_axis(h->opx) && !cz_axis(h->opy) && cfg->ny >= 33 && cfg->ny <= 1024 && (rc = make_cz_tables(h, h->opy, cfg->ny))) return bail(rc);
+            if (want && cz_axis(h->opy) && !cz_axis(h->opx) && cfg->nx >= 33 && cfg->nx <= 1024 && (rc = make_cz_tables(h, h->opx, cfg->nx))) return bail(rc);
+        }
         h->onepass = want && (h->opx.R || h->opx.generic) && (h->opy.R || h->opy.generic);
         h->scheme_b = h->onepass && (h->opx.two || h->opy.two || h->opx.generic || h->opy.generic || h->opx.breg || h->opy.breg ||
                                      h->opx.breg2 || h->opy.breg2 || h->opx.breg4 || h->opy.breg4 || h->opx.wave2k || h->opy.wave2k);
@@ -1482,7 +1539,8 @@ int msl_destroy(msl_handle* h) {
                     h->d_z2s, h->d_species, h->d_ff, h->d_xy, h->plan_x.tw, h->plan_y.tw, h->plan_t.tw, h->tw4_x, h->tw4_y,
                     h->scratch, h->psiT, h->psi0T, h->transT, h->bin_stage, h->st_acc, h->st_s1, h->st_s2, h->st_tw, h->st_bins, h->opx.tw2, h->opx.ptab, h->opy.tw2, h->opy.ptab,
                     ((h->opx.two || h->opx.breg || h->opx.breg2 || h->opx.breg4 || h->opx.wave2k) ? h->opx.tw : nullptr), ((h->opy.two || h->opy.breg || h->opy.breg2 || h->opy.breg4 || h->opy.wave2k) ? h->opy.tw : nullptr),
-                    h->opx.bf, h->opx.bw, h->opy.bf, h->opy.bw, h->opx.qf, h->opy.qf, h->plan_x.chirp, h->plan_x.bfilt, h->plan_y.chirp, h->plan_y.bfilt, h->plan_t.chirp, h->plan_t.bfilt};
+                    h->opx.bf, h->opx.bw, h->opy.bf, h->opy.bw, h->opx.qf, h->opy.qf, h->opx.cz_tw, h->opx.cz_tw2, h->opx.cz_bf, h->opx.cz_bw,
+                    h->opy.cz_tw, h->opy.cz_tw2, h->opy.cz_bf, h->opy.cz_bw, h->plan_x.chirp, h->plan_x.bfilt, h->plan_y.chirp, h->plan_y.bfilt, h->plan_t.chirp, h->plan_t.bfilt};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -1751,10 +1809,16 @@ int msl_build_potential(msl_handle* h, const double* pos, const int32_t* Z, int6
     // (512-point lines only: with 64 complex values per lane the 2048-point instantiation spills and is slower than the generic kernel)
     const bool ifft_t2 = h->onepass && h->opx.two && h->opy.two && h->opx.R == 16 && h->opy.R == 16 && !h->V && !getenv("MSL_NO_IFFT_T2");
     // any length up to 512 on both axes (the register chirp-z tables exist): two transposing chirp-z passes, see ifftTB_kernel
-    const bool ifft_tb = h->onepass && (h->opx.breg || h->opx.breg2) && (h->opy.breg || h->opy.breg2) && !h->V && TRT && !getenv("MSL_NO_IFFT_TB");
+    struct CzRef { int R; const float2 *tw, *tw2, *bf, *bw; };      // R = 64: the 2048-point wave FFT
+    auto cz_of = [](const msl_handle::OpDir& o) -> CzRef {
+        if (o.breg2) return {64, o.tw, o.tw2, o.bf, o.bw};
+        if (o.breg) return {o.R, o.tw, nullptr, o.bf, o.bw};
+        return {o.cz_R, o.cz_tw, o.cz_tw2, o.cz_bf, o.cz_bw};
+    };
+    const bool ifft_tb = h->onepass && cz_of(h->opx).R && cz_of(h->opy).R && !h->V && TRT && !getenv("MSL_NO_IFFT_TB");
     if (ifft_tb) {
-        auto pass = [&](const msl_handle::OpDir& o, IfftTBJob j) -> int {
-            if (o.breg2) {                                  // 513 .. 1024 points: the wave-per-line 2048-point FFT
+        auto pass = [&](const CzRef& o, IfftTBJob j) -> int {
+            if (o.R == 64) {                                // 513 .. 1024 points: the wave-per-line 2048-point FFT
                 constexpr int M2 = 2048, NH2 = 1024, RS = (32 * W2K_PITCH) / 2 + 1;
                 const size_t lds2 = ((size_t)M2 + 64 + NH2 + 2 + NH2 + (size_t)8 * RS) * 8;
                 const long long items2 = (long long)((j.n_lines + 7) / 8) * j.n_images;
@@ -1785,14 +1849,14 @@ int msl_build_potential(msl_handle* h, const double* pos, const int32_t* Z, int6
         a.in = TR; a.out_t = TRT; a.out_rows = nullptr;
         a.in_is = a.out_t_is = (long long)npix; a.in_pitch = c.ny; a.out_t_pitch = c.nx; a.n_lines = c.nx; a.n_line = c.ny; a.n_images = c.nz;
         a.potential = 0; a.rows_parity = -1;
-        if ((rc = pass(h->opy, a))) return rc;
+        if ((rc = pass(cz_of(h->opy), a))) return rc;
         IfftTBJob b{};
         b.in = TRT; b.out_t = TR; b.out_rows = TRT;
         b.in_is = b.out_t_is = b.out_rows_is = (long long)npix; b.in_pitch = c.nx; b.out_t_pitch = c.ny; b.out_rows_pitch = c.nx;
         b.n_lines = c.ny; b.n_line = c.nx; b.n_images = c.nz; b.potential = 1;
         b.rows_parity = slice_is_transposed(h, 1) ? 1 : 0;       // the slices a pass along x reads stay in TRT as rows
         b.scale = vscale; b.sigma_over_pi = (float)(c.sigma / M_PI);
-        if ((rc = pass(h->opx, b))) return rc;
+        if ((rc = pass(cz_of(h->opx), b))) return rc;
     } else if (ifft_t2) {
         // 512 / 2048 grids: two transposing inverse-FFT passes on the register kernels (TR -> TRT along y, TRT -> TR / TRT along
         // x with the potential epilogue; slices a pass along x reads stay in TRT as rows)
