@@ -2230,6 +2230,7 @@ struct IfftTBJob {
     int in_pitch, out_t_pitch, out_rows_pitch, n_lines, n_line, n_images;
     int potential;              // 1: V = Re(.) * scale, out = exp(i sigma V)
     int rows_parity;            // potential: images with (img & 1) == rows_parity are stored as rows, the others transposed; -1: none
+    int herm;                   // 1: only elements 0 .. n_line/2 of an input line exist, the others are conj(line[n_line - e]) (spectrum of a real image)
     float scale, sigma_over_pi;
 };
 
@@ -2264,8 +2265,14 @@ __global__ void __launch_bounds__(16 * R, (R == 32) ? 2 : 4) ifftTB_kernel(IfftT
         const int img = it / lblocks, lb = it - img * lblocks;
         const int L = min(lb * LINES + grp, job.n_lines - 1);                 // surplus lines of the last block repeat the last one
         const float2* src = job.in + (long long)img * job.in_is + (long long)L * job.in_pitch;
+        const int hx = job.herm ? N / 2 : N;
 #pragma unroll
-        for (int j = 0; j < H; ++j) vn[j] = (j * R + ln < N) ? src[j * R + ln] : make_float2(0.f, 0.f);
+        for (int j = 0; j < H; ++j) {
+            const int e = j * R + ln;
+            float2 x = (e < N) ? src[e <= hx ? e : N - e] : make_float2(0.f, 0.f);
+            if (e > hx) x.y = -x.y;
+            vn[j] = x;
+        }
     };
     if ((int)blockIdx.x < n_items) load_line(blockIdx.x);
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
@@ -2371,8 +2378,14 @@ __global__ void __launch_bounds__(512, 2) ifftTB2_kernel(IfftTBJob job) {
         const int img = it / lblocks, lb = it - img * lblocks;
         const int Lc = min(lb * LINES + wv, job.n_lines - 1);
         const float2* src = job.in + (long long)img * job.in_is + (long long)Lc * job.in_pitch;
+        const int hx = job.herm ? N / 2 : N;
 #pragma unroll
-        for (int j = 0; j < H; ++j) vn[j] = (j * 64 + la < N) ? src[j * 64 + la] : make_float2(0.f, 0.f);
+        for (int j = 0; j < H; ++j) {
+            const int e = j * 64 + la;
+            float2 x = (e < N) ? src[e <= hx ? e : N - e] : make_float2(0.f, 0.f);
+            if (e > hx) x.y = -x.y;
+            vn[j] = x;
+        }
     };
     if ((int)blockIdx.x < n_items) load_line(blockIdx.x);
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
