@@ -2130,6 +2130,7 @@ struct IfftT2Job {
     int in_pitch, out_t_pitch, out_rows_pitch, n_lines, n_images;
     int potential;              // 1: V = Re(.) * scale, out = exp(i sigma V)
     int rows_parity;            // potential: images with (img & 1) == rows_parity are stored as rows, the others transposed; -1: none
+    int herm;                   // 1: only elements 0 .. N/2 of an input line exist, the others are conj(line[N - e]) (spectrum of a real image)
     float scale, sigma_over_pi;
 };
 
@@ -2160,10 +2161,21 @@ __global__ void __launch_bounds__(16 * R, 2) ifftT2_kernel(IfftT2Job job) {
         int lnv = ln;                                       // laundered: keeps dozens of per-lane LDS / global addresses from being
         asm volatile("" : "+v"(lnv));                       // hoisted out of the loop into registers the transform needs
         float2 v[2 * R];
+        if (job.herm) {                                     // workgroup-uniform: mirrored elements as two 8-byte loads
 #pragma unroll
-        for (int j = 0; j < R; ++j) {
-            const float4 x = *reinterpret_cast<const float4*>(src + 2 * (j * R + lnv));
-            v[j] = make_float2(x.x, x.y); v[R + j] = make_float2(x.z, x.w);
+            for (int j = 0; j < R; ++j) {
+                const int e0 = 2 * (j * R + lnv), e1 = e0 + 1;
+                float2 a = src[e0 <= N / 2 ? e0 : N - e0], b = src[e1 <= N / 2 ? e1 : N - e1];
+                if (e0 > N / 2) a.y = -a.y;
+                if (e1 > N / 2) b.y = -b.y;
+                v[j] = a; v[R + j] = b;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                const float4 x = *reinterpret_cast<const float4*>(src + 2 * (j * R + lnv));
+                v[j] = make_float2(x.x, x.y); v[R + j] = make_float2(x.z, x.w);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
         float* scr = scratch;

@@ -1718,7 +1718,8 @@ int msl_build_potential(msl_handle* h, const double* pos, const int32_t* Z, int6
     bool recip_written = false;     // the structure-factor kernels write every bin of R_s; zero-fill only when none runs
     // R_s is Hermitian (real V): with the quadrant kernel and four-step transforms on both axes only the rows kx <= nx/2 are
     // written and row-transformed, and the column pass mirrors them while staging (col_pass_kernel<.., HERM>)
-    bool herm_ifft = false, herm_tb = false;
+    bool herm_ifft = false, herm_tb = false, herm_t2 = false;
+    const bool t2_axes = h->onepass && h->opx.two && h->opy.two && h->opx.R == 16 && h->opy.R == 16 && !h->V && !getenv("MSL_NO_IFFT_T2");
     // (the chirp-z inverse transform of the potential runs when both axes have chirp-z tables: see ifft_tb below)
     const bool tb_axes = h->onepass && !h->V && h->transT && !getenv("MSL_NO_IFFT_TB") &&
                          (h->opx.breg || h->opx.breg2 || h->opx.cz_R) && (h->opy.breg || h->opy.breg2 || h->opy.cz_R);
@@ -1785,8 +1786,9 @@ int msl_build_potential(msl_handle* h, const double* pos, const int32_t* Z, int6
                 const int qy = (c.ny / 2 + 32) / 32, n_tiles = ((c.nx / 2 + 32) / 32) * qy;      // ceil((n/2 + 1) / 32) per axis
                 herm_ifft = h->Rx && h->Ry && !getenv("MSL_NO_HERM_IFFT");       // four-step kernels on both axes (256 / 1024)
                 herm_tb = tb_axes && !getenv("MSL_NO_HERM_IFFT");                   // chirp-z inverse transform: rows kx <= nx/2 only, too
+                herm_t2 = t2_axes && !getenv("MSL_NO_HERM_IFFT");                   // and the 512-point register transform
                 hipLaunchKernelGGL(structure_factor_quad_kernel, dim3((n_tiles + 3) / 4, c.nz), dim3(256), 0, h->stream, TR,
-                                   h->d_ex, h->d_ey, h->d_ff, h->d_start, nsp, c.nx, c.ny, qy, n_tiles, (int)n, (herm_ifft || herm_tb) ? 0 : 1);
+                                   h->d_ex, h->d_ey, h->d_ff, h->d_start, nsp, c.nx, c.ny, qy, n_tiles, (int)n, (herm_ifft || herm_tb || herm_t2) ? 0 : 1);
             } else if (use_mfma) {
                 const int ty32 = c.ny / 32, n_tiles = (c.nx / 2 / 32) * ty32;
                 hipLaunchKernelGGL(structure_factor_mfma_kernel, dim3((n_tiles + 3) / 4, c.nz), dim3(256), 0, h->stream, TR,
@@ -1885,11 +1887,13 @@ int msl_build_potential(msl_handle* h, const double* pos, const int32_t* Z, int6
         a.in = TR; a.out_t = TRT; a.out_rows = nullptr; a.tw = h->opy.tw; a.tw2 = h->opy.tw2;
         a.in_is = a.out_t_is = (long long)npix; a.in_pitch = c.ny; a.out_t_pitch = c.nx; a.n_lines = c.nx; a.n_images = c.nz;
         a.potential = 0; a.rows_parity = -1;
+        if (herm_t2) a.n_lines = (c.nx / 2 + 1 + 15) / 16 * 16;        // rows kx <= nx/2 in whole 16-line blocks (the surplus rows are never read)
         if ((rc = pass(h->opy.R, a))) return rc;
         IfftT2Job b{};
         b.in = TRT; b.out_t = TR; b.out_rows = TRT; b.tw = h->opx.tw; b.tw2 = h->opx.tw2;
         b.in_is = b.out_t_is = b.out_rows_is = (long long)npix; b.in_pitch = c.nx; b.out_t_pitch = c.ny; b.out_rows_pitch = c.nx;
         b.n_lines = c.ny; b.n_images = c.nz; b.potential = 1; b.rows_parity = 1;      // scheme b: slice s is read along x iff s is odd
+        b.herm = herm_t2 ? 1 : 0;
         b.scale = vscale; b.sigma_over_pi = (float)(c.sigma / M_PI);
         if ((rc = pass(h->opx.R, b))) return rc;
     } else if (h->Ry) {
