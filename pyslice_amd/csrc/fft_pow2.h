@@ -1771,6 +1771,132 @@ __global__ void __launch_bounds__(512, 2) rowTC_pass_kernel(RowTJob job) {
     }
 }
 
+// The same pass with the two branches of the radix-2 step on TWO waves: wave 2l takes X[2k] (E = IFFT(FFT(x) Qe)), wave 2l + 1
+// takes X[2k+1] (O = conj(W) IFFT(FFT(x W) Qo)), the halves meet in the LDS (y = E + O).  A wave then holds ONE set of 32 complex
+// registers -- no spills -- at the price of four lines per workgroup (32-byte runs in the transposed store; the pass is bound
+// by its eight 2048-point transforms per line, not by the stores).  The two transpose-scratch rows of a pair (2 x 1553 float2)
+// double as the pair's exchange buffer (2048 float2) whenever neither wave is inside a transform.
+__global__ void __launch_bounds__(512, 2) rowTC2_pass_kernel(RowTJob job) {
+    constexpr int R = 32, M2 = 2048, LINES = 4, NT = 512, TCH = 8;
+    constexpr int RS = (R * W2K_PITCH) / 2 + 1;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float2* tw = reinterpret_cast<float2*>(smem_raw);         // 2048, lane order
+    float2* w64 = tw + M2;                                    // 64
+    float2* wq = w64 + 64;                                    // 2048: W_4096^n, lane order
+    float2* qe = wq + M2;                                     // 1026
+    float2* qo = qe + 1026;                                   // 1024 (+2)
+    float2* tile = qo + 1026;                                 // 8 rows of RS: rows 2l, 2l + 1 = pair l
+    const int tid = threadIdx.x;
+    const int N = job.n_line;
+    for (int i = tid; i < M2; i += NT) { tw[lds_pos64(i)] = job.tw[i]; wq[lds_pos64(i)] = job.bw[i]; }
+    if (tid < 64) w64[tid] = job.tw2[tid];
+    for (int i = tid; i < 2052; i += NT) qe[i] = job.bf[i];
+    __syncthreads();
+    const int wv = tid >> 6, L = tid & 63, la = lam64(L);
+    const int line = wv >> 1, role = wv & 1;
+    const float sgn = (L & 1) ? -1.f : 1.f;
+    const int li = tid % LINES, r0 = tid / LINES;
+    float* scr = reinterpret_cast<float*>(tile + wv * RS);
+    float2* pair = tile + 2 * line * RS;                      // the pair's exchange buffer: 2048 float2, natural order
+    const float2* fa = (role ? qo : qe) + la;                 // first half of this branch's filter
+    const float2* fb = role ? qo + 63 - la : qe - la;         // mirrored half (see rowTC_pass_kernel)
+    const int lblocks = (job.n_lines + LINES - 1) / LINES;
+    const int n_items = lblocks * job.n_images;
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int p = item / lblocks, lb = item - p * lblocks;
+        const int Lc = min(lb * LINES + line, job.n_lines - 1);
+        float2 v[R];
+        {
+            const float2* r = job.in + (long long)p * job.in_image_stride + (long long)Lc * job.in_pitch;
+#pragma unroll
+            for (int j = 0; j < R; ++j) v[j] = (j * 64 + la < N) ? ld_stream(r + (j * 64 + la)) : make_float2(0.f, 0.f);
+        }
+        auto mul_wq = [&](auto conj_c) {
+            constexpr bool CONJ = decltype(conj_c)::value;
+#pragma unroll
+            for (int c = 0; c < R; c += TCH) {
+                float2 w[TCH];
+#pragma unroll
+                for (int j = 0; j < TCH; ++j) w[j] = wq[(c + j) * 64 + L];
+#pragma unroll
+                for (int j = 0; j < TCH; ++j) v[c + j] = CONJ ? cmulf_conj(v[c + j], w[j]) : cmulf(v[c + j], w[j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        // this wave's branch of the cyclic convolution; afterwards role 0 holds y (outputs 0 .. N-1, the rest zero)
+        auto conv = [&]() __attribute__((always_inline)) {
+            if (role) mul_wq(std::false_type{});
+            fft2048_wave<false, TCH>(v, scr, tw, w64, L, la, sgn);
+#pragma unroll
+            for (int c = 0; c < R; c += TCH) {
+                float2 w[TCH];
+#pragma unroll
+                for (int j = 0; j < TCH; ++j) w[j] = (c + j < 16) ? fa[(c + j) * 64] : fb[(role ? R - 1 - (c + j) : R - (c + j)) * 64];
+#pragma unroll
+                for (int j = 0; j < TCH; ++j) v[c + j] = cmulf(v[c + j], w[j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            fft2048_wave<true, TCH>(v, scr, tw, w64, L, la, sgn);
+            if (role) mul_wq(std::true_type{});
+            lds_barrier();                                  // every wave has left its transform: the rows are free
+            if (role) {
+#pragma unroll
+                for (int j = 0; j < R; ++j) pair[j * 64 + la] = v[j];
+            }
+            lds_barrier();
+            if (!role) {
+#pragma unroll
+                for (int j = 0; j < R; ++j) {
+                    const float2 o = pair[j * 64 + la];
+                    v[j] = (j * 64 + la < N) ? make_float2(v[j].x + o.x, v[j].y + o.y) : make_float2(0.f, 0.f);
+                }
+            }
+        };
+        if (job.flags & P2_PRE_A) conv();
+        if (!role) {
+            const float2* trow = job.trans + frame_off(job, p) + (long long)Lc * N;
+#pragma unroll
+            for (int c = 0; c < R; c += TCH) {
+                float2 t[TCH];
+#pragma unroll
+                for (int j = 0; j < TCH; ++j) t[j] = ((c + j) * 64 + la < N) ? trow[(c + j) * 64 + la] : make_float2(0.f, 0.f);
+#pragma unroll
+                for (int j = 0; j < TCH; ++j) v[c + j] = cmulf(v[c + j], t[j]);
+            }
+        }
+        if (job.flags & P2_POST_A) {
+            lds_barrier();                                  // role 0 has read the first convolution's O
+            if (!role) {
+#pragma unroll
+                for (int j = 0; j < R; ++j) pair[j * 64 + la] = v[j];
+            }
+            lds_barrier();
+            if (role) {
+#pragma unroll
+                for (int j = 0; j < R; ++j) v[j] = pair[j * 64 + la];
+            }
+            lds_barrier();                                  // ... before anybody's transform writes its scratch row again
+            conv();
+        }
+        lds_barrier();                                      // role 0 has read O: the pair buffers become the tile rows
+        if (!role) {
+#pragma unroll
+            for (int j = 0; j < R; ++j) pair[j * 64 + la] = v[j];
+        }
+        lds_barrier();
+        {
+            float2* dst = job.out + (long long)p * job.out_image_stride + lb * LINES + li;
+            const float2* srcrow = tile + 2 * li * RS;
+#pragma unroll
+            for (int i = 0; i < M2 / (NT / LINES); ++i) {
+                const int pos = r0 + (NT / LINES) * i;
+                if (pos < N) dst[(long long)pos * job.out_pitch] = srcrow[pos];
+            }
+        }
+        lds_barrier();
+    }
+}
+
 // Transposing pass A . t_k . A for 2048-point lines on fft2048_wave: one wave per line, 8 lines per workgroup, the next line
 // prefetched in registers, t_k in registers across a chunk of probes (rowT_pass_kernel's scheme; the 2 R^2 layout of
 // rowT2_pass_kernel<32> has room for neither).  IN_P / OUT_P: paired-lines layout of the work buffers between two passes.

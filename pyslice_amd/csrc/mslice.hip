@@ -900,9 +900,17 @@ int launch_rowT_dir(msl_handle* h, const msl_handle::OpDir& o, RowTJob job, int 
         job.tw2 = o.tw2; job.bf = o.qf; job.bw = o.bw; job.pl = nullptr;
         constexpr int RS = (32 * W2K_PITCH) / 2 + 1;
         const size_t lds = ((size_t)2048 + 64 + 2048 + 2052 + (size_t)8 * RS) * 8;
+        job.pchunk = 1;
+        if (!(getenv("MSL_CONV4096") && atoi(getenv("MSL_CONV4096")) == 1)) {       // default form: two waves per line (no spills)
+            const long long items2 = (long long)((job.n_lines + 3) / 4) * job.n_images;
+            const int grid2 = (int)std::min<long long>(items2, (long long)h->n_cus);
+            (void)hipFuncSetAttribute((const void*)rowTC2_pass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
+            hipLaunchKernelGGL(rowTC2_pass_kernel, dim3(grid2), dim3(512), lds, h->stream, job);
+            HIPCHK(h, hipGetLastError());
+            return mark_launch(h, kind);
+        }
         const long long items = (long long)((job.n_lines + 7) / 8) * job.n_images;
         const int grid = (int)std::min<long long>(items, (long long)h->n_cus);
-        job.pchunk = 1;
         (void)hipFuncSetAttribute((const void*)rowTC_pass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
         hipLaunchKernelGGL(rowTC_pass_kernel, dim3(grid), dim3(512), lds, h->stream, job);
         HIPCHK(h, hipGetLastError());
@@ -1422,11 +1430,12 @@ int msl_create(const msl_config* cfg, msl_handle** out) {
                     return fail(h, MSL_ERR_HIP, "chirp table upload failed");
                 return MSL_OK;
             }
-            if (!two_ok && want && n >= 1025 && n <= 2047 && getenv("MSL_CONV4096") && !getenv("MSL_NO_BLUESTEIN_REG")) {
-                // 1025..2047 (opt-in, MSL_CONV4096=1): cyclic convolution of length 4096 on pairs of 2048-point wave FFTs
-                // (rowTC_pass_kernel).  Parity-green, one pass per slice, but two 64-register line sets plus the transform's
-                // temporaries spill (916 B per lane) and nothing is prefetched: 1100^2 x 16 probes 20.0 k vs 19.6 k slice-steps/s for
-                // the generic two-pass loop, 2000^2 8.0 k vs 6.8 k -- not yet worth making the default.
+            if (!two_ok && want && n >= 1025 && n <= 2047 && !getenv("MSL_NO_CONV4096") && !getenv("MSL_NO_BLUESTEIN_REG")) {
+                // 1025..2047: cyclic convolution of length 4096 on pairs of 2048-point wave FFTs, the two branches of the radix-2
+                // step on two waves (rowTC2_pass_kernel): 16 probes x 20 slices, slice-steps/s against the generic two-pass loop:
+                // 1100^2 19.6 k -> 27.5 k, 1500^2 12.6 k -> 18.3 k, 2000^2 6.8 k -> 11.4 k.  MSL_CONV4096=1 selects the first
+                // version, both branches in one wave (rowTC_pass_kernel): two 64-register line sets plus the transform's
+                // temporaries spill 916 B per lane and it is no faster than the generic loop (20.0 k at 1100^2).
                 constexpr int M = 2048;
                 o.R = 32; o.breg4 = true;
                 std::vector<float2> T(M), W(64), wq(M);

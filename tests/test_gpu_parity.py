@@ -759,13 +759,17 @@ def test_lengths_513_to_1024_on_the_2048_point_wave_fft(ps, orc, nx, ny, nz, P, 
     assert ref_residual(got, want) < RESID_TOL
 
 
-@pytest.mark.parametrize("nx,ny,nz,P,conv4096", [(1100, 1030, 3, 2, 1), (1025, 512, 2, 1, 1), (1100, 1030, 2, 1, 0)])
-def test_lengths_1025_to_2047(ps, orc, nx, ny, nz, P, conv4096, monkeypatch):
-    """Lines of 1025..2047 points: the generic LDS kernels in the two-pass loop (default), and the opt-in cyclic convolution of
-    length 4096 on pairs of 2048-point wave FFTs (rowTC_pass_kernel, MSL_CONV4096=1), next to a 513..1024 and a 512-point axis."""
+@pytest.mark.parametrize("nx,ny,nz,P,mode", [(1100, 1030, 3, 2, "two_waves"), (1025, 512, 2, 1, "two_waves"), (2047, 1200, 2, 1, "two_waves"),
+                                             (1500, 1029, 4, 3, "two_waves"), (1100, 1030, 3, 2, "one_wave"), (1100, 1030, 2, 1, "generic")])
+def test_lengths_1025_to_2047(ps, orc, nx, ny, nz, P, mode, monkeypatch):
+    """Lines of 1025..2047 points: cyclic convolution of length 4096 on pairs of 2048-point wave FFTs, the two branches of the
+    radix-2 step on two waves (rowTC2_pass_kernel, default) or in one (rowTC_pass_kernel, MSL_CONV4096=1), and the generic LDS
+    kernels in the two-pass loop (MSL_NO_CONV4096); next to a 513..1024-point and a 512-point axis, odd and even depths."""
     from pyslice_amd.synthetic import synthetic_trajectory
-    if conv4096:
+    if mode == "one_wave":
         monkeypatch.setenv("MSL_CONV4096", "1")
+    elif mode == "generic":
+        monkeypatch.setenv("MSL_NO_CONV4096", "1")
     tr = synthetic_trajectory(nx, nz, 1, ny=ny, density=0.01, seed=nx + ny)
     lx, ly = tr.box_matrix[0, 0], tr.box_matrix[1, 1]
     pp = [tuple(v) for v in np.random.default_rng(3).random((P, 2)) * [lx, ly]]
