@@ -591,7 +591,7 @@ def test_randomised_shape_sweep(ps, orc):
 
 
 def test_randomised_potential_sweep(ps, orc):
-    """30 random cases of tools/fuzz_potential.py (seed 5): grid shapes over every structure-factor / inverse-FFT path,
+    """40 random cases of tools/fuzz_potential.py (seed 5): grid shapes over every structure-factor / inverse-FFT path,
     1-3 species, atoms outside the box and outside every slice, one-pass and keep_potential engines."""
     import importlib.util
     import os
@@ -599,8 +599,8 @@ def test_randomised_potential_sweep(ps, orc):
     fuzzp = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fuzzp)
     rng = np.random.default_rng(5)
-    for c in range(30):
-        cfg, err = fuzzp.one(rng, max_pix=2 ** 18)
+    for c in range(40):
+        cfg, err = fuzzp.one(rng, max_pix=2 ** 18 if c % 4 else 2 ** 20)       # every fourth case may take the 513 .. 1100-point lengths
         assert err < POT_TOL, (cfg, err)
 
 

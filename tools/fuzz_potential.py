@@ -11,7 +11,7 @@ from oracle import multislice_oracle as orc
 from pyslice_amd import _native
 from pyslice_amd.potentials import loadKirkland
 
-LENGTHS = [256, 512, 64, 96, 128, 160, 200, 243, 250, 320, 101, 97, 127, 26, 39, 33, 1024]
+LENGTHS = [256, 512, 64, 96, 128, 160, 200, 243, 250, 320, 101, 97, 127, 26, 39, 33, 1024, 600, 997, 513, 1100]
 KIRK = None
 
 
