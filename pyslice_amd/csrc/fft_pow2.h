@@ -2595,6 +2595,76 @@ __global__ void __launch_bounds__(512, 2) ifftTB2_kernel(IfftTBJob job) {
     }
 }
 
+// Inverse transform of the potential build for 2048-point axes: one wave per line on fft2048_wave, stored transposed through an
+// 8-line tile (64-byte runs); two passes as ifftT2_kernel, the second with the potential epilogue.  (ifftT2_kernel<32>, the 2 R^2
+// layout with 64 complex per lane, spills and lost to the generic LDS kernel, which this one replaces.)  job.herm: as ifftTB_kernel.
+__global__ void __launch_bounds__(512, 2) ifftTW_kernel(IfftTBJob job) {
+    constexpr int R = 32, N = 2048, LINES = 8, NT = 512;
+    constexpr int RS = N + 1;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float2* tw = reinterpret_cast<float2*>(smem_raw);         // 2048, lane order
+    float2* w64 = tw + N;                                     // 64
+    float2* tile = w64 + 64;                                  // LINES * RS
+    const int tid = threadIdx.x;
+    for (int i = tid; i < N; i += NT) tw[lds_pos64(i)] = job.tw[i];
+    if (tid < 64) w64[tid] = job.tw2[tid];
+    __syncthreads();
+    const int wv = tid >> 6, L = tid & 63, la = lam64(L);
+    const float sgn = (L & 1) ? -1.f : 1.f;
+    const int li = tid % LINES, r0 = tid / LINES;
+    float2* myrow = tile + wv * RS;
+    float* scr = reinterpret_cast<float*>(myrow);
+    const int lblocks = job.n_lines / LINES;
+    const int n_items = lblocks * job.n_images;
+    float2 vn[R];
+    auto load_line = [&](int it) {
+        const int img = it / lblocks, lb = it - img * lblocks;
+        const float2* src = job.in + (long long)img * job.in_is + (long long)(lb * LINES + wv) * job.in_pitch;
+        const int hx = job.herm ? N / 2 : N;
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const int e = j * 64 + la;
+            float2 x = src[e <= hx ? e : N - e];
+            if (e > hx) x.y = -x.y;
+            vn[j] = x;
+        }
+    };
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {      // (no register prefetch: 64 + 64 registers plus the transform spill)
+        const int img = item / lblocks, lb = item - img * lblocks;
+        load_line(item);
+        float2 (&v)[R] = vn;
+        fft2048_wave<true, 8>(v, scr, tw, w64, L, la, sgn);
+        if (job.potential) {
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                if (j % 4 == 0) __builtin_amdgcn_sched_barrier(0);
+                float sn, cs;
+                sincospif(job.sigma_over_pi * (v[j].x * job.scale), &sn, &cs);
+                v[j] = make_float2(cs, sn);
+            }
+        }
+        if (job.potential && (img & 1) == job.rows_parity) {
+            float2* dst = job.out_rows + (long long)img * job.out_rows_is + (long long)(lb * LINES + wv) * job.out_rows_pitch;
+#pragma unroll
+            for (int j = 0; j < R; ++j) dst[j * 64 + la] = v[j];
+            continue;
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int j = 0; j < R; ++j) myrow[j * 64 + la] = v[j];
+        lds_barrier();
+        {
+            float2* dst = job.out_t + (long long)img * job.out_t_is + lb * LINES + li;
+#pragma unroll
+            for (int i = 0; i < N / (NT / LINES); ++i) {
+                const int pos = r0 + (NT / LINES) * i;
+                dst[(long long)pos * job.out_t_pitch] = tile[li * RS + pos];
+            }
+        }
+        lds_barrier();
+    }
+}
+
 // out[img][c][r] = in[img][r][c]  (rows x cols -> cols x rows), 32x32 tiles through LDS
 __global__ void __launch_bounds__(256) transpose_kernel(const float2* __restrict__ in, float2* __restrict__ out, int rows,
                                                         int cols, int in_pitch, int out_pitch, long long in_is,

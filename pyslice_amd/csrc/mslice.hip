@@ -1727,7 +1727,8 @@ int msl_build_potential(msl_handle* h, const double* pos, const int32_t* Z, int6
     bool recip_written = false;     // the structure-factor kernels write every bin of R_s; zero-fill only when none runs
     // R_s is Hermitian (real V): with the quadrant kernel and four-step transforms on both axes only the rows kx <= nx/2 are
     // written and row-transformed, and the column pass mirrors them while staging (col_pass_kernel<.., HERM>)
-    bool herm_ifft = false, herm_tb = false, herm_t2 = false;
+    bool herm_ifft = false, herm_tb = false, herm_t2 = false, herm_tw = false;
+    const bool tw_axes = h->onepass && h->opx.wave2k && h->opy.wave2k && !h->V && h->transT && !getenv("MSL_NO_IFFT_TW");
     const bool t2_axes = h->onepass && h->opx.two && h->opy.two && h->opx.R == 16 && h->opy.R == 16 && !h->V && !getenv("MSL_NO_IFFT_T2");
     // (the chirp-z inverse transform of the potential runs when both axes have chirp-z tables: see ifft_tb below)
     const bool tb_axes = h->onepass && !h->V && h->transT && !getenv("MSL_NO_IFFT_TB") &&
@@ -1796,8 +1797,9 @@ int msl_build_potential(msl_handle* h, const double* pos, const int32_t* Z, int6
                 herm_ifft = h->Rx && h->Ry && !getenv("MSL_NO_HERM_IFFT");       // four-step kernels on both axes (256 / 1024)
                 herm_tb = tb_axes && !getenv("MSL_NO_HERM_IFFT");                   // chirp-z inverse transform: rows kx <= nx/2 only, too
                 herm_t2 = t2_axes && !getenv("MSL_NO_HERM_IFFT");                   // and the 512-point register transform
+                herm_tw = tw_axes && !getenv("MSL_NO_HERM_IFFT");                   // and the 2048-point one
                 hipLaunchKernelGGL(structure_factor_quad_kernel, dim3((n_tiles + 3) / 4, c.nz), dim3(256), 0, h->stream, TR,
-                                   h->d_ex, h->d_ey, h->d_ff, h->d_start, nsp, c.nx, c.ny, qy, n_tiles, (int)n, (herm_ifft || herm_tb || herm_t2) ? 0 : 1);
+                                   h->d_ex, h->d_ey, h->d_ff, h->d_start, nsp, c.nx, c.ny, qy, n_tiles, (int)n, (herm_ifft || herm_tb || herm_t2 || herm_tw) ? 0 : 1);
             } else if (use_mfma) {
                 const int ty32 = c.ny / 32, n_tiles = (c.nx / 2 / 32) * ty32;
                 hipLaunchKernelGGL(structure_factor_mfma_kernel, dim3((n_tiles + 3) / 4, c.nz), dim3(256), 0, h->stream, TR,
@@ -1831,7 +1833,34 @@ int msl_build_potential(msl_handle* h, const double* pos, const int32_t* Z, int6
         return {o.cz_R, o.cz_tw, o.cz_tw2, o.cz_bf, o.cz_bw};
     };
     const bool ifft_tb = h->onepass && cz_of(h->opx).R && cz_of(h->opy).R && !h->V && TRT && !getenv("MSL_NO_IFFT_TB");
-    if (ifft_tb) {
+    // 2048 x 2048: the same two passes on the wave-per-line FFT (ifftTW_kernel)
+    const bool ifft_tw = h->onepass && h->opx.wave2k && h->opy.wave2k && !h->V && TRT && !getenv("MSL_NO_IFFT_TW");
+    if (ifft_tw) {
+        auto passw = [&](const msl_handle::OpDir& o, IfftTBJob j) -> int {
+            constexpr int N2 = 2048;
+            const size_t lds = ((size_t)N2 + 64 + (size_t)8 * (N2 + 1)) * 8;
+            const long long items = (long long)(j.n_lines / 8) * j.n_images;
+            const int grid = (int)std::min<long long>(items, (long long)h->n_cus);
+            j.tw = o.tw; j.tw2 = o.tw2;
+            (void)hipFuncSetAttribute((const void*)ifftTW_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
+            hipLaunchKernelGGL(ifftTW_kernel, dim3(grid), dim3(512), lds, h->stream, j);
+            HIPCHK(h, hipGetLastError());
+            return mark_launch(h, K_OTHER);
+        };
+        IfftTBJob a{};
+        a.in = TR; a.out_t = TRT; a.out_rows = nullptr;
+        a.in_is = a.out_t_is = (long long)npix; a.in_pitch = c.ny; a.out_t_pitch = c.nx; a.n_lines = c.nx; a.n_line = c.ny; a.n_images = c.nz;
+        a.potential = 0; a.rows_parity = -1;
+        if (herm_tw) a.n_lines = (c.nx / 2 + 1 + 7) / 8 * 8;
+        if ((rc = passw(h->opy, a))) return rc;
+        IfftTBJob b{};
+        b.in = TRT; b.out_t = TR; b.out_rows = TRT;
+        b.in_is = b.out_t_is = b.out_rows_is = (long long)npix; b.in_pitch = c.nx; b.out_t_pitch = c.ny; b.out_rows_pitch = c.nx;
+        b.n_lines = c.ny; b.n_line = c.nx; b.n_images = c.nz; b.potential = 1; b.herm = herm_tw ? 1 : 0;
+        b.rows_parity = slice_is_transposed(h, 1) ? 1 : 0;
+        b.scale = vscale; b.sigma_over_pi = (float)(c.sigma / M_PI);
+        if ((rc = passw(h->opx, b))) return rc;
+    } else if (ifft_tb) {
         auto pass = [&](const CzRef& o, IfftTBJob j) -> int {
             if (o.R == 64) {                                // 513 .. 1024 points: the wave-per-line 2048-point FFT
                 constexpr int M2 = 2048, NH2 = 1024, RS = (32 * W2K_PITCH) / 2 + 1;
@@ -1915,7 +1944,7 @@ int msl_build_potential(msl_handle* h, const double* pos, const int32_t* Z, int6
         r.fft1 = -1;
         if ((rc = launch_lines(h, h->plan_y, r, K_OTHER))) return rc;
     }
-    if (ifft_t2 || ifft_tb) {
+    if (ifft_t2 || ifft_tb || ifft_tw) {
         // (both passes done above)
     } else if (h->Rx) {
         ColJob k = col_job(h, TR, TR, c.nz, c.ny, c.ny);

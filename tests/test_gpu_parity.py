@@ -759,6 +759,28 @@ def test_lengths_513_to_1024_on_the_2048_point_wave_fft(ps, orc, nx, ny, nz, P, 
     assert ref_residual(got, want) < RESID_TOL
 
 
+@pytest.mark.parametrize("nz", [3, 2])
+def test_transmission_functions_2048_grid(ps, orc, nz):
+    """exp(i sigma V) on the C5 grid straight against the oracle: quadrant structure factor, half-spectrum inverse transform on the
+    2048-point wave FFT (ifftTW_kernel), x-pass slices kept transposed and restored by the download; odd and even depths."""
+    from pyslice_amd import _native
+    from pyslice_amd.potentials import loadKirkland, slice_edges
+    rng = np.random.default_rng(3 + nz)
+    n, dx, dz, na = 2048, 0.1, 0.5, 300
+    xs, zs = np.arange(n) * dx, np.arange(nz) * dz
+    pos = rng.random((na, 3)) * [n * dx, n * dx, nz * dz]
+    Z = rng.choice([6, 14, 79], size=na).astype(np.int32)
+    sig = orc.interaction_sigma(100e3)
+    want = np.exp(1j * sig * np.moveaxis(orc.potential(xs, xs, zs, pos, Z), 2, 0))
+    eng = _native.Engine(n, n, nz, dx, dx, dz, orc.wavelength(100e3), sig, n_probes=1, n_frames=0)
+    eng.set_kirkland(loadKirkland())
+    eng.set_slices(*slice_edges(zs))
+    eng.build_potential(pos, Z, 2)
+    got = np.asarray(eng.transmission())
+    eng.close()
+    assert np.abs(got - want).max() < 1e-5
+
+
 @pytest.mark.parametrize("nx,ny,nz,P,mode", [(1100, 1030, 3, 2, "two_waves"), (1025, 512, 2, 1, "two_waves"), (2047, 1200, 2, 1, "two_waves"),
                                              (1500, 1029, 4, 3, "two_waves"), (1100, 1030, 3, 2, "one_wave"), (1100, 1030, 2, 1, "generic")])
 def test_lengths_1025_to_2047(ps, orc, nx, ny, nz, P, mode, monkeypatch):
