@@ -70,6 +70,7 @@ struct msl_handle {
     char* scratch = nullptr;       // reductions: partial sums / masks / index lists
     size_t scratch_bytes = 0;
     bool onepass = false;
+    bool sf_quad = true;            // structure factor on the quadrant kernel (decided at msl_create: the phase tables are then n/2 + 1 columns wide)
     bool conv_form = true;          // any-length register kernels: propagation as a cyclic convolution (MSL_CHIRPZ=1: chirp-z DFTs)
     bool scheme_b = false;         // a direction of 2R^2 points: every pass transposes, first pass along y, final transpose if nz is odd
     // one-pass kernel per direction: R^2 register kernel, 2 R^2 (two) register kernel with its tables, or the generic LDS kernel
@@ -1075,8 +1076,9 @@ int ensure_atoms(msl_handle* h, size_t n) {
     if ((rc = dalloc(h, &h->d_order, cap))) return rc;
     if ((rc = dalloc(h, &h->d_u1, cap))) return rc;
     if ((rc = dalloc(h, &h->d_u2, cap))) return rc;
-    if ((rc = dalloc(h, &h->d_ex, cap * (size_t)h->cfg.nx))) return rc;
-    if ((rc = dalloc(h, &h->d_ey, cap * (size_t)h->cfg.ny))) return rc;
+    // phase tables: the quadrant kernel reads the columns 0 .. n/2 only
+    if ((rc = dalloc(h, &h->d_ex, cap * (size_t)(h->sf_quad ? h->cfg.nx / 2 + 1 : h->cfg.nx)))) return rc;
+    if ((rc = dalloc(h, &h->d_ey, cap * (size_t)(h->sf_quad ? h->cfg.ny / 2 + 1 : h->cfg.ny)))) return rc;
     h->atom_cap = cap;
     return MSL_OK;
 }
@@ -1280,6 +1282,7 @@ int msl_create(const msl_config* cfg, msl_handle** out) {
     msl_handle* h = new (std::nothrow) msl_handle();
     if (!h) return fail(nullptr, MSL_ERR_NOMEM, "msl_create: out of host memory");
     h->cfg = *cfg;
+    h->sf_quad = !getenv("MSL_NO_QUAD") && !getenv("MSL_NO_MFMA") && !getenv("MSL_NO_HERMITIAN");
     h->FB = (cfg->frame_batch > 1 && !cfg->keep_potential) ? cfg->frame_batch : 1;
     // k-window, centred on the DC pixel of the fftshifted spectrum (index n/2): [n/2 - w/2, n/2 - w/2 + w)
     h->wx = cfg->window_nx ? cfg->window_nx : cfg->nx;
@@ -1780,13 +1783,13 @@ int msl_build_potential(msl_handle* h, const double* pos, const int32_t* Z, int6
             const int* n_sorted = h->d_start + nkeys;
             recip_written = true;
             // default: matrix-core kernel over the quadrant of non-negative frequencies (any nx, ny); the older forms are A/B switches
-            const bool quad = !getenv("MSL_NO_QUAD") && !getenv("MSL_NO_MFMA") && !getenv("MSL_NO_HERMITIAN");
+            const bool quad = h->sf_quad;                   // (MSL_NO_QUAD / MSL_NO_MFMA / MSL_NO_HERMITIAN, read at msl_create)
             const int cx = quad ? c.nx / 2 + 1 : c.nx, cy = quad ? c.ny / 2 + 1 : c.ny;     // table columns the kernels read
             long long tx = (long long)n * cx, ty = (long long)n * cy;
             hipLaunchKernelGGL(phase_table_kernel, dim3((unsigned)((tx + 255) / 256)), dim3(256), 0, h->stream, h->d_ex, h->d_u1,
-                               h->d_order, n_sorted, c.nx, cx);
+                               h->d_order, n_sorted, c.nx, cx, cx);
             hipLaunchKernelGGL(phase_table_kernel, dim3((unsigned)((ty + 255) / 256)), dim3(256), 0, h->stream, h->d_ey, h->d_u2,
-                               h->d_order, n_sorted, c.ny, cy);
+                               h->d_order, n_sorted, c.ny, cy, cy);
             const int tiles_y = (c.ny + SF_TILE - 1) / SF_TILE;
             const bool hermitian = !quad && (c.nx % (2 * SF_TILE) == 0) && (c.ny % 2 == 0) && !getenv("MSL_NO_HERMITIAN");
             const int tiles_x = hermitian ? c.nx / 2 / SF_TILE : (c.nx + SF_TILE - 1) / SF_TILE;
@@ -1799,7 +1802,7 @@ int msl_build_potential(msl_handle* h, const double* pos, const int32_t* Z, int6
                 herm_t2 = t2_axes && !getenv("MSL_NO_HERM_IFFT");                   // and the 512-point register transform
                 herm_tw = tw_axes && !getenv("MSL_NO_HERM_IFFT");                   // and the 2048-point one
                 hipLaunchKernelGGL(structure_factor_quad_kernel, dim3((n_tiles + 3) / 4, c.nz), dim3(256), 0, h->stream, TR,
-                                   h->d_ex, h->d_ey, h->d_ff, h->d_start, nsp, c.nx, c.ny, qy, n_tiles, (int)n, (herm_ifft || herm_tb || herm_t2 || herm_tw) ? 0 : 1);
+                                   h->d_ex, h->d_ey, h->d_ff, h->d_start, nsp, c.nx, c.ny, qy, n_tiles, (int)n, (herm_ifft || herm_tb || herm_t2 || herm_tw) ? 0 : 1, cx, cy);
             } else if (use_mfma) {
                 const int ty32 = c.ny / 32, n_tiles = (c.nx / 2 / 32) * ty32;
                 hipLaunchKernelGGL(structure_factor_mfma_kernel, dim3((n_tiles + 3) / 4, c.nz), dim3(256), 0, h->stream, TR,

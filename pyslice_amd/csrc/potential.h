@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(1024) bin_fill_kernel(const int* __restrict__ 
 // Only the first n_cols columns of every row of n are filled (the quadrant kernel reads m <= n/2).  The reduction t - rint(t)
 // is odd in t, so the full table is exactly conjugate-symmetric: table[a][n-m] == conj(table[a][m]).
 __global__ void phase_table_kernel(float2* __restrict__ table, const double* __restrict__ u,
-                                   const int* __restrict__ order, const int* __restrict__ n_sorted_ptr, int n, int n_cols) {
+                                   const int* __restrict__ order, const int* __restrict__ n_sorted_ptr, int n, int n_cols, int pitch) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)(*n_sorted_ptr) * n_cols) return;
     int a = (int)(i / n_cols), m = (int)(i - (long long)a * n_cols);
@@ -120,7 +120,7 @@ __global__ void phase_table_kernel(float2* __restrict__ table, const double* __r
     t -= rint(t);
     float sn, cs;
     sincospif((float)(-2.0 * t), &sn, &cs);
-    table[(long long)a * n + m] = make_float2(cs, sn);
+    table[(long long)a * pitch + m] = make_float2(cs, sn);
 }
 
 // R[s][kx][ky] = sum_species ff[sp][kx][ky] * sum_{atoms of (s,sp)} ex[a][kx] * ey[a][ky]
@@ -287,7 +287,7 @@ __global__ void __launch_bounds__(256) structure_factor_quad_kernel(float2* __re
                                                                     const float* __restrict__ ff,
                                                                     const int* __restrict__ start, int n_species,
                                                                     int nx, int ny, int tiles_y, int n_tiles, int n_rows,
-                                                                    int write_mx) {
+                                                                    int write_mx, int px_pitch, int py_pitch) {
     const int s = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -308,8 +308,8 @@ __global__ void __launch_bounds__(256) structure_factor_quad_kernel(float2* __re
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int r = min(a + 2 * u, n_rows - 1);
-                x[u] = ex[(size_t)r * nx + lx];
-                y[u] = ey[(size_t)r * ny + ly];
+                x[u] = ex[(size_t)r * px_pitch + lx];
+                y[u] = ey[(size_t)r * py_pitch + ly];
             }
         };
         auto mfma16 = [&](int a, float2 (&x)[4], float2 (&y)[4]) {

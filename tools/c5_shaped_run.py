@@ -50,7 +50,7 @@ def main():
     gb = lambda n: f"{n / 1e9:.2f} GB"
     P, nz, na = len(pp), a.slices, tr.n_atoms
     print("  transmission stacks (2 orientations): " + gb(2 * nz * npix * 8))
-    print("  phase tables of the potential build  : " + gb(2 * na * a.grid * 8))
+    print("  phase tables of the potential build  : " + gb(2 * na * (a.grid // 2 + 1) * 8) + "  (columns 0 .. n/2: the quadrant kernel)")
     print("  work buffers (psi0, psi, psiT)        : " + gb(3 * P * a.grid * (a.grid + 16) * 8))
     print("  staging window + ring + accumulators : " + gb(P * 512 * 512 * 8 + P * calc._engine.n_frames * 128 * 128 * 8 + P * a.frames * 128 * 128 * 12))
     print(f"  the reference's layout for the same run (P,T,nx,ny) complex128: {gb(P * a.frames * npix * 16)}; "
