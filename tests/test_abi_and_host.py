@@ -145,3 +145,28 @@ def test_m0_is_only_touched_by_the_addtid_exchange(tmp_path):
         assert lines[i].startswith("s_mov_b32 m0,"), lines[i]
         assert lines[i + 1].startswith("s_nop"), (lines[i], lines[i + 1])
     assert sum(l.startswith("ds_write_addtid_b32") for l in lines) > 0
+    # the kernels the default paths launch neither spill nor fall below two waves per SIMD (the kernels kept for A/B runs --
+    # rowTC_pass_kernel, rowT2_pass_kernel<32>, ifftT2_kernel<32>, the generic line kernels -- are known to spill and are listed
+    # in DESIGN.md)
+    text = "\n".join(lines)
+    shipped = ["rowT_pass_kernelILi32ELi16ELi4E", "rowT_pass_kernelILi16ELi16ELi4E", "rowT2_pass_kernelILi16E", "rowTW_pass_kernelILb1ELb1E",
+               "rowTB_pass_kernelILi32ELb1E", "rowTB_pass_kernelILi16ELb1E", "rowTB2_pass_kernelILb0ELb0ELb1E", "rowTC2_pass_kernel",
+               "ifftTB_kernelILi32E", "ifftTB_kernelILi16E", "ifftTB2_kernel", "ifftTW_kernel", "ifftT2_kernelILi16E",
+               "structure_factor_quad_kernel", "col_pass_kernelILi32ELi16ELb1E", "col_pass_kernelILi16ELi32ELb0E"]
+    for name in shipped:
+        m = re.search(r"\.amdhsa_kernel (_ZN3msl\d+" + re.escape(name) + r"\S*)(.*?)\.end_amdhsa_kernel", text, re.S)
+        assert m, name
+        body = m.group(2)
+        scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1))
+        vgpr = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1))
+        assert scratch == 0, (name, scratch)
+        assert vgpr <= 256, (name, vgpr)
+
+
+def test_default_frame_batch_rule():
+    from pyslice_amd.calculators import default_frame_batch
+    assert default_frame_batch(64, 200, 1024, 1024) == 4          # C3: about 256 images per launch
+    assert default_frame_batch(1, 100, 512, 512) == 32            # C2: 16 GB of transmission stacks bound it (38 -> a multiple of 16)
+    assert default_frame_batch(1, 50, 256, 256) == 256            # C1
+    assert default_frame_batch(16, 400, 2048, 2048) == 1          # C5: one frame's stacks are 27 GB
+    assert default_frame_batch(300, 10, 64, 64) == 1
