@@ -39,6 +39,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
+EXIT_EXCHANGE_STALLED = 3 # exit code when the end-of-run exchanges (or the final barrier) of an N > 1 run hung: line printed, run failed
 TACAW_T = 256             # BASELINE C3's frame count; the four-step time-FFT kernel serves T = 256 and 1024
 
 
@@ -62,6 +63,8 @@ def parse():
     ap.add_argument("--cpu-slices", type=int, default=100,
                     help="slices of the bounded CPU sample (100 of 200 at 1024^2: about 12 s of single-thread work)")
     ap.add_argument("--no-tacaw", action="store_true", help="skip the TACAW time->frequency FFT leg (N=1)")
+    ap.add_argument("--tacaw-frames", type=int, default=TACAW_T,
+                    help="frame slots of the TACAW leg (default 256 = BASELINE C3; 100 = the reference notebook's run)")
     ap.add_argument("--no-exchange", action="store_true", help="skip the end-of-run exchange timing (N>1)")
     ap.add_argument("--no-launch-timing", action="store_true",
                     help="run the library as production does (no per-launch HIP events, frames queue asynchronously); "
@@ -224,8 +227,8 @@ def run(a):
     tacaw_T = None
     if world == 1 and not a.no_tacaw and n_local >= 2:
         free_b, _ = torch.cuda.mem_get_info(local_rank)
-        want = max(TACAW_T, n_local)
-        if 12.0 * P * want * npix + 24e9 < free_b and n_local <= TACAW_T:
+        want = max(a.tacaw_frames, n_local)
+        if 12.0 * P * want * npix + 24e9 < free_b and n_local <= a.tacaw_frames:
             slots, tacaw_T = want, want
         else:
             tacaw_T = n_local
@@ -299,7 +302,7 @@ def run(a):
         eng.tacaw()
         ms = eng.counters()["ms_tacaw"] - before
         tacaw = {"ms": round(ms, 3), "GBps": round(12.0 * P * tacaw_T * npix / (ms * 1e-3) / 1e9, 1), "frames": tacaw_T,
-                 "probes": P, "kernel": "four-step time FFT" if tacaw_T in (256, 1024) else "generic LDS kernel",
+                 "probes": P, "kernel": "four-step time FFT" if tacaw_T in (256, 1024) else ("chirp-z on the register FFTs" if tacaw_T <= 512 else "generic LDS kernel"),
                  "algorithmic_bytes": 12.0 * P * tacaw_T * npix, "frac_of_hbm_peak": round(12.0 * P * tacaw_T * npix / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                  "note": f"{n_local} computed frames, remaining slots filled with copies (timing is data-independent)"}
 
@@ -365,10 +368,16 @@ def run(a):
             tpath = os.path.join(REPO, "profiles", "pmc_traffic_current.json")
             if os.path.exists(tpath):
                 tj = json.load(open(tpath))
+                sys.path.insert(0, os.path.join(REPO, "tools"))
+                from update_traffic import csrc_sha256
                 if (tj.get("grid") == n and tj.get("probes") == P and tj.get("frame_batch", 1) == eng.frame_batch
                         and round(passes_per_slice) == tj.get("passes_per_slice")):
-                    traffic = tj.get("hbm_bytes_per_launch")
-                    tsrc = "profiles/pmc_traffic_current.json (rocprofv3 --pmc passes of this command, committed; not re-measured in this run)"
+                    if tj.get("csrc_sha256") == csrc_sha256():
+                        traffic = tj.get("hbm_bytes_per_launch")
+                        tsrc = (f"profiles/pmc_traffic_current.json: rocprofv3 --pmc passes of this command on these very kernel sources "
+                                f"(sha256 {tj['csrc_sha256'][:12]}, kernel {tj.get('kernel')}); committed, not re-measured in this run")
+                    else:
+                        tsrc = "profiles/pmc_traffic_current.json is stale (kernel sources changed since the counters were taken): traffic withheld"
             loop_32 = (32.0 * npix * P * nz * frames_timed_local / (ctr["ms_slice_kernels"] * 1e-3) / 1e9) if ctr["ms_slice_kernels"] else None
             roof = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
@@ -410,28 +419,36 @@ def run(a):
         # `--exchange-timeout` seconds and rank 0 still prints the line, with the failure recorded instead of the timings.
         import threading
         finished = threading.Event()
+        emit = threading.Lock()             # the line is printed once, by whoever gets here first
 
         def watchdog():
             if not finished.wait(a.exchange_timeout):
-                if rank == 0:
-                    out["exchange_ms"] = {"error": f"end-of-run exchanges did not finish within {a.exchange_timeout} s"}
-                    print(json.dumps(out), flush=True)
-                os._exit(0)
+                with emit:
+                    if finished.is_set():                # the exchanges came in at the last moment: the main thread has the line
+                        return
+                    if rank == 0:
+                        out["exchange_ms"] = {"error": f"end-of-run exchanges did not finish within {a.exchange_timeout} s"}
+                        print(json.dumps(out), flush=True)
+                    else:
+                        time.sleep(2.0)                  # rank 0 prints first: the launcher ends the job at the first failing rank
+                    os._exit(EXIT_EXCHANGE_STALLED)      # the measurement is out, but the run did NOT end well: callers must see it
         threading.Thread(target=watchdog, daemon=True).start()
         try:
             ex = run_exchange()
         except Exception as exc:                     # a failing exchange must not cost the measured line
             ex = {"error": repr(exc)}
-        finished.set()
-        if rank == 0:
-            out["exchange_ms"] = ex
-    if rank == 0:
+        with emit:
+            finished.set()
+            if rank == 0:
+                out["exchange_ms"] = ex
+                print(json.dumps(out), flush=True)
+    elif rank == 0:
         print(json.dumps(out), flush=True)
     del wf_view
     eng.close()
     if world > 1:
         import threading
-        t = threading.Timer(60.0, lambda: os._exit(0))      # the line is out: a peer that died must not keep this rank in the barrier
+        t = threading.Timer(60.0, lambda: os._exit(EXIT_EXCHANGE_STALLED))      # the line is out: a peer that died must not keep this rank in the barrier
         t.daemon = True
         t.start()
         try:

@@ -79,7 +79,13 @@ typedef enum {
     MSL_BUF_TRANSMISSION = 3,  /* (nz,nx,ny) c64    exp(i sigma V)                           */
     MSL_BUF_WAVEFUNCTION = 4,  /* (P,T_local,wx,wy) c64  fftshift(fft2(exit)) per frame slot (wx,wy = nx,ny or the k-window) */
     MSL_BUF_INTENSITY = 5,     /* (P,T,wx,wy) f32   TACAW |FFT_t|^2 of the last msl_tacaw    */
-    MSL_BUF_FORMFACTOR = 6     /* (n_species,nx,ny) f32 Kirkland f_Z(q^2) of the last potential build */
+    MSL_BUF_FORMFACTOR = 6,    /* (n_species,nx,ny) f32 Kirkland f_Z(q^2) of the last potential build */
+    /* streaming TACAW, while a stream is open (msl_tacaw_stream_begin .. _finish): the partial sums of this handle, for the
+     * caller's collective when the frames of a run are sharded over several handles / processes (msl_device_ptr only) */
+    MSL_BUF_STREAM_ACC = 7,    /* (P,n_bins,K) c64  sum_t (Psi[p,t,k] - ref[p,k]) exp(-2 pi i u t / T) over the frames pushed so far */
+    MSL_BUF_STREAM_S1 = 8,     /* (P,K) 2 x f64     sum_t Psi */
+    MSL_BUF_STREAM_S2 = 9,     /* (P,K) f64         sum_t |Psi|^2 */
+    MSL_BUF_STREAM_REF = 10    /* (P,K) c64         the reference pattern (msl_tacaw_stream_set_reference), NULL when none is set */
 } msl_buffer;
 
 typedef struct {
@@ -189,6 +195,19 @@ int  msl_tacaw(msl_handle* h, const void* d_src_c64, void* d_dst_f32, int64_t ba
 int  msl_tacaw_stream_begin(msl_handle* h, int32_t T_total, int32_t n_bins, const int32_t* bins);
 int  msl_tacaw_stream_push(msl_handle* h, int32_t first_slot, int32_t count, int32_t t0);
 int  msl_tacaw_stream_finish(msl_handle* h, double* total_PK);
+/* Reference pattern of an open stream: every frame pushed afterwards is folded as Psi[p,t,k] - ref[p,k].  A time-independent
+ * offset only changes the u = 0 bin, which the reference's mean subtraction (tacaw_data.py:94) zeroes anyway, so the result is
+ * unchanged -- but the float32 accumulators then hold the thermal part instead of T Bragg amplitudes that have to cancel.
+ * d_ref_c64: device (P,K) c64, or NULL to take frame slot `slot` of this handle's ring.  Call it before the first push; all
+ * handles that share one run (frame shards) must use the SAME reference (MSL_BUF_STREAM_REF gives the pointer to broadcast). */
+int  msl_tacaw_stream_set_reference(msl_handle* h, const void* d_ref_c64, int32_t slot);
+/* Frame-sharded runs (one handle per GPU, each pushing its own frames with their global time indices t0): the partial sums
+ * MSL_BUF_STREAM_ACC / _S1 / _S2 are linear in the frames, so the caller sum-reduces them over the handles (RCCL
+ * reduce-scatter over probes: pyslice_amd/distributed.py) into the probe range [p0, p0+count) of THIS handle's buffers and
+ * then finishes that range only: intensity (count, n_bins, K) f32 into d_dst_f32 (device; NULL only for the full range, which
+ * goes to the handle's intensity buffer like msl_tacaw_stream_finish), total_host (count*K f64, may be NULL).  Closes the stream.
+ * Replaces, together with the pushes, TACAWData.fft_from_wf_data on the (P,T,nx,ny) array no rank holds (tacaw_data.py:89-104). */
+int  msl_tacaw_stream_finish_range(msl_handle* h, int32_t p0, int32_t count, void* d_dst_f32, double* total_host);
 
 /* ---- consumers of the resident results: reductions that stream the array once on the device ----
  * The TACAW reductions take a (B,F,K) float32 intensity array: d_src == NULL selects the handle's own intensity buffer
@@ -199,6 +218,9 @@ int  msl_tacaw_stream_finish(msl_handle* h, double* total_PK);
  *   Replaces the k-space sums of TACAWData.spectrum (tacaw_data.py:109-143), spectrum_image (:145-179) and
  *   masked_spectrum (:256-300); the mean over probes / the frequency pick is a lookup in the (B,F) result. */
 int  msl_tacaw_spectrum(msl_handle* h, const void* d_src_f32, int64_t B, int64_t F, int64_t K, const uint8_t* mask, double* out);
+/* msl_tacaw_spectrum_weighted: out[b*F+f] = sum_k weight[k] I[b,f,k] with K float64 host weights: a non-boolean mask of
+ *   TACAWData.masked_spectrum, which multiplies the intensity (tacaw_data.py:286-296). */
+int  msl_tacaw_spectrum_weighted(msl_handle* h, const void* d_src_f32, int64_t B, int64_t F, int64_t K, const double* weight, double* out);
 /* msl_tacaw_diffraction: out[k] = scale * sum_{b0<=b<b1} sum_{f0<=f<f1} I[b,f,k]   (K float64).
  *   Replaces TACAWData.diffraction (tacaw_data.py:183-217: all f, one probe or scale=1/P over all probes) and
  *   spectral_diffraction (:219-254: one f). */

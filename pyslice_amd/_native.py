@@ -14,7 +14,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MSL_LIB") or os.path.join(_HERE, "libmslice.so")
 
 MSL_OK, MSL_ERR_INVALID, MSL_ERR_HIP, MSL_ERR_UNSUPPORTED, MSL_ERR_STATE, MSL_ERR_NOMEM = 0, -1, -2, -3, -4, -5
-(BUF_PROBES, BUF_EXIT, BUF_POTENTIAL, BUF_TRANSMISSION, BUF_WAVEFUNCTION, BUF_INTENSITY, BUF_FORMFACTOR) = range(7)
+(BUF_PROBES, BUF_EXIT, BUF_POTENTIAL, BUF_TRANSMISSION, BUF_WAVEFUNCTION, BUF_INTENSITY, BUF_FORMFACTOR,
+ BUF_STREAM_ACC, BUF_STREAM_S1, BUF_STREAM_S2, BUF_STREAM_REF) = range(11)
 
 EXPORTS = [
     "msl_abi_version", "msl_last_error", "msl_create", "msl_destroy", "msl_set_kirkland", "msl_set_slices",
@@ -23,9 +24,10 @@ EXPORTS = [
     "msl_download", "msl_download_frame", "msl_upload_frame", "msl_buffer_bytes", "msl_device_ptr", "msl_synchronize",
     "msl_get_counters",
     "msl_reset_counters", "msl_fft2_host",
-    "msl_tacaw_spectrum", "msl_tacaw_diffraction", "msl_tacaw_dispersion", "msl_adf",
+    "msl_tacaw_spectrum", "msl_tacaw_spectrum_weighted", "msl_tacaw_diffraction", "msl_tacaw_dispersion", "msl_adf",
     "msl_select_batch_slot", "msl_propagate_frames", "msl_frame_batch",
     "msl_tacaw_stream_begin", "msl_tacaw_stream_push", "msl_tacaw_stream_finish",
+    "msl_tacaw_stream_set_reference", "msl_tacaw_stream_finish_range",
 ]
 
 
@@ -89,6 +91,7 @@ def load():
         "msl_reset_counters": (C.c_int, [vp]),
         "msl_fft2_host": (C.c_int, [vp, vp, vp, i32, i32]),
         "msl_tacaw_spectrum": (C.c_int, [vp, vp, i64, i64, i64, vp, vp]),
+        "msl_tacaw_spectrum_weighted": (C.c_int, [vp, vp, i64, i64, i64, vp, vp]),
         "msl_tacaw_diffraction": (C.c_int, [vp, vp, i64, i64, i64, i64, i64, i64, i64, dbl, vp]),
         "msl_tacaw_dispersion": (C.c_int, [vp, vp, i64, i64, i64, vp, i64, vp]),
         "msl_adf": (C.c_int, [vp, vp, i64, i64, i64, vp, vp]),
@@ -98,6 +101,8 @@ def load():
         "msl_tacaw_stream_begin": (C.c_int, [vp, i32, i32, vp]),
         "msl_tacaw_stream_push": (C.c_int, [vp, i32, i32, i32]),
         "msl_tacaw_stream_finish": (C.c_int, [vp, vp]),
+        "msl_tacaw_stream_set_reference": (C.c_int, [vp, vp, i32]),
+        "msl_tacaw_stream_finish_range": (C.c_int, [vp, i32, i32, vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -256,6 +261,19 @@ class Engine:
     def tacaw_stream_push(self, first_slot, count, t0):
         self._chk(self._lib.msl_tacaw_stream_push(self._h, int(first_slot), int(count), int(t0)))
 
+    def tacaw_stream_set_reference(self, slot=0, ref_ptr=None):
+        """frames pushed afterwards are folded as Psi - ref: ref = frame slot `slot` of the ring, or a device (P,K) c64 array"""
+        self._chk(self._lib.msl_tacaw_stream_set_reference(self._h, C.c_void_p(int(ref_ptr)) if ref_ptr else None, int(slot)))
+
+    def tacaw_stream_finish_range(self, p0, count, dst_ptr, want_total=True):
+        """finish the probes [p0, p0+count) only (frame-sharded runs after the reduce): intensity (count, n_bins, K) f32 into the
+        device array at dst_ptr; -> (count, wx, wy) float64 total over all bins (or None)"""
+        tot = np.empty((int(count), self.wx, self.wy), dtype=np.float64) if want_total else None
+        self._chk(self._lib.msl_tacaw_stream_finish_range(self._h, int(p0), int(count), C.c_void_p(int(dst_ptr)) if dst_ptr else None,
+                                                          _ptr(tot) if tot is not None and tot.size else None))
+        self.intensity_F = self._stream_F
+        return tot
+
     def tacaw_stream_finish(self, want_total=True):
         """-> (P, wx, wy) float64: sum over ALL frequency bins of the intensity (or None); the selected bins become the
         resident intensity buffer (P, n_bins, wx, wy)"""
@@ -286,6 +304,17 @@ class Engine:
         out = np.empty((B, F), dtype=np.float64)
         p, b, f, k = self._src(src)
         self._chk(self._lib.msl_tacaw_spectrum(self._h, p, b, f, k, _ptr(m) if m is not None else None, _ptr(out)))
+        return out
+
+    def tacaw_spectrum_weighted(self, weight, src=None):
+        """(B,F) float64: sum over k of weight[k] * intensity (any float mask)."""
+        B, F, K = self._bfk(src)
+        w = np.ascontiguousarray(np.asarray(weight, dtype=np.float64).reshape(-1))
+        if w.size != K:
+            raise ValueError(f"mask has {w.size} entries, k-space has {K}")
+        out = np.empty((B, F), dtype=np.float64)
+        p, b, f, k = self._src(src)
+        self._chk(self._lib.msl_tacaw_spectrum_weighted(self._h, p, b, f, k, _ptr(w), _ptr(out)))
         return out
 
     def tacaw_diffraction(self, probes=None, freqs=None, scale=1.0, src=None):

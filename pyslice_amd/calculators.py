@@ -186,8 +186,6 @@ class MultisliceCalculator:
         batch = 1 if self._cache else max(1, min(batch, len(self._frames)))
         slots = max(1, len(self._frames))
         if self._stream_tile is not None:
-            if self._world > 1:
-                raise NotImplementedError("streaming TACAW runs in one process (shard probes over processes instead)")
             slots = max(1, min(self._stream_tile, slots))
             batch = min(batch, slots)
         if self._k_bin is not None:
@@ -319,8 +317,13 @@ class MultisliceCalculator:
         t0 = time.time()
         eng.tacaw_stream_begin(T, unshifted)
         ring, B = eng.n_frames, eng.frame_batch
-        for tile0 in range(0, T, ring):
-            tile = list(range(tile0, min(T, tile0 + ring)))
+        # This rank's MD frames (all of them in a single-process run): propagated through the ring tile by tile and folded with
+        # their GLOBAL time indices.  The first frame of the run is the reference pattern every rank subtracts before folding
+        # (msl_tacaw_stream_set_reference): rank 0 takes it from its first tile and broadcasts it (P x stored pixels, once).
+        frames = self._frames
+        have_ref = False
+        for tile0 in range(0, max(len(frames), 1), ring):
+            tile = frames[tile0:tile0 + ring]
             for s0 in range(0, len(tile), B):
                 chunk = tile[s0:s0 + B]
                 if B > 1:
@@ -331,15 +334,24 @@ class MultisliceCalculator:
                 else:
                     eng.build_potential(self.trajectory.positions[chunk[0]], self._Z, self.slice_axis)
                     eng.propagate_frame(s0)
-            eng.tacaw_stream_push(0, len(tile), tile0)
-        total = eng.tacaw_stream_finish(True)
-        self.elapsed = time.time() - t0
+            if not have_ref:
+                self._stream_reference(eng)
+                have_ref = True
+            if tile:
+                eng.tacaw_stream_push(0, len(tile), tile[0])
         kxs, kys = self._k_axes()
         tac = TACAWData.__new__(TACAWData)
         tac.__dict__.update(dict(probe_positions=self.probe_positions, time=time_array, kxs=_as_tensor(kxs), kys=_as_tensor(kys),
                                  layer=np.array([0]), wavefunction_data=None, probe=self.base_probe,
-                                 frequencies=freqs[sel], frequency_bins=sel, total_diffraction=total,
-                                 _engine=eng, _intensity_src=(eng, None), _output=self._output))
+                                 frequencies=freqs[sel], frequency_bins=sel, _engine=eng, _output=self._output))
+        if self._world > 1:
+            self._finish_stream_sharded(eng, tac)
+            self.elapsed = time.time() - t0
+            return tac
+        total = eng.tacaw_stream_finish(True)
+        self.elapsed = time.time() - t0
+        tac.total_diffraction = total
+        tac._intensity_src = (eng, None)
         if self._output == "device":
             ptr = eng.device_ptr(_native.BUF_INTENSITY)
             tac.intensity = torch.as_tensor(_native.DeviceArray(ptr, (eng.n_probes, eng.intensity_F, eng.wx, eng.wy), "<f4", owner=eng),
@@ -347,6 +359,56 @@ class MultisliceCalculator:
         else:
             tac.intensity = _as_tensor(eng.intensity().astype(np.float64))
         return tac
+
+    def _stream_reference(self, eng):
+        """the run's first frame (frame slot 0 of rank 0's first tile) becomes the reference pattern of every rank's fold"""
+        if self._world == 1:
+            eng.tacaw_stream_set_reference(slot=0)
+            return
+        dev = torch.device("cuda", eng.device)
+        P, K = eng.n_probes, eng.wx * eng.wy
+        if self._rank == 0:
+            eng.tacaw_stream_set_reference(slot=0)
+            eng.synchronize()
+            ref = torch.as_tensor(_native.DeviceArray(eng.device_ptr(_native.BUF_STREAM_REF), (P, K), "<c8", owner=eng), device=dev)
+            distributed.broadcast_from(ref, src=0)
+        else:
+            ref = torch.empty((P, K), dtype=torch.complex64, device=dev)
+            distributed.broadcast_from(ref, src=0)
+            torch.cuda.synchronize(dev)
+            eng.tacaw_stream_set_reference(ref_ptr=ref.data_ptr())
+            eng.synchronize()                     # the copy out of `ref` is done before the tensor goes away
+
+    def _finish_stream_sharded(self, eng, tac):
+        """Frame-sharded streaming TACAW: sum the ranks' partial sums (reduce-scatter over probes, distributed.reduce_probes),
+        finish this rank's probes, gather the intensities (distributed.gather_probes).  tacaw_data.py:89-104 on an array no
+        rank ever holds."""
+        dev = torch.device("cuda", eng.device)
+        P, F, K = eng.n_probes, len(tac.frequency_bins), eng.wx * eng.wy
+        eng.synchronize()
+
+        def view(what, shape, typestr):
+            return torch.as_tensor(_native.DeviceArray(eng.device_ptr(what), shape, typestr, owner=eng), device=dev)
+        p0, p1 = distributed.reduce_probes(view(_native.BUF_STREAM_ACC, (P, F, K), "<c8"), P)
+        distributed.reduce_probes(view(_native.BUF_STREAM_S1, (P, K, 2), "<f8"), P)
+        distributed.reduce_probes(view(_native.BUF_STREAM_S2, (P, K), "<f8"), P)
+        torch.cuda.synchronize(dev)
+        mine = torch.empty((p1 - p0, F, eng.wx, eng.wy), dtype=torch.float32, device=dev)
+        total = eng.tacaw_stream_finish_range(p0, p1 - p0, mine.data_ptr(), True)       # (an empty shard still closes the stream)
+        tot = torch.from_numpy(total).to(dev)
+        tac.probe_range = (p0, p1)
+        if self._gather == "none":
+            full, tot_full = mine, tot
+        else:
+            dst = None if self._gather == "all" else 0
+            full = distributed.gather_probes(mine, P, dst=dst)
+            tot_full = distributed.gather_probes(tot, P, dst=dst)
+        if full is None:
+            tac.intensity, tac.total_diffraction = None, None
+            return
+        tac._intensity_src = (eng, full)
+        tac.total_diffraction = tot_full.cpu().numpy()
+        tac.intensity = full if self._output == "device" else full.to(torch.float64).cpu()
 
     # ------------------------------------------------------------------------------------------
     def _collect(self):

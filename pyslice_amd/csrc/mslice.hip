@@ -17,6 +17,7 @@
 #include "potential.h"
 #include "reduce.h"
 #include "stream.h"
+#include "tacaw_time.h"
 
 using namespace msl;
 
@@ -65,6 +66,7 @@ struct msl_handle {
     float2* bin_stage = nullptr;   // binning: full-resolution window of the frames of one launch sequence, (FB*P, wx, wy)
     // streaming TACAW
     float2* st_acc = nullptr; double2* st_s1 = nullptr; double* st_s2 = nullptr; float2* st_tw = nullptr; int* st_bins = nullptr;
+    float2* st_ref = nullptr; bool st_have_ref = false;      // reference pattern subtracted before folding (msl_tacaw_stream_set_reference)
     int st_T = 0, st_F = 0; bool st_open = false;
     int64_t intensity_F = 0;       // frequency bins of the resident intensity buffer (T after msl_tacaw, n_bins after a stream)
     char* scratch = nullptr;       // reductions: partial sums / masks / index lists
@@ -81,6 +83,8 @@ struct msl_handle {
         // only the potential's inverse transform uses them (ifftTB_kernel / ifftTB2_kernel).  cz_R: 16 / 32 (M = R^2) or 64 (the 2048-point wave FFT)
         int cz_R = 0; float2* cz_tw = nullptr; float2* cz_tw2 = nullptr; float2* cz_bf = nullptr; float2* cz_bw = nullptr;
                    float2* ptab = nullptr; float2* bf = nullptr; float2* bw = nullptr; } opx, opy;
+    OpDir opt;                     // chirp-z tables of the TACAW time axis (cz_* only), made for opt_T frames (time_cz_kernel)
+    int opt_T = 0;
     float2* psiT = nullptr;
     float2* psi0T = nullptr;
     bool need_psi0T = false;
@@ -1549,10 +1553,10 @@ int msl_destroy(msl_handle* h) {
     void* bufs[] = {h->psi0, h->psi, h->trans, h->V, h->wf, h->intensity, h->pxt, h->pyt, h->d_abcd, h->d_lo, h->d_hi,
                     h->d_pos, h->d_Z, h->d_key, h->d_order, h->d_u1, h->d_u2, h->d_ex, h->d_ey, h->d_counts, h->d_start,
                     h->d_z2s, h->d_species, h->d_ff, h->d_xy, h->plan_x.tw, h->plan_y.tw, h->plan_t.tw, h->tw4_x, h->tw4_y,
-                    h->scratch, h->psiT, h->psi0T, h->transT, h->bin_stage, h->st_acc, h->st_s1, h->st_s2, h->st_tw, h->st_bins, h->opx.tw2, h->opx.ptab, h->opy.tw2, h->opy.ptab,
+                    h->scratch, h->psiT, h->psi0T, h->transT, h->bin_stage, h->st_acc, h->st_s1, h->st_s2, h->st_tw, h->st_bins, h->st_ref, h->opx.tw2, h->opx.ptab, h->opy.tw2, h->opy.ptab,
                     ((h->opx.two || h->opx.breg || h->opx.breg2 || h->opx.breg4 || h->opx.wave2k) ? h->opx.tw : nullptr), ((h->opy.two || h->opy.breg || h->opy.breg2 || h->opy.breg4 || h->opy.wave2k) ? h->opy.tw : nullptr),
                     h->opx.bf, h->opx.bw, h->opy.bf, h->opy.bw, h->opx.qf, h->opy.qf, h->opx.cz_tw, h->opx.cz_tw2, h->opx.cz_bf, h->opx.cz_bw,
-                    h->opy.cz_tw, h->opy.cz_tw2, h->opy.cz_bf, h->opy.cz_bw, h->plan_x.chirp, h->plan_x.bfilt, h->plan_y.chirp, h->plan_y.bfilt, h->plan_t.chirp, h->plan_t.bfilt};
+                    h->opy.cz_tw, h->opy.cz_tw2, h->opy.cz_bf, h->opy.cz_bw, h->opt.cz_tw, h->opt.cz_tw2, h->opt.cz_bf, h->opt.cz_bw, h->plan_x.chirp, h->plan_x.bfilt, h->plan_y.chirp, h->plan_y.bfilt, h->plan_t.chirp, h->plan_t.bfilt};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -2073,10 +2077,34 @@ int msl_tacaw(msl_handle* h, const void* d_src, void* d_dst, int64_t batch, int3
     if (npix > 0x7fffffffLL) return fail(h, MSL_ERR_UNSUPPORTED, "msl_tacaw: npix too large");
     const int Rt = (c.fft_path == 0) ? fast_radix(T) : 0;           // 256 or 1024 frames: four-step column kernel
     const bool fast_t = Rt && (npix % 16 == 0) && npix >= 32 && !getenv("MSL_TACAW_GENERIC");
+    // any other frame count up to 512: chirp-z on the register FFTs (time_cz_kernel), 32-pixel tiles for T <= 128, else 16
+    const bool cz_t = !fast_t && c.fft_path == 0 && T <= 512 && (npix % 16 == 0) && !getenv("MSL_TACAW_GENERIC");
     int rc = MSL_OK;
     float2* tw4_t = nullptr;
     if (fast_t) {
         if ((rc = make_tw4(h, &tw4_t, Rt))) return rc;
+    } else if (cz_t) {
+        if (h->opt_T != T) {
+            h->opt_T = 0;
+            if ((rc = make_cz_tables(h, h->opt, T < 33 ? 33 : T))) return rc;       // (the table builder's R rule starts at 33 points)
+            if (T < 33) {                                                             // chirp of the real T: redo the two T-dependent tables
+                const int M = 256, NH = 128;
+                std::vector<float2> bw(NH, make_float2(0.f, 0.f)), bf(NH + 2, make_float2(0.f, 0.f));
+                std::vector<double> cr(M, 0.0), ci(M, 0.0);
+                for (int i = 0; i < T; ++i) {
+                    const long long q = ((long long)i * i) % (2LL * T);
+                    const double a = -M_PI * (double)q / (double)T;
+                    bw[i] = make_float2((float)cos(a), (float)sin(a));
+                    cr[i] = cos(a); ci[i] = -sin(a);
+                    if (i) { cr[M - i] = cr[i]; ci[M - i] = ci[i]; }
+                }
+                host_fft_pow2(cr, ci);
+                for (int j = 0; j <= NH; ++j) bf[j] = make_float2((float)(cr[j] / M), (float)(ci[j] / M));
+                HIPCHK(h, hipMemcpy(h->opt.cz_bw, bw.data(), NH * sizeof(float2), hipMemcpyHostToDevice));
+                HIPCHK(h, hipMemcpy(h->opt.cz_bf, bf.data(), (NH + 2) * sizeof(float2), hipMemcpyHostToDevice));
+            }
+            h->opt_T = T;
+        }
     } else if ((rc = make_plan(h, h->plan_t, T))) {
         return rc;
     }
@@ -2100,6 +2128,26 @@ int msl_tacaw(msl_handle* h, const void* d_src, void* d_dst, int64_t batch, int3
             h->Rx = saved;
         }
         if (rc) { (void)hipFree(tw4_t); return rc; }
+    } else if (cz_t) {
+        TimeJob j{};
+        j.in = src; j.out = dst; j.tw = h->opt.cz_tw; j.bf = h->opt.cz_bf; j.bw = h->opt.cz_bw;
+        j.image_stride = (long long)T * npix; j.npix = (int)npix; j.n_images = (int)batch; j.T = T;
+        auto launch = [&](auto r_c, auto cols_c) -> int {
+            constexpr int R = decltype(r_c)::value, COLS = decltype(cols_c)::value;
+            constexpr int M = R * R, NH = M / 2, CS = R * (R + 1) + 2;
+            const size_t lds = ((size_t)M + NH + 2 + NH + (size_t)COLS * CS) * 8;
+            const long long tiles = (npix / COLS) * batch;
+            const int per_cu = std::max(1, std::min(2, (int)((size_t)h->lds_limit / lds)));
+            const int grid = (int)std::min<long long>(tiles, (long long)h->n_cus * per_cu);
+            (void)hipFuncSetAttribute((const void*)time_cz_kernel<R, COLS>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
+            hipLaunchKernelGGL((time_cz_kernel<R, COLS>), dim3(grid), dim3(COLS * R), lds, h->stream, j);
+            HIPCHK(h, hipGetLastError());
+            return mark_launch(h, K_OTHER);
+        };
+        if (h->opt.cz_R == 16) rc = (npix % 32 == 0) ? launch(std::integral_constant<int, 16>{}, std::integral_constant<int, 32>{})
+                                                     : launch(std::integral_constant<int, 16>{}, std::integral_constant<int, 16>{});
+        else rc = launch(std::integral_constant<int, 32>{}, std::integral_constant<int, 16>{});
+        if (rc) return rc;
     } else {
         LineArgs a;
         a.in = src; a.out = nullptr; a.out_real = dst;
@@ -2148,7 +2196,28 @@ int msl_tacaw_stream_begin(msl_handle* h, int32_t T_total, int32_t n_bins, const
     HIPCHK(h, hipMemsetAsync(h->st_s1, 0, PK * sizeof(double2), h->stream));
     HIPCHK(h, hipMemsetAsync(h->st_s2, 0, PK * sizeof(double), h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));            // the host vectors go out of scope
-    h->st_T = T_total; h->st_F = n_bins; h->st_open = true;
+    h->st_T = T_total; h->st_F = n_bins; h->st_open = true; h->st_have_ref = false;
+    return MSL_OK;
+}
+
+int msl_tacaw_stream_set_reference(msl_handle* h, const void* d_ref_c64, int32_t slot) {
+    if (!h) return fail(h, MSL_ERR_INVALID, "null handle");
+    if (!h->st_open) return fail(h, MSL_ERR_STATE, "msl_tacaw_stream_set_reference: no open stream (msl_tacaw_stream_begin)");
+    const msl_config& c = h->cfg;
+    if (!d_ref_c64 && (slot < 0 || slot >= c.n_frames))
+        return fail(h, MSL_ERR_INVALID, "msl_tacaw_stream_set_reference: slot %d outside the ring of %d", slot, c.n_frames);
+    HIPCHK(h, hipSetDevice(c.device));
+    const size_t K = h->wpix;
+    int rc;
+    if (!h->st_ref && (rc = dalloc(h, &h->st_ref, (size_t)c.n_probes * K))) return rc;
+    if (d_ref_c64) {
+        HIPCHK(h, hipMemcpyAsync(h->st_ref, d_ref_c64, (size_t)c.n_probes * K * sizeof(float2), hipMemcpyDeviceToDevice, h->stream));
+    } else {
+        // frame slot `slot` of the (P, ring, K) buffer: P strided images
+        HIPCHK(h, hipMemcpy2DAsync(h->st_ref, K * sizeof(float2), h->wf + (size_t)slot * K, (size_t)c.n_frames * K * sizeof(float2),
+                                   K * sizeof(float2), c.n_probes, hipMemcpyDeviceToDevice, h->stream));
+    }
+    h->st_have_ref = true;
     return MSL_OK;
 }
 
@@ -2162,6 +2231,7 @@ int msl_tacaw_stream_push(msl_handle* h, int32_t first_slot, int32_t count, int3
     HIPCHK(h, hipSetDevice(c.device));
     FoldJob j{};
     j.wf = h->wf; j.acc = h->st_acc; j.s1 = h->st_s1; j.s2 = h->st_s2; j.tw = h->st_tw; j.bins = h->st_bins;
+    j.ref = h->st_have_ref ? h->st_ref : nullptr;
     j.K = (long long)h->wpix; j.ring = c.n_frames; j.first_slot = first_slot; j.count = count; j.t0 = t0; j.T = h->st_T; j.F = h->st_F;
     const dim3 grid((unsigned)((h->wpix + 255) / 256), c.n_probes);
     for (int f0 = 0; f0 < h->st_F; f0 += MSL_FOLD_FCH) {
@@ -2172,32 +2242,47 @@ int msl_tacaw_stream_push(msl_handle* h, int32_t first_slot, int32_t count, int3
     return MSL_OK;
 }
 
-int msl_tacaw_stream_finish(msl_handle* h, double* total_PK) {
+int msl_tacaw_stream_finish_range(msl_handle* h, int32_t p0, int32_t count, void* d_dst_f32, double* total_host) {
     if (!h) return fail(h, MSL_ERR_INVALID, "null handle");
     if (!h->st_open) return fail(h, MSL_ERR_STATE, "msl_tacaw_stream_finish: no open stream");
     const msl_config& c = h->cfg;
+    if (p0 < 0 || count < 0 || p0 + count > c.n_probes)
+        return fail(h, MSL_ERR_INVALID, "msl_tacaw_stream_finish_range: probes [%d,%d) outside [0,%d)", p0, p0 + count, c.n_probes);
+    if (!d_dst_f32 && count > 0 && (p0 != 0 || count != c.n_probes))
+        return fail(h, MSL_ERR_INVALID, "msl_tacaw_stream_finish_range: a probe sub-range needs a destination (the handle's intensity buffer holds all probes)");
     HIPCHK(h, hipSetDevice(c.device));
-    const size_t PK = (size_t)c.n_probes * h->wpix, need = PK * h->st_F;
+    const size_t PK = (size_t)count * h->wpix, need = PK * h->st_F;
     int rc;
-    if (h->intensity_elems != need) {
-        if ((rc = dalloc(h, &h->intensity, need))) return rc;
-        h->intensity_elems = need;
+    float* dst = (float*)d_dst_f32;
+    if (!dst && count > 0) {
+        if (h->intensity_elems != need) {
+            if ((rc = dalloc(h, &h->intensity, need))) return rc;
+            h->intensity_elems = need;
+        }
+        h->intensity_F = h->st_F;
+        dst = h->intensity;
     }
-    h->intensity_F = h->st_F;
-    hipLaunchKernelGGL(tacaw_stream_finish_kernel, dim3((unsigned)((need + 255) / 256)), dim3(256), 0, h->stream, h->st_acc, h->intensity,
-                       h->st_bins, (long long)h->st_F, (long long)h->wpix, (long long)need);
-    HIPCHK(h, hipGetLastError());
-    if (total_PK) {
-        if ((rc = ensure_scratch(h, PK * sizeof(double)))) return rc;
-        hipLaunchKernelGGL(tacaw_stream_total_kernel, dim3((unsigned)((PK + 255) / 256)), dim3(256), 0, h->stream, h->st_s1, h->st_s2,
-                           (double)h->st_T, (long long)PK, (double*)h->scratch);
+    if (need) {
+        hipLaunchKernelGGL(tacaw_stream_finish_kernel, dim3((unsigned)((need + 255) / 256)), dim3(256), 0, h->stream,
+                           h->st_acc + (size_t)p0 * h->st_F * h->wpix, dst, h->st_bins, (long long)h->st_F, (long long)h->wpix, (long long)need);
         HIPCHK(h, hipGetLastError());
-        HIPCHK(h, hipMemcpyAsync(total_PK, h->scratch, PK * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    }
+    if (total_host && PK) {
+        if ((rc = ensure_scratch(h, PK * sizeof(double)))) return rc;
+        hipLaunchKernelGGL(tacaw_stream_total_kernel, dim3((unsigned)((PK + 255) / 256)), dim3(256), 0, h->stream, h->st_s1 + (size_t)p0 * h->wpix,
+                           h->st_s2 + (size_t)p0 * h->wpix, (double)h->st_T, (long long)PK, (double*)h->scratch);
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipMemcpyAsync(total_host, h->scratch, PK * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     (void)hipFree(h->st_acc); h->st_acc = nullptr;           // the accumulators are the big part: give them back
     h->st_open = false;
     return MSL_OK;
+}
+
+int msl_tacaw_stream_finish(msl_handle* h, double* total_PK) {
+    if (!h) return fail(h, MSL_ERR_INVALID, "null handle");
+    return msl_tacaw_stream_finish_range(h, 0, h->cfg.n_probes, nullptr, total_PK);
 }
 
 size_t msl_buffer_bytes(const msl_handle* h, msl_buffer what) {
@@ -2211,6 +2296,10 @@ size_t msl_buffer_bytes(const msl_handle* h, msl_buffer what) {
         case MSL_BUF_WAVEFUNCTION: return h->wf ? h->wpix * c.n_probes * c.n_frames * 8 : 0;
         case MSL_BUF_INTENSITY: return h->intensity_elems * 4;
         case MSL_BUF_FORMFACTOR: return npix * h->n_species * 4;
+        case MSL_BUF_STREAM_ACC: return (h->st_open && h->st_acc) ? h->wpix * c.n_probes * (size_t)h->st_F * 8 : 0;
+        case MSL_BUF_STREAM_S1: return (h->st_open && h->st_s1) ? h->wpix * c.n_probes * 16 : 0;
+        case MSL_BUF_STREAM_S2: return (h->st_open && h->st_s2) ? h->wpix * c.n_probes * 8 : 0;
+        case MSL_BUF_STREAM_REF: return (h->st_open && h->st_have_ref) ? h->wpix * c.n_probes * 8 : 0;
     }
     return 0;
 }
@@ -2225,6 +2314,10 @@ void* msl_device_ptr(msl_handle* h, msl_buffer what) {
         case MSL_BUF_WAVEFUNCTION: return h->wf;
         case MSL_BUF_INTENSITY: return h->intensity;
         case MSL_BUF_FORMFACTOR: return h->d_ff;
+        case MSL_BUF_STREAM_ACC: return h->st_open ? h->st_acc : nullptr;
+        case MSL_BUF_STREAM_S1: return h->st_open ? h->st_s1 : nullptr;
+        case MSL_BUF_STREAM_S2: return h->st_open ? h->st_s2 : nullptr;
+        case MSL_BUF_STREAM_REF: return (h->st_open && h->st_have_ref) ? h->st_ref : nullptr;
     }
     return nullptr;
 }
@@ -2290,6 +2383,35 @@ int msl_tacaw_spectrum(msl_handle* h, const void* d_src_f32, int64_t B, int64_t 
         return MSL_OK;
     }
     return reduce_rows(h, d_src_f32, false, B * F, K, mask, out);
+}
+
+int msl_tacaw_spectrum_weighted(msl_handle* h, const void* d_src_f32, int64_t B, int64_t F, int64_t K, const double* weight, double* out) {
+    if (!out || !weight) return fail(h, MSL_ERR_INVALID, "msl_tacaw_spectrum_weighted: null argument");
+    int rc = intensity_source(h, "msl_tacaw_spectrum_weighted", &d_src_f32, &B, &F, &K);
+    if (rc) return rc;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const int64_t rows_per = std::min<int64_t>(B * F, 32768);
+    const int n_chunks = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(K / 4096, 4096 / std::max<int64_t>(1, rows_per)), 64));
+    const size_t w_bytes = (size_t)K * sizeof(double), part_bytes = (size_t)rows_per * n_chunks * sizeof(double);
+    if ((rc = ensure_scratch(h, w_bytes + part_bytes))) return rc;
+    double* d_w = (double*)h->scratch;
+    double* d_part = (double*)(h->scratch + w_bytes);
+    HIPCHK(h, hipMemcpyAsync(d_w, weight, w_bytes, hipMemcpyHostToDevice, h->stream));
+    std::vector<double> part((size_t)rows_per * n_chunks);
+    for (int64_t r0 = 0; r0 < B * F; r0 += rows_per) {
+        const int64_t rows = std::min<int64_t>(rows_per, B * F - r0);
+        hipLaunchKernelGGL(reduce_kw_kernel, dim3(n_chunks, (unsigned)rows), dim3(256), 0, h->stream, (const float*)d_src_f32 + r0 * K, d_w,
+                           (long long)K, n_chunks, d_part);
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipMemcpyAsync(part.data(), d_part, (size_t)rows * n_chunks * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        for (int64_t r = 0; r < rows; ++r) {
+            double s = 0;
+            for (int c = 0; c < n_chunks; ++c) s += part[(size_t)r * n_chunks + c];
+            out[r0 + r] = s;
+        }
+    }
+    return MSL_OK;
 }
 
 int msl_adf(msl_handle* h, const void* d_src_c64, int64_t B, int64_t T, int64_t K, const uint8_t* mask, double* out) {

@@ -26,6 +26,21 @@ __device__ __forceinline__ double block_sum_256(double v, double* lds4) {
     return lds4[0] + lds4[1] + lds4[2] + lds4[3];
 }
 
+// partial[row * n_chunks + chunk] = sum over the chunk's share of k of weight[k] * src[row*K + k]   (float64 weights: a
+// non-boolean mask of TACAWData.masked_spectrum multiplies the intensity, tacaw_data.py:286-296)
+__global__ void __launch_bounds__(256) reduce_kw_kernel(const float* __restrict__ src, const double* __restrict__ weight, long long K,
+                                                        int n_chunks, double* __restrict__ partial) {
+    __shared__ double lds4[4];
+    const long long row = blockIdx.y;
+    const int chunk = blockIdx.x;
+    const long long k0 = K * chunk / n_chunks, k1 = K * (chunk + 1) / n_chunks;
+    const float* r = src + row * K;
+    double acc = 0.0;
+    for (long long k = k0 + threadIdx.x; k < k1; k += 256) acc += weight[k] * (double)r[k];
+    const double tot = block_sum_256(acc, lds4);
+    if (threadIdx.x == 0) partial[row * n_chunks + chunk] = tot;
+}
+
 // partial[row * n_chunks + chunk] = sum over the chunk's share of k of w(k) * a(row, k)
 //   COMPLEX_ABS = false: a = src_f32[row*K + k]      COMPLEX_ABS = true: a = |src_c64[row*K + k]|
 //   mask (K bytes) optional: w = mask[k] != 0

@@ -44,6 +44,7 @@ struct FoldJob {
     double* s2;                // (P, K)  sum_t |Psi|^2        (float64: T s2 - |s1|^2 cancels to the thermal part)
     const float2* tw;          // (T) exp(-2 pi i m / T)
     const int* bins;           // (F) unshifted FFT bin u_f of every accumulated frequency
+    const float2* ref;         // (P, K) reference pattern subtracted from every frame before it is folded, or null
     long long K;
     int ring, first_slot, count, t0, T, F, f0;
 };
@@ -61,10 +62,15 @@ __global__ void __launch_bounds__(256) tacaw_fold_kernel(FoldJob job) {
     const bool sums = (job.f0 == 0);
     double s1x = 0.0, s1y = 0.0, s2 = 0.0;
     const float2* src = job.wf + ((long long)p * job.ring + job.first_slot) * job.K + k;
+    // Any time-independent offset only changes the u = 0 bin (sum_t exp(-2 pi i u t / T) = 0 otherwise), which the mean
+    // subtraction zeroes anyway (tacaw_data.py:94): folding Psi_t - ref keeps the float32 accumulators at the size of the
+    // thermal part instead of the Bragg amplitude, whose T terms would have to cancel.  S1 / S2 take the frames as they are.
+    const float2 r = job.ref ? job.ref[(long long)p * job.K + k] : make_float2(0.f, 0.f);
     for (int i = 0; i < job.count; ++i) {
-        const float2 v = src[(long long)i * job.K];
+        float2 v = src[(long long)i * job.K];
         const int t = job.t0 + i;                    // uniform
         if (sums) { s1x += (double)v.x; s1y += (double)v.y; s2 += (double)v.x * v.x + (double)v.y * v.y; }
+        v.x -= r.x; v.y -= r.y;
 #pragma unroll
         for (int f = 0; f < MSL_FOLD_FCH; ++f) {
             if (f < nf) {

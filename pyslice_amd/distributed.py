@@ -5,6 +5,11 @@ independent (calculators.py:172-186), so MD frames are sharded in contiguous blo
 and nothing is exchanged while frames are propagated.  Two exchanges exist, both at the end:
 
   * gather_frames      -- assemble (P, T, nx, ny) from the (P, T_r, nx, ny) shards (WFData);
+  * reduce_probes      -- streaming TACAW (the (P,T,nx,ny) array is never held anywhere: BASELINE config C5): every rank has
+                          folded ITS frames into partial sums A_r[p,f,k]; the transform is linear in the frames, so the
+                          result is sum_r A_r -- a reduce-scatter over probes done as a direct exchange (every pair of
+                          GPUs its own xGMI link, each rank sums the world-1 slices it receives for its probes), followed
+                          by gather_probes of the finished intensities.  No ring, no all-reduce of the full accumulator;
   * frames_to_probes   -- all-to-all re-shard from frame-sharded to probe-sharded so every rank
                           holds complete time series for its probes and can run the TACAW time FFT
                           locally (tacaw_data.py:94-96 couples all frames of one probe/pixel),
@@ -173,3 +178,57 @@ def gather_probes(local, n_probes: int, dst: Optional[int] = 0):
     sends = [(_chunk(local), d, 0) for d in receivers if d != rank]
     _exchange(sends, recvs, world)
     return _restore(full, cplx, dev)
+
+
+def broadcast_from(t, src: int = 0):
+    """in-place broadcast of a tensor from rank `src` (the streaming TACAW reference pattern: small, once per run)"""
+    rank, world = rank_world()
+    if world == 1:
+        return t
+    r, cplx, dev = _as_real(t)
+    dist.broadcast(r, src=src)
+    if dev is not None and rank != src:
+        torch.view_as_real(t).copy_(r) if cplx else t.copy_(r)
+    return t
+
+
+def reduce_probes(acc, n_probes: int, temp_bytes: float = 32e9):
+    """Sum-reduce-scatter over probes, in place.  acc: (P, ...) partial sums of this rank (real or complex, device or host).
+    On return acc[p0:p1] holds the sum over ALL ranks for this rank's probe range [p0, p1) = shard_bounds(P, world, rank);
+    the rest of acc is unchanged (stale partial sums).  Returns (p0, p1).
+
+    Direct exchange: in round s every rank sends the slice of rank (rank + s) % world and receives its own slice from rank
+    (rank - s) % world -- as many rounds at once as `temp_bytes` of receive buffers allow (all world-1 of them when they fit:
+    one grouped launch, every pair of GPUs on its own link), then adds what it received.  Per link: one probe shard of the
+    accumulator; C5 (256 probes x 1024 bins x 128^2 stored pixels on 8 GPUs): 4.3 GB per pair, 30 GB of receive buffers."""
+    rank, world = rank_world()
+    pb = [shard_bounds(n_probes, world, r) for r in range(world)]
+    p0, p1 = pb[rank]
+    if world == 1:
+        return p0, p1
+    real, cplx, dev = _as_real(acc)          # under gloo with device data: a host copy (rehearsal path)
+    mine = real[p0:p1]
+    shard_bytes = max(1, mine.numel() * mine.element_size())
+    # the same number of shifts per round on every rank: sized for the LARGEST probe shard
+    biggest = max(b - a for a, b in pb) * (real[0].numel() if real.shape[0] else 0) * real.element_size()
+    per_round = int(max(1, min(world - 1, temp_bytes // max(1, biggest))))
+    for s0 in range(1, world, per_round):
+        shifts = range(s0, min(world, s0 + per_round))
+        temp = _alloc((len(shifts),) + tuple(mine.shape), mine.dtype, mine.device)
+        sends, recvs = [], []
+        for i, s in enumerate(shifts):
+            to, frm = (rank + s) % world, (rank - s) % world
+            a, b = pb[to]
+            if b > a:
+                sends.append((_chunk(real[a:b]), to, 0))
+            if p1 > p0:
+                recvs.append((temp[i], frm, 0))
+        _exchange(sends, recvs, world)
+        if p1 > p0:
+            for i in range(len(shifts)):         # fixed order: deterministic sums; in place: no allocation beyond the receive buffers
+                mine.add_(temp[i])
+        del temp
+    if dev is not None and p1 > p0:          # gloo rehearsal with device data: write the reduced slice back
+        target = torch.view_as_real(acc) if cplx else acc
+        target[p0:p1].copy_(mine)
+    return p0, p1

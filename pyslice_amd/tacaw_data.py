@@ -174,19 +174,17 @@ class TACAWData(WFData):
 
     def masked_spectrum(self, mask: np.ndarray, probe_index: int = None) -> np.ndarray:
         """reference tacaw_data.py:256-300 (its self.kx/self.ky lookup is broken, Q18; kxs/kys used here).
-        As in the reference the mask multiplies the intensity, so a non-boolean mask weights it: weights other than
-        0/1 are applied by one masked sum per distinct weight."""
+        As in the reference the mask multiplies the intensity, so a non-boolean mask weights it: a 0/1 mask takes the byte-mask
+        kernel, any other mask the float64-weighted sum (msl_tacaw_spectrum_weighted)."""
         if mask.shape != (len(self.kxs), len(self.kys)):
             raise ValueError(f"Mask shape {mask.shape} doesn't match k-space shape ({len(self.kxs)}, {len(self.kys)})")
         eng, src, (B, F, K), ptr = self._source()
         mask = np.asarray(mask)
-        weights = [w for w in np.unique(mask) if w != 0]
-        if len(weights) > 8:
-            raise NotImplementedError("masked_spectrum: more than 8 distinct mask weights")
+        binary = mask.dtype == np.bool_ or bool(np.all((mask == 0) | (mask == 1)))
 
         def masked(b0, nb):
             s = (ptr + 4 * b0 * F * K, nb, F, K)
-            return sum(float(w) * eng.tacaw_spectrum(mask == w, src=s) for w in weights) if weights else np.zeros((nb, F))
+            return eng.tacaw_spectrum(mask != 0, src=s) if binary else eng.tacaw_spectrum_weighted(mask, src=s)
 
         if probe_index is None:
             return masked(0, len(self.probe_positions)).mean(axis=0)

@@ -81,6 +81,63 @@ def test_frame_shard_exchanges_gloo(P, T, world, max_ops):
     assert all(ok for _, ok in res), res
 
 
+def _reduce_worker(rank, world, port, P, F, K, temp_bytes, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pyslice_amd import distributed as D
+        # partial sums of every rank (the streaming TACAW accumulators of a frame shard): complex64 (P,F,K), float64 (P,K,2), (P,K)
+        parts = []
+        for r in range(world):
+            rng = np.random.default_rng(100 + r)
+            parts.append((torch.from_numpy((rng.standard_normal((P, F, K)) + 1j * rng.standard_normal((P, F, K))).astype(np.complex64)),
+                          torch.from_numpy(rng.standard_normal((P, K, 2))), torch.from_numpy(rng.standard_normal((P, K)))))
+        mine = [t.clone() for t in parts[rank]]
+        lo, hi = D.shard_bounds(P, world, rank)
+        ok = True
+        for i, t in enumerate(mine):
+            D.alloc_log.clear()
+            p0, p1 = D.reduce_probes(t, P, temp_bytes=temp_bytes)
+            ok &= (p0, p1) == (lo, hi)
+            # summed in rank order after this rank's own part: compare against the same order (exact in float64, 1 ulp-ish in float32)
+            want = parts[rank][i][lo:hi].clone()
+            for s in range(1, world):
+                want = want + parts[(rank - s) % world][i][lo:hi]
+            ok &= bool(torch.equal(t[lo:hi], want))
+            # receive buffers only, never more than the budget allows (one shard at least)
+            shard = (hi - lo) * (t[0].numel() if P else 0) * t.element_size()
+            biggest = max(b - a for a, b in (D.shard_bounds(P, world, r) for r in range(world))) * t[0].numel() * t.element_size()
+            per_round = int(max(1, min(world - 1, temp_bytes // max(1, biggest))))
+            ok &= all(a <= per_round * max(shard, 1) for a in D.alloc_log)
+            # the rest of the array is left alone
+            if lo > 0:
+                ok &= bool(torch.equal(t[:lo], parts[rank][i][:lo]))
+        # the reference pattern travels from rank 0 to everybody
+        ref = parts[0][0][:, 0].clone() if rank == 0 else torch.zeros((P, K), dtype=torch.complex64)
+        D.broadcast_from(ref, src=0)
+        ok &= bool(torch.equal(ref, parts[0][0][:, 0]))
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("P,world,temp_bytes", [(4, 2, 32e9), (3, 2, 32e9), (1, 2, 32e9), (7, 3, 32e9), (7, 3, 1.0)])
+def test_reduce_scatter_over_probes_gloo(P, world, temp_bytes):
+    """frame-sharded streaming TACAW: the ranks' partial sums are summed by a direct exchange, probe-sharded result
+    (uneven shards, a rank without probes, one round of all peers or -- tiny receive budget -- one peer per round)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_reduce_worker, args=(r, world, port, P, 5, 6, temp_bytes, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok in res), res
+
+
 def test_shard_bounds_cover():
     from pyslice_amd.distributed import shard_bounds, shard_frames
     for n in (1, 2, 7, 256):

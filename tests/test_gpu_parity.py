@@ -241,6 +241,9 @@ def test_g8_tacaw(ps, golden):
         assert rel_l2(t.masked_spectrum(mask, 0), (I[0] * mask[None]).sum(axis=(1, 2))) < TACAW_TOL
         assert rel_l2(t.masked_spectrum(mask), (I * mask[None, None]).sum(axis=(2, 3)).mean(axis=0)) < TACAW_TOL
         assert rel_l2(t.masked_spectrum(mask * 0.5, 1), 0.5 * (I[1] * mask[None]).sum(axis=(1, 2))) < TACAW_TOL
+        soft = np.exp(-(kxs[:, None] ** 2 + kys[None, :] ** 2) / 2.0)          # a smooth detector function: every weight distinct
+        assert rel_l2(t.masked_spectrum(soft, 1), (I[1] * soft[None]).sum(axis=(1, 2))) < TACAW_TOL
+        assert rel_l2(t.masked_spectrum(soft), (I * soft[None, None]).sum(axis=(2, 3)).mean(axis=0)) < TACAW_TOL
         assert rel_l2(t.dispersion(kxp, kyp, 1), I[1][:, ix, iy]) < TACAW_TOL
         assert rel_l2(t.dispersion(kxp, kyp), I[:, :, ix, iy].mean(axis=0)) < TACAW_TOL
         assert t.dispersion(kxp, kyp[:3]).shape == (len(g["frequencies"]), 7)
@@ -696,6 +699,38 @@ def test_streaming_tacaw_matches_the_full_transform(ps, orc, n, T, tile, P, fb, 
     assert rel_l2(tw.diffraction(P - 1), inten[P - 1][sel].sum(axis=0)) < TACAW_TOL
 
 
+def test_streaming_fold_weak_bins_at_strong_pixels(ps):
+    """The fold alone, on uploaded frames whose exact transform is known: a pixel with a time mean 1e5 times its thermal part
+    (a Bragg spot or the central beam).  Every non-zero bin there is what is left after T large terms cancel; the fold
+    subtracts the run's first frame before accumulating (msl_tacaw_stream_set_reference -- a constant offset only changes
+    the u = 0 bin, which the mean subtraction of tacaw_data.py:94 zeroes), so the float32 accumulators hold the thermal part
+    only.  Checked PER PIXEL at T = 256 and 1024 against the float64 DFT of the very same float32 frames."""
+    from pyslice_amd import _native
+    rng = np.random.default_rng(3)
+    for T, ring in ((256, 32), (1024, 64)):
+        nx = ny = 8
+        eng = _native.Engine(nx, ny, 1, 0.1, 0.1, 0.5, 0.037, 1e-3, n_probes=2, n_frames=ring)
+        big = (rng.standard_normal((2, 1, nx, ny)) + 1j * rng.standard_normal((2, 1, nx, ny))) * 1e3
+        big[:, :, ::2, ::3] = 0.0                                              # some pixels without a mean
+        small = (rng.standard_normal((2, T, nx, ny)) + 1j * rng.standard_normal((2, T, nx, ny))) * 1e-2
+        frames = (big + small).astype(np.complex64)                           # the data as the device sees it
+        want = np.abs(np.fft.fftshift(np.fft.fft(frames.astype(np.complex128) - frames.astype(np.complex128).mean(axis=1, keepdims=True), axis=1), axes=1)) ** 2
+        eng.tacaw_stream_begin(T, (np.arange(T) + (T + 1) // 2) % T)        # bins in fftshifted order, like the calculator
+        for t0 in range(0, T, ring):
+            for i in range(ring):
+                eng.upload_frame(i, frames[:, t0 + i])
+            if t0 == 0:
+                eng.tacaw_stream_set_reference(slot=0)
+            eng.tacaw_stream_push(0, ring, t0)
+        total = eng.tacaw_stream_finish(True)
+        got = eng.intensity().astype(np.float64)
+        eng.close()
+        assert got[:, T // 2].max() == 0.0
+        err = np.linalg.norm(got - want, axis=1) / np.linalg.norm(want, axis=1)     # per (probe, pixel), over the frequency axis
+        assert err.max() < 2e-5, (T, err.max())
+        assert rel_l2(total, want.sum(axis=1)) < 1e-6
+
+
 def test_streaming_tacaw_c5_grid_window_and_bin(ps, orc):
     """BASELINE C5's grid (2048^2) with the k-window and bin DESIGN picks for it (window 512 x 512, bin 4 x 4), a shallow stack
     so that the oracle stays affordable: streamed TACAW of 6 frames against the oracle's transform of its own binned window."""
@@ -1133,6 +1168,43 @@ def test_g10_probe_defocus(ps, golden):
     before = npy(pr.array).copy()
     pr.defocus(0)
     assert np.array_equal(npy(pr.array), before)
+
+
+@pytest.mark.parametrize("T", [2, 3, 33, 40, 100, 128, 129, 255, 257, 500, 512])
+@pytest.mark.parametrize("shape", [(8, 8), (6, 8)])
+def test_tacaw_any_frame_count_on_the_register_kernel(ps, T, shape):
+    """The reference transforms whatever frame count the trajectory has (tacaw_data.py:94-96; 100 frames in its notebook,
+    example.ipynb:578).  Every T <= 512 that is not 256 runs the chirp-z register kernel (time_cz_kernel: M = 256 for T <= 128
+    on 32- or 16-pixel tiles, M = 1024 above): against the float64 transform of the same float32 frames, per pixel -- some
+    pixels with a time mean 1e4 times their thermal part (the kernel subtracts the line's first sample instead of the mean) --
+    and against the generic LDS kernel."""
+    from pyslice_amd import _native
+    rng = np.random.default_rng(T)
+    nx, ny = shape
+    eng = _native.Engine(nx, ny, 1, 0.1, 0.1, 0.5, 0.037, 1e-3, n_probes=3, n_frames=T)
+    big = (rng.standard_normal((3, 1, nx, ny)) + 1j * rng.standard_normal((3, 1, nx, ny))) * 1e2
+    big[:, :, ::2, ::3] = 0.0
+    small = (rng.standard_normal((3, T, nx, ny)) + 1j * rng.standard_normal((3, T, nx, ny))) * 1e-2
+    frames = (big + small).astype(np.complex64)
+    f64 = frames.astype(np.complex128)
+    want = np.abs(np.fft.fftshift(np.fft.fft(f64 - f64.mean(axis=1, keepdims=True), axis=1), axes=1)) ** 2
+    for t in range(T):
+        eng.upload_frame(t, frames[:, t])
+    eng.tacaw()
+    got = eng.intensity().astype(np.float64)
+    assert got.shape == want.shape
+    assert got[:, T // 2].max() == 0.0
+    err = np.linalg.norm(got - want, axis=1) / np.linalg.norm(want, axis=1)
+    assert err.max() < 5e-5, (T, err.max())
+    os.environ["MSL_TACAW_GENERIC"] = "1"
+    try:
+        eng.tacaw()
+        gen = eng.intensity().astype(np.float64)
+    finally:
+        del os.environ["MSL_TACAW_GENERIC"]
+    eng.close()
+    weak = big[:, 0] == 0                                     # the generic kernel transforms the raw lines: compare where no mean has to cancel
+    assert rel_l2(got.transpose(0, 2, 3, 1)[weak], gen.transpose(0, 2, 3, 1)[weak]) < 1e-5
 
 
 def test_tacaw_fourstep_time_axis_256_frames(ps, orc):
