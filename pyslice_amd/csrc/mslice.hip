@@ -2134,8 +2134,8 @@ int msl_tacaw(msl_handle* h, const void* d_src, void* d_dst, int64_t batch, int3
         j.image_stride = (long long)T * npix; j.npix = (int)npix; j.n_images = (int)batch; j.T = T;
         auto launch = [&](auto r_c, auto cols_c) -> int {
             constexpr int R = decltype(r_c)::value, COLS = decltype(cols_c)::value;
-            constexpr int M = R * R, NH = M / 2, CS = R * (R + 1) + 2;
-            const size_t lds = ((size_t)M + NH + 2 + NH + (size_t)COLS * CS) * 8;
+            constexpr int M = R * R, NH = M / 2;
+            const size_t lds = ((size_t)M + NH + 2 + NH + (size_t)2 * COLS * tcz_stride(R, T)) * 8;          // two tile buffers
             const long long tiles = (npix / COLS) * batch;
             const int per_cu = std::max(1, std::min(2, (int)((size_t)h->lds_limit / lds)));
             const int grid = (int)std::min<long long>(tiles, (long long)h->n_cus * per_cu);

@@ -31,19 +31,28 @@ struct TimeJob {
     int npix, n_images, T;
 };
 
+// column stride (float2) of the LDS tile: the T samples of a line or its share of the wave's exchange scratch (R x 68 floats per
+// 64 / R columns = 17 R^2 / 32 float2 per column), whichever is larger, made odd
+__host__ __device__ constexpr int tcz_min_stride(int R) { return 17 * R * R / 32; }
+__host__ __device__ inline int tcz_stride(int R, int T) { const int s = T > tcz_min_stride(R) ? T : tcz_min_stride(R); return s | 1; }
+
 template <int R, int COLS>
 __global__ void __launch_bounds__(COLS * R) time_cz_kernel(TimeJob job) {
     constexpr int M = R * R, H = R / 2, NH = M / 2, NT = COLS * R, TCH = 8;
-    constexpr int CS = R * (R + 1) + 2;               // LDS column stride in float2: even (16-byte aligned exchange scratch), conflict-free staging
+    // LDS column stride in float2: odd, so that the column-major staging (lanes = pixel pairs: stride 2 CS) and the row reads of
+    // the output fall into distinct banks (an even stride put pixel pairs q and q + 8 into the same bank: 31 % of the LDS
+    // cycles were conflicts, profiles/r03_tacaw_t100_before_summary.json).  A wave's exchange scratch starts at its first column:
+    // 64/R columns = a multiple of 16 bytes for any stride.  The stride follows T (tcz_stride): 137 float2 for T <= 136 on the
+    // 256-point kernel, 545 on the 1024-point one.
+    const int CS = tcz_stride(R, job.T);
     constexpr int QN = COLS / 2;                      // threads (two pixels = 16 bytes each) per row segment
     constexpr int ROWS_PER_IT = NT / QN;              // 2 R
     constexpr int NIT = NH / ROWS_PER_IT;             // R / 4 staging loads per thread and tile (rows beyond T skipped)
-    static_assert(R * 68 * 4 <= (64 / R) * CS * 8, "the wave's add-tid exchange scratch must fit its own columns");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float2* tw = reinterpret_cast<float2*>(smem_raw);         // M
     float2* bf = tw + M;                                      // NH + 2
     float2* bw = bf + NH + 2;                                 // NH
-    float2* cols = bw + NH;                                   // COLS * CS
+    float2* bufs = bw + NH;                                   // two tiles of COLS * CS
     const int tid = threadIdx.x;
     const int T = job.T;
     for (int i = tid; i < M; i += NT) tw[i] = job.tw[i];
@@ -51,14 +60,11 @@ __global__ void __launch_bounds__(COLS * R) time_cz_kernel(TimeJob job) {
     for (int i = tid; i < NH; i += NT) bw[i] = job.bw[i];
     const int grp = tid / R, ln = tid % R;            // pixel handled in the transform phase
     const int q = tid % QN, r0 = tid / QN;            // staging role: pixel pair q, frames r0 + ROWS_PER_IT * i
-    float2* mycol = cols + grp * CS;
-    // exchange scratch of the wave (ds_write_addtid_b32 stores): starts at the first column of the wave's 64 / R pixels
-    const float* wscr = reinterpret_cast<const float*>(cols + (grp - grp % (64 / R)) * CS);
-    const unsigned wscr_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(cols + (grp - grp % (64 / R)) * CS));
     const float2* fa = bf + ln;                       // Bf[j R + ln],                             j <  R/2
     const float2* fb = bf - ln;                       // Bf[M - (j R + ln)] = bf[(R - j) R - ln],  j >= R/2
     const int tiles_per_image = job.npix / COLS;
     const long long n_tiles = (long long)tiles_per_image * job.n_images;
+    const int half = T / 2;                           // np.fft.fftshift: bin u lands at (u + T/2) mod T
     float4 stage[NIT];
     auto load_tile = [&](long long t) {
         const long long p = t / tiles_per_image, c0 = (t % tiles_per_image) * COLS;
@@ -69,12 +75,9 @@ __global__ void __launch_bounds__(COLS * R) time_cz_kernel(TimeJob job) {
             if (f < T) stage[i] = *reinterpret_cast<const float4*>(src + (long long)f * job.npix);
         }
     };
-    long long tile = blockIdx.x;
-    if (tile < n_tiles) load_tile(tile);
-    __syncthreads();
-    const int half = T / 2;                           // np.fft.fftshift: bin u lands at (u + T/2) mod T
-    for (; tile < n_tiles; tile += gridDim.x) {
-        // ---- registers -> LDS, column-major
+    // registers -> LDS, column-major: thread (q, r0) owns the slots (2q, f), (2q + 1, f) of its frames f in BOTH directions -- it
+    // is also the thread that reads the intensities of those slots back (store_tile)
+    auto stage_tile = [&](float2* cols) {
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
             const int f = r0 + ROWS_PER_IT * i;
@@ -83,74 +86,95 @@ __global__ void __launch_bounds__(COLS * R) time_cz_kernel(TimeJob job) {
                 cols[(2 * q + 1) * CS + f] = make_float2(stage[i].z, stage[i].w);
             }
         }
-        lds_barrier();
-        // ---- next tile's loads go out now and fly during the transform
-        const long long nxt = tile + gridDim.x;
-        if (nxt < n_tiles) load_tile(nxt);
-        // ---- my pixel's time line: subtract the first sample, chirp, FFT_M, filter, IFFT_M, chirp
+    };
+    // LDS -> HBM: COLS x 4-byte row segments of the float output (the intensity of bin f sits in the .x of slot f)
+    auto store_tile = [&](const float2* cols, long long t) {
+        const long long p = t / tiles_per_image, c0 = (t % tiles_per_image) * COLS;
+        float* dst = job.out + p * job.image_stride + c0 + 2 * q;
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int f = r0 + ROWS_PER_IT * i;
+            if (f < T) *reinterpret_cast<float2*>(dst + (long long)f * job.npix) = make_float2(cols[(2 * q) * CS + f].x, cols[(2 * q + 1) * CS + f].x);
+        }
+    };
+    // my pixel's time line: subtract the first sample, chirp, FFT_M, filter, IFFT_M; |.|^2 (fftshifted) back into the column
+    auto transform_tile = [&](float2* cols) {
+        float2* mycol = cols + grp * CS;
+        // exchange scratch of the wave (ds_write_addtid_b32 stores): starts at the first column of the wave's 64 / R pixels
+        const float* wscr = reinterpret_cast<const float*>(cols + (grp - grp % (64 / R)) * CS);
+        const unsigned wscr_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(cols + (grp - grp % (64 / R)) * CS));
+        float2 v[R];
+        const float2 ref = mycol[0];
+#pragma unroll
+        for (int j = 0; j < H; ++j) {
+            const int n = j * R + ln;
+            const float2 x = (n < T) ? mycol[n] : ref;
+            v[j] = make_float2(x.x - ref.x, x.y - ref.y);
+        }
+        wave_lds_fence();
         {
-            float2 v[R];
-            const float2 ref = mycol[0];
 #pragma unroll
-            for (int j = 0; j < H; ++j) {
-                const int n = j * R + ln;
-                const float2 x = (n < T) ? mycol[n] : ref;
-                v[j] = make_float2(x.x - ref.x, x.y - ref.y);
-            }
-            wave_lds_fence();
-            auto mul_chirp = [&]() {
-#pragma unroll
-                for (int c = 0; c < H; c += TCH) {
-                    float2 w[TCH];
-#pragma unroll
-                    for (int j = 0; j < TCH; ++j) if (c + j < H) w[j] = bw[(c + j) * R + ln];
-#pragma unroll
-                    for (int j = 0; j < TCH; ++j) if (c + j < H) v[c + j] = cmulf(v[c + j], w[j]);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-#pragma unroll
-                for (int j = H; j < R; ++j) v[j] = make_float2(0.f, 0.f);
-            };
-            mul_chirp();
-            fourstep_split_addtid<R, false, TCH>(v, wscr, wscr_lds, tw, ln, tid & 63);
-#pragma unroll
-            for (int c = 0; c < R; c += TCH) {
+            for (int c = 0; c < H; c += TCH) {
                 float2 w[TCH];
 #pragma unroll
-                for (int j = 0; j < TCH; ++j) w[j] = (c + j < H) ? fa[(c + j) * R] : fb[(R - (c + j)) * R];
+                for (int j = 0; j < TCH; ++j) if (c + j < H) w[j] = bw[(c + j) * R + ln];
 #pragma unroll
-                for (int j = 0; j < TCH; ++j) v[c + j] = cmulf(v[c + j], w[j]);
+                for (int j = 0; j < TCH; ++j) if (c + j < H) v[c + j] = cmulf(v[c + j], w[j]);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            fourstep_split_addtid<R, true, TCH>(v, wscr, wscr_lds, tw, ln, tid & 63);
-            // |X[k]|^2 with the chirp's unit modulus dropped (|w[k]| = 1): the last chirp product is not needed for an intensity
-            wave_lds_fence();
-            float* fcol = reinterpret_cast<float*>(mycol);
 #pragma unroll
-            for (int j = 0; j < H; ++j) {
-                const int k = j * R + ln;
-                if (k < T) {
-                    int ks = k + half;
-                    if (ks >= T) ks -= T;
-                    fcol[ks] = (k == 0) ? 0.f : fmaf(v[j].x, v[j].x, v[j].y * v[j].y);
+            for (int j = H; j < R; ++j) v[j] = make_float2(0.f, 0.f);
+            fourstep_split_addtid<R, false, TCH>(v, wscr, wscr_lds, tw, ln, tid & 63);
+            {
+#pragma unroll
+                for (int c = 0; c < R; c += TCH) {
+                    float2 w[TCH];
+#pragma unroll
+                    for (int j = 0; j < TCH; ++j) w[j] = (c + j < H) ? fa[(c + j) * R] : fb[(R - (c + j)) * R];
+#pragma unroll
+                    for (int j = 0; j < TCH; ++j) v[c + j] = cmulf(v[c + j], w[j]);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
+                fourstep_split_addtid<R, true, TCH>(v, wscr, wscr_lds, tw, ln, tid & 63);
             }
         }
-        lds_barrier();
-        // ---- LDS -> HBM: COLS x 4-byte row segments of the float output
-        {
-            const long long p = tile / tiles_per_image, c0 = (tile % tiles_per_image) * COLS;
-            float* dst = job.out + p * job.image_stride + c0 + 2 * q;
-            const float* fa0 = reinterpret_cast<const float*>(cols + (2 * q) * CS);
-            const float* fa1 = reinterpret_cast<const float*>(cols + (2 * q + 1) * CS);
+        // |X[k]|^2 with the chirp's unit modulus dropped (|w[k]| = 1): the last chirp product is not needed for an intensity
+        wave_lds_fence();
 #pragma unroll
-            for (int i = 0; i < NIT; ++i) {
-                const int f = r0 + ROWS_PER_IT * i;
-                if (f < T) *reinterpret_cast<float2*>(dst + (long long)f * job.npix) = make_float2(fa0[f], fa1[f]);
+        for (int j = 0; j < H; ++j) {
+            const int k = j * R + ln;
+            if (k < T) {
+                int ks = k + half;
+                if (ks >= T) ks -= T;
+                mycol[ks].x = (k == 0) ? 0.f : fmaf(v[j].x, v[j].x, v[j].y * v[j].y);
             }
         }
-        lds_barrier();                          // LDS is free for the next tile's staging from here on
+    };
+    // Software pipeline over the workgroup's tiles with ONE barrier per tile: while tile i is transformed in one LDS buffer, the
+    // intensities of tile i - 1 leave the other one and tile i + 1 is staged into it -- by the same thread slot for slot, so no
+    // barrier is needed between the two -- and the loads of tile i + 2 fly in registers.  A wave that has finished its share of the
+    // memory work starts its transform while the others are still storing: the phases of a workgroup overlap instead of
+    // alternating.  (Measured equal to the three-barrier form, 64 probes x 100 frames x 1024^2: 31.4 ms either way, 16.1 ms
+    // with the transform disabled -- the kernel is bound by the rate of its register FFTs, two M-point transforms per line
+    // whatever T is: ~1 G 1024-point FFTs per second on the chip, as in the slice-loop kernels.)
+    const long long step = gridDim.x;
+    long long tile = blockIdx.x;
+    if (tile < n_tiles) load_tile(tile);
+    __syncthreads();
+    if (tile < n_tiles) stage_tile(bufs);
+    if (tile + step < n_tiles) load_tile(tile + step);
+    lds_barrier();
+    int it = 0;
+    for (; tile < n_tiles; tile += step, ++it) {
+        float2* cur = bufs + (it & 1) * (COLS * CS);
+        float2* oth = bufs + ((it & 1) ^ 1) * (COLS * CS);
+        if (it > 0) store_tile(oth, tile - step);
+        if (tile + step < n_tiles) stage_tile(oth);
+        if (tile + 2 * step < n_tiles) load_tile(tile + 2 * step);
+        transform_tile(cur);
+        lds_barrier();
     }
+    if (it > 0) store_tile(bufs + ((it - 1) & 1) * (COLS * CS), tile - step);
 }
 
 }  // namespace msl

@@ -728,7 +728,7 @@ def test_streaming_fold_weak_bins_at_strong_pixels(ps):
         assert got[:, T // 2].max() == 0.0
         err = np.linalg.norm(got - want, axis=1) / np.linalg.norm(want, axis=1)     # per (probe, pixel), over the frequency axis
         assert err.max() < 2e-5, (T, err.max())
-        assert rel_l2(total, want.sum(axis=1)) < 1e-6
+        assert rel_l2(total, want.sum(axis=1)) < 2e-5            # T S2 - |S1|^2 in float64: 1e11 cancels to 1e1
 
 
 def test_streaming_tacaw_c5_grid_window_and_bin(ps, orc):
