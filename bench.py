@@ -261,9 +261,8 @@ def run(a):
         todo = [f for s in range(s0, s1) for f in my_frames[s]]
         for i in range(0, len(todo), eng.frame_batch):
             chunk = todo[i:i + eng.frame_batch]
-            for b, f in enumerate(chunk):
-                eng.select_batch_slot(b)
-                eng.build_potential(tr.positions[f], Z, 2)
+            consecutive = chunk[-1] - chunk[0] + 1 == len(chunk)
+            eng.build_potentials(tr.positions[chunk[0]:chunk[-1] + 1] if consecutive else tr.positions[chunk], Z, 2)
             eng.propagate_frames(slot_of[chunk[0]], len(chunk))
 
     def fence():

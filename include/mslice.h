@@ -174,6 +174,12 @@ int  msl_propagate_frame(msl_handle* h, int32_t slot);
  * Replaces count iterations of the reference's serial frame loop (calculators.py:172-186). */
 int  msl_select_batch_slot(msl_handle* h, int32_t b);
 int  msl_propagate_frames(msl_handle* h, int32_t first_slot, int32_t count);
+/* The potentials of `count` MD frames (1 <= count <= frame_batch) into the batch slots 0 .. count-1 in ONE sequence of launches:
+ * pos = count x n_atoms x 3 doubles (frame-major), Z = the n_atoms atomic numbers every frame shares (Trajectory.atom_types,
+ * trajectory.py:8-14); axes as msl_build_potential.  Replaces `count` constructions of Potential (calculators.py:172-186 builds
+ * one per frame, potentials.py:188-348) -- with the reference's default single probe the per-frame build is the frame. */
+int  msl_build_potentials(msl_handle* h, const double* pos, const int32_t* Z, int64_t n_atoms, int32_t count,
+                          int32_t ax1, int32_t ax2, int32_t axs);
 int  msl_frame_batch(const msl_handle* h);
 
 /* TACAW: intensity[p,w,kx,ky] = | fftshift_t fft_t( Psi - <Psi>_t ) |^2 over a (B,T,npix) c64 device

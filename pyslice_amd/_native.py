@@ -25,7 +25,7 @@ EXPORTS = [
     "msl_get_counters",
     "msl_reset_counters", "msl_fft2_host",
     "msl_tacaw_spectrum", "msl_tacaw_spectrum_weighted", "msl_tacaw_diffraction", "msl_tacaw_dispersion", "msl_adf",
-    "msl_select_batch_slot", "msl_propagate_frames", "msl_frame_batch",
+    "msl_select_batch_slot", "msl_propagate_frames", "msl_frame_batch", "msl_build_potentials",
     "msl_tacaw_stream_begin", "msl_tacaw_stream_push", "msl_tacaw_stream_finish",
     "msl_tacaw_stream_set_reference", "msl_tacaw_stream_finish_range",
 ]
@@ -77,6 +77,7 @@ def load():
         "msl_upload_probes": (C.c_int, [vp, vp, i32]),
         "msl_shift_probes": (C.c_int, [vp, vp, vp, i32]),
         "msl_build_potential": (C.c_int, [vp, vp, vp, i64, i32, i32, i32]),
+        "msl_build_potentials": (C.c_int, [vp, vp, vp, i64, i32, i32, i32, i32]),
         "msl_upload_potential": (C.c_int, [vp, vp]),
         "msl_propagate": (C.c_int, [vp]),
         "msl_propagate_frame": (C.c_int, [vp, i32]),
@@ -225,6 +226,20 @@ class Engine:
             raise ValueError(f"slice_axis must be 0, 1 or 2, got {slice_axis}")
         axes.remove(slice_axis)
         self._chk(self._lib.msl_build_potential(self._h, _ptr(pos), _ptr(z), pos.shape[0], axes[0], axes[1], slice_axis))
+
+    def build_potentials(self, positions, Z, slice_axis=2):
+        """potentials of B = positions.shape[0] frames (B <= frame_batch) into the batch slots 0..B-1, one sequence of launches"""
+        pos = np.ascontiguousarray(positions, dtype=np.float64)
+        if pos.ndim != 3 or pos.shape[2] != 3:
+            raise ValueError(f"positions must be (n_frames,n_atoms,3), got {pos.shape}")
+        z = np.ascontiguousarray(Z, dtype=np.int32)
+        if z.shape != (pos.shape[1],):
+            raise ValueError("one atomic number per atom required")
+        axes = [0, 1, 2]
+        if slice_axis not in axes:
+            raise ValueError(f"slice_axis must be 0, 1 or 2, got {slice_axis}")
+        axes.remove(slice_axis)
+        self._chk(self._lib.msl_build_potentials(self._h, _ptr(pos), _ptr(z), pos.shape[1], pos.shape[0], axes[0], axes[1], slice_axis))
 
     def upload_potential(self, V_nz_nx_ny):
         v = np.ascontiguousarray(V_nz_nx_ny, dtype=np.float32)

@@ -224,9 +224,7 @@ class MultisliceCalculator:
             # batches of B frames: B potentials into the batch slots, then one slice loop over B x P images
             for s0 in range(0, len(frames), B):
                 chunk = frames[s0:s0 + B]
-                for b, frame_idx in enumerate(chunk):
-                    eng.select_batch_slot(b)
-                    eng.build_potential(self.trajectory.positions[frame_idx], self._Z, self.slice_axis)
+                eng.build_potentials(self.trajectory.positions[chunk[0]:chunk[-1] + 1], self._Z, self.slice_axis)
                 eng.propagate_frames(s0, len(chunk))
                 self.frames_computed += len(chunk)
                 if bar is not None:
@@ -327,9 +325,7 @@ class MultisliceCalculator:
             for s0 in range(0, len(tile), B):
                 chunk = tile[s0:s0 + B]
                 if B > 1:
-                    for b, frame_idx in enumerate(chunk):
-                        eng.select_batch_slot(b)
-                        eng.build_potential(self.trajectory.positions[frame_idx], self._Z, self.slice_axis)
+                    eng.build_potentials(self.trajectory.positions[chunk[0]:chunk[-1] + 1], self._Z, self.slice_axis)
                     eng.propagate_frames(s0, len(chunk))
                 else:
                     eng.build_potential(self.trajectory.positions[chunk[0]], self._Z, self.slice_axis)

@@ -108,57 +108,7 @@ __device__ __forceinline__ void fourstep_split(float2 (&v)[R], float* scratch, c
     fft_regs<R, INV>(v);
 }
 
-// The same exchange with 16-byte reads: scratch rows of PW = R + 4 floats (16-byte aligned; a lane's R consecutive floats come
-// back as R/4 ds_read_b128, conflict-free at this pitch: 16 lanes x 4 dwords cover the 64 banks) -- half the LDS read cycles and
-// a quarter of the read instructions of the R + 1 pitch.  The scratch must be 16-byte aligned and hold R (R + 4) floats.
-template <int R, bool INV, int CH = 8>
-__device__ __forceinline__ void fourstep_split_wide(float2 (&v)[R], float* scratch, const float2* tw, int ln) {
-    static_assert(64 % R == 0 && R % 4 == 0, "an R-lane group must lie inside one wave; rows are read four floats at a time");
-    constexpr int PW = R + 4;
-    fft_regs<R, INV>(v);
-    mul_table<R, 1, INV, R, CH>(v, tw, ln);
-#pragma unroll
-    for (int k1 = 0; k1 < R; ++k1) scratch[k1 * PW + ln] = v[k1].x;
-    wave_lds_fence();
-#pragma unroll
-    for (int g = 0; g < R / 4; ++g) {
-        const float4 q = *reinterpret_cast<const float4*>(scratch + ln * PW + 4 * g);
-        v[4 * g].x = q.x; v[4 * g + 1].x = q.y; v[4 * g + 2].x = q.z; v[4 * g + 3].x = q.w;
-    }
-    wave_lds_fence();
-#pragma unroll
-    for (int k1 = 0; k1 < R; ++k1) scratch[k1 * PW + ln] = v[k1].y;
-    wave_lds_fence();
-#pragma unroll
-    for (int g = 0; g < R / 4; ++g) {
-        const float4 q = *reinterpret_cast<const float4*>(scratch + ln * PW + 4 * g);
-        v[4 * g].y = q.x; v[4 * g + 1].y = q.y; v[4 * g + 2].y = q.z; v[4 * g + 3].y = q.w;
-    }
-    wave_lds_fence();
-    fft_regs<R, INV>(v);
-}
-
-// Complex form of the wide exchange: 8-byte writes (one per register instead of two), 16-byte reads of two complex values;
-// scratch rows of R + 2 float2 (16-byte aligned, conflict-free for both patterns), R (R + 2) float2 in all.
-template <int R, bool INV, int CH = 8>
-__device__ __forceinline__ void fourstep_c64_wide(float2 (&v)[R], float2* scratch, const float2* tw, int ln) {
-    static_assert(64 % R == 0 && R % 2 == 0, "an R-lane group must lie inside one wave");
-    constexpr int PW = R + 2;
-    fft_regs<R, INV>(v);
-    mul_table<R, 1, INV, R, CH>(v, tw, ln);
-#pragma unroll
-    for (int k1 = 0; k1 < R; ++k1) scratch[k1 * PW + ln] = v[k1];
-    wave_lds_fence();
-#pragma unroll
-    for (int g = 0; g < R / 2; ++g) {
-        const float4 q = *reinterpret_cast<const float4*>(scratch + ln * PW + 2 * g);
-        v[2 * g] = make_float2(q.x, q.y); v[2 * g + 1] = make_float2(q.z, q.w);
-    }
-    wave_lds_fence();
-    fft_regs<R, INV>(v);
-}
-
-// The wide exchange with ds_write_addtid_b32 stores: the address is M0 + offset + 4 * lane, so the store needs no address
+// Exchange with ds_write_addtid_b32 stores and 16-byte reads: the store address is M0 + offset + 4 * lane, so it needs no address
 // register and runs at twice the rate of ds_write_b32 (128 B/clk: MI355X_MICROARCH.md, LDS).  The 64 / R line groups of a wave
 // share one scratch of R rows x 68 floats: row k1 holds the k1-th register of all 64 lanes (group g at columns [g R, (g+1) R)),
 // and lane (g, l) reads back row l, columns g R + n2, as R/4 ds_read_b128 (row pitch 68: 16-byte aligned, conflict-free).
@@ -209,19 +159,7 @@ __device__ __forceinline__ void fourstep_c64(float2 (&v)[R], float2* scratch, co
     fft_regs<R, INV>(v);
 }
 
-// Exchange variants of the transposing kernels: 0 = real and imaginary parts one after the other, rows of R + 1 floats;
-// 1 = complex, rows of R + 1 float2; 2 / 3 = the same with 16-byte reads (rows of R + 4 floats / R + 2 float2).
-template <int R, int XCH> constexpr int xch_scratch_float2() {      // scratch per line in float2 (4: per wave, R x 68 floats over 64/R lines)
-    return XCH == 0 ? (R * (R + 1) + 1) / 2 : XCH == 1 ? R * (R + 1) : XCH == 2 ? R * (R + 4) / 2 : XCH == 3 ? R * (R + 2) : (R * 68 / 2 + 64 / R - 1) / (64 / R);
-}
-template <int R, bool INV, int XCH, int CH>
-__device__ __forceinline__ void fourstep_x(float2 (&v)[R], float2* scratch, const float2* tw, int ln) {
-    if constexpr (XCH == 0) fourstep_split<R, INV, CH>(v, reinterpret_cast<float*>(scratch), tw, ln);
-    else if constexpr (XCH == 1) fourstep_c64<R, INV, CH>(v, scratch, tw, ln);
-    else if constexpr (XCH == 2) fourstep_split_wide<R, INV, CH>(v, reinterpret_cast<float*>(scratch), tw, ln);
-    else fourstep_c64_wide<R, INV, CH>(v, scratch, tw, ln);
-}
-
+#ifdef MSL_STAMPS
 // The two halves of a four-step transform (diagnostic build of the transposing pass: phase timing per half):
 // head = first register FFT and the inter-FFT twiddles (no scratch access), tail = lane<->register transpose through the
 // scratch and the second register FFT.
@@ -257,6 +195,7 @@ __device__ __forceinline__ void fourstep_tail(float2 (&v)[R], float2* scratch2, 
     }
     fft_regs<R, INV>(v);
 }
+#endif  // MSL_STAMPS
 
 struct RowJob {
     float2* psi;            // (P, nx, pitch) working waves, rows contiguous
@@ -288,54 +227,8 @@ __device__ __forceinline__ long long frame_off(const Job& job, int p) {
     return (long long)f * job.t_stride;
 }
 
-// Row pass.  Workgroup = 256 threads = 256/R lines per iteration, persistent over line groups.
-// Line-group order is x-major, probe-minor, so the t_z rows one group needs are being read by the
-// neighbouring workgroups (other probes, same x) at the same time and stay in L2.
-template <int R>
-__global__ void __launch_bounds__(256, R == 32 ? 3 : 4) row_pass_kernel(RowJob job) {
-    constexpr int N = R * R;
-    constexpr int G = 256 / R;                       // lines per workgroup iteration
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float2* tw = reinterpret_cast<float2*>(smem_raw);                 // N float2
-    float* scratch_all = reinterpret_cast<float*>(tw + N);            // G * R*(R+1) floats
-    const int tid = threadIdx.x;
-    for (int i = tid; i < N; i += 256) tw[i] = job.tw[i];
-    __syncthreads();
-    const int grp = tid / R, ln = tid % R;
-    float* scratch = scratch_all + grp * (R * (R + 1));
-    const int xgroups = job.nx / G;
-    // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 share an L2).  Give each XCD whole
-    // x-groups (all probes of the same rows) so a t_z row is fetched into one L2 once instead of into all 8.
-    const bool xcd_map = (xgroups % 8 == 0) && (gridDim.x % 8 == 0);
-    const long long n_groups = xcd_map ? (long long)(xgroups / 8) * job.n_images : (long long)xgroups * job.n_images;
-    const long long g0 = xcd_map ? blockIdx.x / 8 : blockIdx.x;
-    const long long gstep = xcd_map ? gridDim.x / 8 : gridDim.x;
-    for (long long g = g0; g < n_groups; g += gstep) {
-        int xg = (int)(g / job.n_images);
-        const int p = (int)(g % job.n_images);
-        if (xcd_map) xg = xg * 8 + (int)(blockIdx.x % 8);
-        const int x = xg * G + grp;
-        float2* row = job.psi + (long long)p * job.image_stride + (long long)x * job.pitch;
-        float2 v[R];
-#pragma unroll
-        for (int j = 0; j < R; ++j) v[j] = row[j * R + ln];
-        if (job.do_ifft) fourstep_split<R, true>(v, scratch, tw, ln);
-        if (job.trans) {
-            const float2* trow = job.trans + frame_off(job, p) + (long long)x * N;
-            mul_table<R, 0, false>(v, trow, ln);
-        }
-        if (job.do_fft) {
-            fourstep_split<R, false>(v, scratch, tw, ln);
-            if (job.py) {
-                mul_table<R, 0, false>(v, job.py, ln);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < R; ++j) row[j * R + ln] = v[j];
-    }
-}
-
-// Row pass, software-pipelined variant.  A work item is (x-group, chunk of `pchunk` probes): the t_z rows
+// Row pass (two-pass loop, stand-alone FFTs), software-pipelined.  Workgroup = 256 threads = 256/R lines per iteration.
+// A work item is (x-group, chunk of `pchunk` probes): the t_z rows
 // of the x-group are loaded once into registers and reused for every probe of the chunk, so t_z costs
 // nx*ny*8*P/pchunk bytes per launch instead of depending on L2 luck.  The next line's wave data (HBM) is
 // in flight while the current one is transformed; Py comes from LDS.  ~230 VGPRs -> 2 waves per SIMD,
@@ -421,7 +314,8 @@ struct ColJob {
     float scale;            // applied at the store (1/(nx ny) of a stand-alone inverse transform)
     float sigma;            // COL_POTENTIAL: t = exp(i sigma V)
     float* out_real;        // COL_POTENTIAL: optional V (same pitch / image stride as `out`)
-    int tparity;            // COL_TPOT: images whose index parity differs from this are stored transposed ...
+    int slice_mod;          // COL_TPOT: slice number of image p = p % slice_mod (several frames' stacks in one launch); 0: p itself
+    int tparity;            // COL_TPOT: images whose slice-number parity differs from this are stored transposed ...
     float2* out_t;          // ... into this separate (n_images, ny, nx) buffer (in-place transposition would race)
     // COL_SHIFT only: k-window in fftshifted coordinates.  Columns [win_c0, win_c0 + win_nc) are transformed (win_nc == 0:
     // all ny), rows [win_x0, win_x0 + win_nx) are stored, both rebased to 0.  win_c0, win_nc and ny/2 are multiples of 16.
@@ -522,7 +416,7 @@ __global__ void __launch_bounds__(COLS * R) col_pass_kernel(ColJob job) {
             if (job.flags & COL_INV) fourstep_c64<R, true>(v, mycol, tw, ln);
             wave_lds_fence();
             const long long pimg = tile / tiles_per_image;
-            tstore = (job.flags & COL_TPOT) && (((int)pimg & 1) != job.tparity);
+            tstore = (job.flags & COL_TPOT) && ((((int)(job.slice_mod > 0 ? pimg % job.slice_mod : pimg)) & 1) != job.tparity);
             if (tstore) {
                 // transposed transmission slice: column (fixed y) is a contiguous line of the (ny, nx) image
                 const int y = tile_col(tile % tiles_per_image) + grp;
@@ -714,7 +608,7 @@ struct RowTJob {
 #define MSL_STAMP(id)
 #endif
 
-template <int R, int LINES, int XCH>
+template <int R, int LINES>
 __global__ void __launch_bounds__(LINES * R, (R == 16) ? 3 : 2) rowT_pass_kernel(RowTJob job) {
     constexpr int N = R * R;
 #ifdef MSL_STAMPS
@@ -723,9 +617,9 @@ __global__ void __launch_bounds__(LINES * R, (R == 16) ? 3 : 2) rowT_pass_kernel
     constexpr int TCH = (R == 32) ? 16 : 8;             // table-multiply chunk (see mul_table)
 #endif
     constexpr int NT = LINES * R;
-    // tile line pitch in float2: the 1024 positions of a line / the exchange scratch, whichever is larger; odd (narrow
-    // exchanges) or 2 mod 32 (wide ones, whose rows must be 16-byte aligned): conflict-free staging either way
-    constexpr int CS = (XCH < 2) ? R * (R + 1) + 1 : ((xch_scratch_float2<R, XCH>() > R * R ? xch_scratch_float2<R, XCH>() : R * R) + 33) / 32 * 32 + 2;
+    // tile line pitch in float2: the R^2 positions of a line (the wave's exchange scratch, R x 68 floats over 64 / R lines, is
+    // smaller); 2 mod 32: rows 16-byte aligned for the exchange's wide reads, conflict-free staging
+    constexpr int CS = (R * R + 33) / 32 * 32 + 2;
     constexpr int TPS = LINES / 2;                    // threads (16 B = 2 lines each) per output segment of LINES*8 bytes
     constexpr int POS_PER_IT = NT / TPS;
     constexpr int NIT = N / POS_PER_IT;
@@ -740,7 +634,7 @@ __global__ void __launch_bounds__(LINES * R, (R == 16) ? 3 : 2) rowT_pass_kernel
     const int grp = tid / R, ln = tid % R;
     const int q = tid % TPS, r0 = tid / TPS;
     float2* myrow = tile + grp * CS;
-    // addtid exchange (XCH == 4): the groups of a wave share the scratch that starts at the first of their tile rows
+    // add-tid exchange: the groups of a wave share the scratch that starts at the first of their tile rows
     const float* wscr = reinterpret_cast<const float*>(tile + (grp - grp % (64 / R)) * CS);
     const unsigned wscr_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(tile + (grp - grp % (64 / R)) * CS));
     const int lblocks = job.n_lines / LINES;
@@ -824,7 +718,7 @@ __global__ void __launch_bounds__(LINES * R, (R == 16) ? 3 : 2) rowT_pass_kernel
         };
         auto tail = [&](auto inv_c) {
             constexpr bool INV = decltype(inv_c)::value;
-            if constexpr (MSL_ABL & 4) fft_regs<R, INV>(v); else fourstep_tail<R, INV, (XCH & 1) != 0>(v, myrow, ln);
+            if constexpr (MSL_ABL & 4) fft_regs<R, INV>(v); else fourstep_tail<R, INV, false>(v, myrow, ln);
         };
         auto mulp = [&]() {
             if constexpr (MSL_ABL & 8) {
@@ -852,23 +746,23 @@ __global__ void __launch_bounds__(LINES * R, (R == 16) ? 3 : 2) rowT_pass_kernel
         pf(MSL_IC(24), MSL_IC(32)); MSL_STAMP(17);
 #else
         if (job.flags & P2_PRE_A) {
-            { if constexpr (XCH == 4) fourstep_split_addtid<R, false, TCH>(v, wscr, wscr_lds, tw, ln, tid & 63); else fourstep_x<R, false, XCH, TCH>(v, myrow, tw, ln); }
+            fourstep_split_addtid<R, false, TCH>(v, wscr, wscr_lds, tw, ln, tid & 63);
         }
         prefetch_part(MSL_IC(0), MSL_IC(8));
         if (job.flags & P2_PRE_A) {
             mul_table<R, 0, false, R, TCH>(v, pl, ln);
-            { if constexpr (XCH == 4) fourstep_split_addtid<R, true, TCH>(v, wscr, wscr_lds, tw, ln, tid & 63); else fourstep_x<R, true, XCH, TCH>(v, myrow, tw, ln); }
+            fourstep_split_addtid<R, true, TCH>(v, wscr, wscr_lds, tw, ln, tid & 63);
         }
         prefetch_part(MSL_IC(8), MSL_IC(16));
 #pragma unroll
         for (int j = 0; j < R; ++j) v[j] = cmulf(v[j], tv[j]);
         if (job.flags & P2_POST_A) {
-            { if constexpr (XCH == 4) fourstep_split_addtid<R, false, TCH>(v, wscr, wscr_lds, tw, ln, tid & 63); else fourstep_x<R, false, XCH, TCH>(v, myrow, tw, ln); }
+            fourstep_split_addtid<R, false, TCH>(v, wscr, wscr_lds, tw, ln, tid & 63);
         }
         prefetch_part(MSL_IC(16), MSL_IC(24));
         if (job.flags & P2_POST_A) {
             mul_table<R, 0, false, R, TCH>(v, pl, ln);
-            { if constexpr (XCH == 4) fourstep_split_addtid<R, true, TCH>(v, wscr, wscr_lds, tw, ln, tid & 63); else fourstep_x<R, true, XCH, TCH>(v, myrow, tw, ln); }
+            fourstep_split_addtid<R, true, TCH>(v, wscr, wscr_lds, tw, ln, tid & 63);
         }
         prefetch_part(MSL_IC(24), MSL_IC(32));
 #endif
@@ -904,339 +798,34 @@ __global__ void __launch_bounds__(LINES * R, (R == 16) ? 3 : 2) rowT_pass_kernel
 #endif
 }
 
-// ---- transposing pass on PAIRED lines: two independent workgroups per CU ----------------------------------------
-// rowT_pass_kernel needs 16 lines per tile for 128-byte transposed segments, i.e. one 512-thread workgroup per CU whose
-// 8 waves run in lockstep: they all issue their loads, transpose through the LDS, store and wait at the barriers at the
-// same time, and the phase timeline (tools/rowt_timeline.hip) shows a wave computing only ~60% of its life.  Here the
-// work buffers between two passes hold the lines in PAIRS: element e of line L lives at
-//     (L/2) * (2*pitch) + 2*e + (L & 1)                                 [float2 units]
-// so the two lines of a pair are interleaved element by element.  Reading is as coalesced as before (the two 32-lane groups
-// of a wave take the two lines of a pair: one load instruction covers 512 contiguous bytes), and a transposed segment of
-// 128 bytes now consists of TWO neighbouring positions of EIGHT lines -- the tile shrinks to 8 lines (66 KB), a workgroup
-// to 256 threads, and two workgroups fit a CU (2 x 80 KB of LDS, 2 x 4 waves x 256 VGPRs).  They are independent: while
-// one waits for memory or at its barrier the other one has the SIMDs to itself.  Only the passes between two transposing
-// passes use the layout; the first pass reads and the last one writes the natural layout (IN_P / OUT_P), so probes, the
-// final in-place pass and the exit FFT are untouched.  The Fresnel table is symmetric, P[m] = P[N - m], and only its
-// first N/2 + 1 entries are kept in the LDS to make the two workgroups fit.
-template <int R, bool IN_P, bool OUT_P>
-__global__ void __launch_bounds__(8 * R, 2) rowTP_pass_kernel(RowTJob job) {
-    static_assert(R == 32, "1024-point lines");
-    constexpr int N = R * R, LINES = 8, NT = LINES * R, TCH = 8;
-    constexpr int CS = R * (R + 1) + 1;               // tile line pitch (odd: conflict-free staging), also the transpose scratch
-    constexpr int NH = N / 2 + 2;                     // stored part of the symmetric propagator table (+1 pad)
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float2* tw = reinterpret_cast<float2*>(smem_raw);
-    float2* plh = tw + N;
-    float2* tile = plh + NH;                          // LINES * CS
-    const int tid = threadIdx.x;
-    for (int i = tid; i < N; i += NT) tw[i] = job.tw[i];
-    for (int i = tid; i <= N / 2; i += NT) plh[i] = job.pl[i];
-    __syncthreads();
-    const int grp = tid / R, ln = tid % R;
-    float2* myrow = tile + grp * CS;
-    const float2* pa = plh + ln;                      // P[j R + ln],           j <  R/2
-    const float2* pb = plh - ln;                      // P[N - (j R + ln)] = plh[(R - j) R - ln],  j >= R/2
-    auto mul_p = [&](float2 (&vv)[R]) {
-#pragma unroll
-        for (int c = 0; c < R; c += TCH) {
-            float2 w[TCH];
-#pragma unroll
-            for (int j = 0; j < TCH; ++j) w[j] = (c + j < R / 2) ? pa[(c + j) * R] : pb[(R - (c + j)) * R];
-#pragma unroll
-            for (int j = 0; j < TCH; ++j) vv[c + j] = cmulf(vv[c + j], w[j]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    const int lblocks = job.n_lines / LINES;
-    const int PC = job.pchunk;
-    const int pchunks = (job.n_images + PC - 1) / PC;
-    const int n_items = lblocks * pchunks;
-    const int step_lb = (int)gridDim.x / pchunks, step_pc = (int)gridDim.x % pchunks;
-    // element e of this thread's line: base[e * ES]
-    constexpr int ES = IN_P ? 2 : 1;
-    auto line_ptr = [&](int lbb, int pcc, int kk) {
-        const int L = lbb * LINES + grp;
-        const long long off = IN_P ? (long long)(L >> 1) * (2 * job.in_pitch) + (L & 1) : (long long)L * job.in_pitch;
-        return job.in + (long long)(pcc * PC + kk) * job.in_image_stride + off + ln * ES;
-    };
-    int item = blockIdx.x;
-    int lb = item / pchunks, pc = item - lb * pchunks, k = 0;
-    float2 vn[R];
-    if (item < n_items) {
-        const float2* r = line_ptr(lb, pc, 0);
-#pragma unroll
-        for (int j = 0; j < R; ++j) vn[j] = ld_stream(r + (j * R * ES));
-    }
-    float2 tv[R];
-    while (item < n_items) {
-        float2 v[R];
-#pragma unroll
-        for (int j = 0; j < R; ++j) v[j] = vn[j];
-        const int p = pc * PC + k;
-        const int cur_lb = lb;
-        if (k == 0) {
-            const float2* trow = job.trans + frame_off(job, pc * PC) + (long long)(lb * LINES + grp) * N;
-#pragma unroll
-            for (int j = 0; j < R; ++j) tv[j] = trow[j * R + ln];
-        }
-        int nitem = item, nlb = lb, npc = pc, nk = k + 1;
-        if (nk >= min(PC, job.n_images - pc * PC)) {
-            nk = 0; nitem = item + (int)gridDim.x; nlb = lb + step_lb; npc = pc + step_pc;
-            if (npc >= pchunks) { npc -= pchunks; ++nlb; }
-        }
-        auto prefetch_part = [&](auto lo_c, auto hi_c) {
-            constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
-            __builtin_amdgcn_sched_barrier(0);
-            if (nitem < n_items) {
-                const float2* r = line_ptr(nlb, npc, nk);
-#pragma unroll
-                for (int j = LO; j < HI; ++j) vn[j] = ld_stream(r + (j * R * ES));
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        if (job.flags & P2_PRE_A) fourstep_split<R, false, TCH>(v, reinterpret_cast<float*>(myrow), tw, ln);
-        prefetch_part(MSL_IC(0), MSL_IC(8));
-        if (job.flags & P2_PRE_A) {
-            mul_p(v);
-            fourstep_split<R, true, TCH>(v, reinterpret_cast<float*>(myrow), tw, ln);
-        }
-        prefetch_part(MSL_IC(8), MSL_IC(16));
-#pragma unroll
-        for (int j = 0; j < R; ++j) v[j] = cmulf(v[j], tv[j]);
-        if (job.flags & P2_POST_A) fourstep_split<R, false, TCH>(v, reinterpret_cast<float*>(myrow), tw, ln);
-        prefetch_part(MSL_IC(16), MSL_IC(24));
-        if (job.flags & P2_POST_A) {
-            mul_p(v);
-            fourstep_split<R, true, TCH>(v, reinterpret_cast<float*>(myrow), tw, ln);
-        }
-        prefetch_part(MSL_IC(24), MSL_IC(32));
-        wave_lds_fence();
-#pragma unroll
-        for (int j = 0; j < R; ++j) myrow[j * R + ln] = v[j];
-        lds_barrier();
-        if constexpr (OUT_P) {
-            // segment = positions (2 mm, 2 mm + 1) of the tile's 8 lines = 128 contiguous bytes of the paired output; thread =
-            // (line i, pair mm).  The four octets of a half-wave take pairs 4 apart: with the odd line pitch their LDS reads
-            // then fall into different banks.
-            const int i = tid & 7, oct = tid >> 3, q = oct & 3, hh = oct >> 2;
-            const int mm0 = (hh & 3) + 4 * q + 16 * (hh >> 2);
-            const float2* src = tile + i * CS + 2 * mm0;
-            float2* dst = job.out + (long long)p * job.out_image_stride + 2 * (cur_lb * LINES + i);
-            int off0 = mm0 * 2 * job.out_pitch;
-            asm volatile("" : "+v"(off0));
-            const int ostep = 32 * 2 * job.out_pitch;
-#pragma unroll
-            for (int it = 0; it < N / 2 / 32; ++it) {
-                const float2 a = src[it * 64], b = src[it * 64 + 1];
-                st_stream(dst + (off0 + it * ostep), a.x, a.y, b.x, b.y);
-            }
-        } else {
-            // natural output (last transposing pass): out[e][L], 8 lines = 64-byte segments, thread = (position e, two lines)
-            const int q4 = tid & 3, e0 = tid >> 2;
-            float2* dst = job.out + (long long)p * job.out_image_stride + cur_lb * LINES + 2 * q4;
-            int off0 = e0 * job.out_pitch;
-            asm volatile("" : "+v"(off0));
-            const int ostep = (NT / 4) * job.out_pitch;
-#pragma unroll
-            for (int it = 0; it < N / (NT / 4); ++it) {
-                const int e = e0 + (NT / 4) * it;
-                const float2 a = tile[(2 * q4) * CS + e], b = tile[(2 * q4 + 1) * CS + e];
-                st_stream(dst + (off0 + it * ostep), a.x, a.y, b.x, b.y);
-            }
-        }
-        lds_barrier();
-        item = nitem; lb = nlb; pc = npc; k = nk;
-    }
-}
-
-// ---- 1024-point lines, THREE workgroups per CU ------------------------------------------------------------------------------
-// The ablations of tools/rowt_timeline.hip put the floor of the transposing pass at the VALU pipe (175 us per 1024^2 x 64
-// pass at two waves per SIMD, pipe saturated) with LDS and memory time added on top almost in full, because two waves per SIMD
-// leave nothing to issue while one of them waits.  This variant trades registers for occupancy: 8-line tiles in the
-// paired-lines layout (see rowTP_pass_kernel), stored in TWO position halves so that a tile row is 4.2 KB (just the transpose
-// scratch), t_k re-read from L2 per probe instead of held in 64 registers, and only the first half of the next line prefetched
-// into registers (the second half is loaded straight into the registers of the line being retired, after they have gone to the
-// tile).  46 KB of LDS and <= 168 VGPRs per 256-thread workgroup: three independent workgroups = three waves per SIMD.
-template <bool IN_P, bool OUT_P>
-__global__ void __launch_bounds__(256, 3) rowT3_pass_kernel(RowTJob job) {
-    constexpr int R = 32, N = R * R, LINES = 8, NT = LINES * R, TCH = 8, H = R / 2;
-    constexpr int RS = R * (R + 1) / 2 + 1;           // tile row in float2: the transpose scratch (R(R+1) floats), >= N/2 positions, odd
-    constexpr int NH = N / 2 + 2;
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float2* tw = reinterpret_cast<float2*>(smem_raw);
-    float2* plh = tw + N;
-    float2* tile = plh + NH;                          // LINES * RS
-    const int tid = threadIdx.x;
-    for (int i = tid; i < N; i += NT) tw[i] = job.tw[i];
-    for (int i = tid; i <= N / 2; i += NT) plh[i] = job.pl[i];
-    __syncthreads();
-    const int grp = tid / R, ln = tid % R;
-    float2* myrow = tile + grp * RS;
-    const float2* pa = plh + ln;
-    const float2* pb = plh - ln;
-    auto mul_p = [&](float2 (&vv)[R]) {
-#pragma unroll
-        for (int c = 0; c < R; c += TCH) {
-            float2 w[TCH];
-#pragma unroll
-            for (int j = 0; j < TCH; ++j) w[j] = (c + j < R / 2) ? pa[(c + j) * R] : pb[(R - (c + j)) * R];
-#pragma unroll
-            for (int j = 0; j < TCH; ++j) vv[c + j] = cmulf(vv[c + j], w[j]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    const int lblocks = job.n_lines / LINES;
-    const int PC = job.pchunk;
-    const int pchunks = (job.n_images + PC - 1) / PC;
-    const int n_items = lblocks * pchunks;
-        constexpr int ES = IN_P ? 2 : 1;
-    auto line_ptr = [&](int lbb, int pcc, int kk) {
-        int lnx = tid;                                // per-thread part re-derived (register limit)
-        asm volatile("" : "+v"(lnx));
-        const int L = lbb * LINES + lnx / R;
-        const long long off = IN_P ? (long long)(L >> 1) * (2 * job.in_pitch) + (L & 1) : (long long)L * job.in_pitch;
-        return job.in + (long long)(pcc * PC + kk) * job.in_image_stride + off + (lnx % R) * ES;
-    };
-    // Workgroups are dealt round-robin over the 8 XCDs: give every XCD a contiguous eighth of the items (line-block major),
-    // so that the t_k lines a workgroup re-reads per probe stay in ITS L2 (1 MB of the 8 MB slice per XCD)
-    // (with a grid that is a multiple of 8 a workgroup's items are an arithmetic sequence again: the cursor stays incremental)
-    const bool xmap = (n_items % 8 == 0) && (gridDim.x % 8 == 0);
-    const int istep = xmap ? (int)gridDim.x / 8 : (int)gridDim.x;
-    const int step_lb = istep / pchunks, step_pc = istep % pchunks;
-    int vitem = blockIdx.x;
-    int item = xmap ? (int)(blockIdx.x & 7) * (n_items >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-    int lb = item / pchunks, pc = item - lb * pchunks, k = 0;
-    float2 vn[H];
-    float2 v[R];
-    if (vitem < n_items) {
-        const float2* r = line_ptr(lb, pc, 0);
-#pragma unroll
-        for (int j = 0; j < H; ++j) vn[j] = ld_stream(r + (j * R * ES));
-#pragma unroll
-        for (int j = H; j < R; ++j) v[j] = r[j * R * ES];
-    }
-    while (vitem < n_items) {
-#pragma unroll
-        for (int j = 0; j < H; ++j) v[j] = vn[j];
-        const int p = pc * PC + k;
-        const int cur_lb = lb;
-        int nvitem = vitem, nitem = item, nlb = lb, npc = pc, nk = k + 1;
-        if (nk >= min(PC, job.n_images - pc * PC)) {
-            nk = 0; nvitem = vitem + (int)gridDim.x; nitem = nvitem < n_items ? item + istep : n_items;
-            nlb = lb + step_lb; npc = pc + step_pc;
-            if (npc >= pchunks) { npc -= pchunks; ++nlb; }
-        }
-        auto prefetch_part = [&](auto lo_c, auto hi_c) {
-            constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
-            __builtin_amdgcn_sched_barrier(0);
-            if (nitem < n_items) {
-                const float2* r = line_ptr(nlb, npc, nk);
-#pragma unroll
-                for (int j = LO; j < HI; ++j) vn[j] = ld_stream(r + (j * R * ES));
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        float* scr = reinterpret_cast<float*>(myrow);
-        if (job.flags & P2_PRE_A) fourstep_split<R, false, TCH>(v, scr, tw, ln);
-        prefetch_part(MSL_IC(0), MSL_IC(4));
-        if (job.flags & P2_PRE_A) {
-            mul_p(v);
-            fourstep_split<R, true, TCH>(v, scr, tw, ln);
-        }
-        prefetch_part(MSL_IC(4), MSL_IC(8));
-        {
-            int lnx = tid;
-            asm volatile("" : "+v"(lnx));
-            lnx = (lnx / R) * N + (lnx % R);
-            mul_table<R, 0, false, R, TCH>(v, job.trans + frame_off(job, p) + (long long)cur_lb * LINES * N, lnx);
-        }
-        if (job.flags & P2_POST_A) fourstep_split<R, false, TCH>(v, scr, tw, ln);
-        prefetch_part(MSL_IC(8), MSL_IC(12));
-        if (job.flags & P2_POST_A) {
-            mul_p(v);
-            fourstep_split<R, true, TCH>(v, scr, tw, ln);
-        }
-        prefetch_part(MSL_IC(12), MSL_IC(16));
-        // transposed store in two position halves: registers [0, R/2) = positions [0, N/2), then the rest
-#pragma unroll
-        for (int ph = 0; ph < 2; ++ph) {
-            wave_lds_fence();
-#pragma unroll
-            for (int j = 0; j < H; ++j) myrow[j * R + ln] = v[ph * H + j];
-            if (ph == 1) {
-                // the line has left the registers: the second half of the NEXT line goes straight into them
-                __builtin_amdgcn_sched_barrier(0);
-                if (nitem < n_items) {
-                    const float2* r = line_ptr(nlb, npc, nk);
-#pragma unroll
-                    for (int j = H; j < R; ++j) v[j] = r[j * R * ES];
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            lds_barrier();
-            if constexpr (OUT_P) {
-                const int i = tid & 7, oct = tid >> 3, q = oct & 3, hh = oct >> 2;
-                const int mm0 = (hh & 3) + 4 * q + 16 * (hh >> 2);
-                const float2* src = tile + i * RS + 2 * mm0;
-                float2* dst = job.out + (long long)p * job.out_image_stride + 2 * (cur_lb * LINES + i);
-                int off0 = (ph * (N / 4) + mm0) * 2 * job.out_pitch;
-                asm volatile("" : "+v"(off0));
-                const int ostep = 32 * 2 * job.out_pitch;
-#pragma unroll
-                for (int it = 0; it < N / 4 / 32; ++it) {
-                    const float2 a = src[it * 64], b = src[it * 64 + 1];
-                    st_stream(dst + (off0 + it * ostep), a.x, a.y, b.x, b.y);
-                }
-            } else {
-                const int q4 = tid & 3, e0 = tid >> 2;
-                float2* dst = job.out + (long long)p * job.out_image_stride + cur_lb * LINES + 2 * q4;
-                int off0 = (ph * (N / 2) + e0) * job.out_pitch;
-                asm volatile("" : "+v"(off0));
-                const int ostep = (NT / 4) * job.out_pitch;
-#pragma unroll
-                for (int it = 0; it < N / 2 / (NT / 4); ++it) {
-                    const int e = e0 + (NT / 4) * it;
-                    const float2 a = tile[(2 * q4) * RS + e], b = tile[(2 * q4 + 1) * RS + e];
-                    st_stream(dst + (off0 + it * ostep), a.x, a.y, b.x, b.y);
-                }
-            }
-            lds_barrier();
-        }
-        vitem = nvitem; item = nitem; lb = nlb; pc = npc; k = nk;
-    }
-}
-
-// ---- lines of ANY length N <= R^2/2: Bluestein's chirp-z transform on the register FFTs -------------------------------------
+// ---- lines of ANY length N <= R^2/2: propagation as a zero-padded cyclic convolution on the register FFTs -------------------------
 // The reference's grids are n = int(L/sampling) + 1 points (potentials.py:123-125; its own probe test uses 501 x 491,
 // src/unittests/00_probe.py:7-8), almost never a power of two.  The generic LDS Stockham kernel (fft_generic.h) serves them at
 // 0.1 of the roofline: every radix stage is a round trip of the whole tile through the LDS between two barriers.  Here a line of
-// N points is embedded, zero-padded, in the M = R^2 point register layout of the power-of-two kernels (element n = reg R + lane)
-// and every N-point DFT is the chirp-z convolution
-//     fft_N(x)[k] = w[k] . IFFT_M( FFT_M(pad(x w)) . Bf )[k],     w[n] = exp(-i pi n^2 / N),   Bf = FFT_M(conj w, wrapped) / M
-// (M >= 2N - 1), the inverse the same with conjugated chirp and filter (Bf is even, so FFT/IFFT order is immaterial).  One pass
-// A . t_k . A,  A = ifft_N P fft_N,  is 8 register FFTs of length M and 11 table multiplies per line -- twice the work of a line
-// of the 1024-point kernel, which is the price of ANY length: a 501 x 491 grid runs at the speed of a 1024 x 1024 one instead of
-// 3.5 x slower.  Inside A the chirps cancel (w P conj w = P); entries beyond N, which hold wrapped-around convolution terms, are
-// zeroed by the zero padding of the P and chirp tables.  Everything else -- prefetch of the next line, t_k in registers across
-// a chunk of probes, 16-line tile, 128-byte transposed segments -- is rowT_pass_kernel's.  The number of lines need not be a
-// multiple of 16: the last tile re-reads the last line and its surplus columns land in the row padding of the output
-// (pitch >= n_lines rounded up to 16), which no pass reads.
-template <int R, bool CONV>
+// N points is embedded, zero-padded, in the M = R^2 point register layout of the power-of-two kernels (element n = reg R + lane).
+// Inside the slice loop the N-point spectrum is never needed: A = ifft_N . P . fft_N is a circular convolution of length N with
+// the fixed kernel a = ifft_N(P), and on the zero-padded line that is ONE cyclic convolution of length M >= 2N - 1 with
+// q[j] = a[j], q[M - j] = a[N - j] (0 < j < N):  A x = IFFT_M(FFT_M(pad x) . Q)[0:N],  Q = FFT_M(q) / M (built in float64 on the
+// host; symmetric, Q[M - k] = Q[k], so its first half is stored).  One pass A . t_k . A is four register FFTs of length M and
+// three table products per line, for ANY length: a 501 x 491 grid runs at the speed of a 1024 x 1024 one instead of 3.5 x slower.
+// (Round 2's first form evaluated every N-point DFT by Bluestein's chirp-z -- eight FFTs and eleven products per pass; the
+// chirp-z tables live on in the potential's inverse transform, ifftTB_kernel, which does need the spectrum.)
+// Everything else -- prefetch of the next line, t_k in registers across a chunk of probes, 16-line tile, 128-byte transposed
+// segments -- is rowT_pass_kernel's.  The number of lines need not be a multiple of 16: the last tile re-reads the last line and
+// its surplus columns land in the row padding of the output (pitch >= n_lines rounded up to 16), which no pass reads.
+template <int R>
 __global__ void __launch_bounds__(16 * R, (R == 32) ? 2 : 4) rowTB_pass_kernel(RowTJob job) {
     constexpr int M = R * R, H = R / 2, NH = M / 2, LINES = 16, NT = LINES * R, TCH = 8;
     constexpr int CS = R * (R + 1) + 2;               // even (16-byte aligned rows for the wide exchange), conflict-free staging
     constexpr int TPS = LINES / 2, POS_PER_IT = NT / TPS, NIT = NH / POS_PER_IT;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float2* tw = reinterpret_cast<float2*>(smem_raw);         // M: four-step twiddles
-    float2* bf = tw + M;                                      // NH + 2: filter, first half
-    float2* bp = bf + NH + 2;                                 // NH: Fresnel factor (1/N folded in), zero beyond N   (chirp-z form only)
-    float2* bw = bp + NH;                                     // NH: chirp, zero beyond N                           (chirp-z form only)
-    float2* tile = CONV ? bp : bw + NH;                       // LINES * CS
+    float2* bf = tw + M;                                      // NH + 2: filter Q, first half
+    float2* tile = bf + NH + 2;                               // LINES * CS
     const int tid = threadIdx.x;
     const int N = job.n_line;
     for (int i = tid; i < M; i += NT) tw[i] = job.tw[i];
     for (int i = tid; i <= NH; i += NT) bf[i] = job.bf[i];
-    if constexpr (!CONV) { for (int i = tid; i < NH; i += NT) { bp[i] = job.pl[i]; bw[i] = job.bw[i]; } }
     __syncthreads();
     const int grp = tid / R, ln = tid % R;
     const int q = tid % TPS, r0 = tid / TPS;
@@ -1246,32 +835,16 @@ __global__ void __launch_bounds__(16 * R, (R == 32) ? 2 : 4) rowTB_pass_kernel(R
     const unsigned wscr_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(tile + (grp - grp % (64 / R)) * CS));
     const float2* fa = bf + ln;                               // Bf[j R + ln],                      j <  R/2
     const float2* fb = bf - ln;                               // Bf[M - (j R + ln)] = bf[(R - j) R - ln],  j >= R/2
-    auto mul_filter = [&](float2 (&vv)[R], auto conj_c) {
-        constexpr bool CONJ = decltype(conj_c)::value;
+    auto mul_filter = [&](float2 (&vv)[R]) {
 #pragma unroll
         for (int c = 0; c < R; c += TCH) {
             float2 w[TCH];
 #pragma unroll
             for (int j = 0; j < TCH; ++j) w[j] = (c + j < H) ? fa[(c + j) * R] : fb[(R - (c + j)) * R];
 #pragma unroll
-            for (int j = 0; j < TCH; ++j) vv[c + j] = CONJ ? cmulf_conj(vv[c + j], w[j]) : cmulf(vv[c + j], w[j]);
+            for (int j = 0; j < TCH; ++j) vv[c + j] = cmulf(vv[c + j], w[j]);
             __builtin_amdgcn_sched_barrier(0);
         }
-    };
-    // v[j] *= tab[j R + ln] (conjugated when CONJ) for the R/2 registers that can hold line elements; the rest is padding: zero
-    auto mul_half = [&](float2 (&vv)[R], const float2* tab, auto conj_c) {
-        constexpr bool CONJ = decltype(conj_c)::value;
-#pragma unroll
-        for (int c = 0; c < H; c += TCH) {
-            float2 w[TCH];
-#pragma unroll
-            for (int j = 0; j < TCH; ++j) w[j] = tab[(c + j) * R + ln];
-#pragma unroll
-            for (int j = 0; j < TCH; ++j) vv[c + j] = CONJ ? cmulf_conj(vv[c + j], w[j]) : cmulf(vv[c + j], w[j]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int j = H; j < R; ++j) vv[j] = make_float2(0.f, 0.f);
     };
     const int lblocks = (job.n_lines + LINES - 1) / LINES;
     const int PC = job.pchunk;
@@ -1319,52 +892,22 @@ __global__ void __launch_bounds__(16 * R, (R == 32) ? 2 : 4) rowTB_pass_kernel(R
             }
             __builtin_amdgcn_sched_barrier(0);
         };
-        // A = ifft_N . P . fft_N on the zero-padded line
-        auto a_first = [&]() {
-            mul_half(v, bw, std::false_type{});
-            fourstep_split_addtid<R, false, TCH>(v, wscr, wscr_lds, tw, ln, tid & 63);
-            mul_filter(v, std::false_type{});
-            fourstep_split_addtid<R, true, TCH>(v, wscr, wscr_lds, tw, ln, tid & 63);
-        };
-        auto a_second = [&]() {
-            mul_half(v, bp, std::false_type{});
-            fourstep_split_addtid<R, false, TCH>(v, wscr, wscr_lds, tw, ln, tid & 63);
-            mul_filter(v, std::true_type{});
-            fourstep_split_addtid<R, true, TCH>(v, wscr, wscr_lds, tw, ln, tid & 63);
-            mul_half(v, bw, std::true_type{});
-        };
-        // CONV: A = ifft_N . P . fft_N is a circular convolution of length N with the fixed kernel a = ifft_N(P); on the
-        // zero-padded line it is ONE cyclic convolution of length M >= 2N - 1 with q[j] = a[j], q[M - j] = a[N - j] (0 < j < N):
-        // two M-point FFTs and one filter product (bf = FFT_M(q) / M, symmetric like the chirp filter) instead of the chirp-z
-        // form's four FFTs and five products.  The N-point spectrum itself is never needed inside the slice loop.
+        // A = ifft_N . P . fft_N as one cyclic convolution of length M: two M-point FFTs and the filter product
         auto a_conv = [&]() {
             fourstep_split_addtid<R, false, TCH>(v, wscr, wscr_lds, tw, ln, tid & 63);
-            mul_filter(v, std::false_type{});
+            mul_filter(v);
             fourstep_split_addtid<R, true, TCH>(v, wscr, wscr_lds, tw, ln, tid & 63);
 #pragma unroll
             for (int j = 0; j < H; ++j) if (j * R + ln >= N) v[j] = make_float2(0.f, 0.f);    // keep outputs 0 .. N-1: the padding stays zero
 #pragma unroll
             for (int j = H; j < R; ++j) v[j] = make_float2(0.f, 0.f);
         };
-        if constexpr (CONV) {
-            if (job.flags & P2_PRE_A) a_conv();
-            prefetch_part(MSL_IC(0), MSL_IC(H / 2));
-#pragma unroll
-            for (int j = 0; j < H; ++j) v[j] = cmulf(v[j], tv[j]);
-            if (job.flags & P2_POST_A) a_conv();
-            prefetch_part(MSL_IC(H / 2), MSL_IC(H));
-        } else {
-        if (job.flags & P2_PRE_A) a_first();
-        prefetch_part(MSL_IC(0), MSL_IC(H / 4));
-        if (job.flags & P2_PRE_A) a_second();
-        prefetch_part(MSL_IC(H / 4), MSL_IC(H / 2));
+        if (job.flags & P2_PRE_A) a_conv();
+        prefetch_part(MSL_IC(0), MSL_IC(H / 2));
 #pragma unroll
         for (int j = 0; j < H; ++j) v[j] = cmulf(v[j], tv[j]);
-        if (job.flags & P2_POST_A) a_first();
-        prefetch_part(MSL_IC(H / 2), MSL_IC(3 * H / 4));
-        if (job.flags & P2_POST_A) a_second();
-        prefetch_part(MSL_IC(3 * H / 4), MSL_IC(H));
-        }
+        if (job.flags & P2_POST_A) a_conv();
+        prefetch_part(MSL_IC(H / 2), MSL_IC(H));
         wave_lds_fence();
 #pragma unroll
         for (int j = 0; j < H; ++j) myrow[j * R + ln] = v[j];
@@ -1386,7 +929,7 @@ __global__ void __launch_bounds__(16 * R, (R == 32) ? 2 : 4) rowTB_pass_kernel(R
     }
 }
 
-// ---- 2048-point register FFT, one wave per line; lines of any length 513..1024 by chirp-z on it ------------------------------
+// ---- 2048-point register FFT, one wave per line; lines of any length 513..1024 by the cyclic convolution on it ------------------------------
 // A line of M = 2048 points in ONE wave: 64 lanes x 32 registers, element index = reg * 64 + lam(lane), where
 //     lam(L) = 32 (L & 1) + (L >> 1)
 // spreads the logical positions over the physical lanes so that the two lanes that share a 64-point sub-transform are
@@ -1471,10 +1014,12 @@ __device__ __forceinline__ void fft2048_wave(float2 (&v)[32], float* scr, const 
     }
 }
 
-// Transposing pass A . t_k . A for lines of any length 513 <= N <= 1024: rowTB_pass_kernel's chirp-z scheme on fft2048_wave.
-// One wave per line, 8 lines per workgroup; between two of these passes the work buffers are in the paired-lines layout (see
-// rowTP_pass_kernel), so that a transposed 128-byte segment is two positions of the tile's eight lines.
-template <bool IN_P, bool OUT_P, bool CONV>
+// Transposing pass A . t_k . A for lines of any length 513 <= N <= 1024: rowTB_pass_kernel's convolution scheme on fft2048_wave (M = 2048).
+// One wave per line, 8 lines per workgroup.  IN_P / OUT_P: the PAIRED-LINES layout of a work buffer between two such passes --
+// element e of line L at (L/2) * (2 * pitch) + 2 * e + (L & 1) [float2 units], the two lines of a pair interleaved element by
+// element -- in which a transposed 128-byte segment is two neighbouring positions of the tile's eight lines (in the natural
+// layout eight lines give 64-byte runs).  Reading stays coalesced (a wave's load covers 512 contiguous bytes of its pair).
+template <bool IN_P, bool OUT_P>
 __global__ void __launch_bounds__(512, 2) rowTB2_pass_kernel(RowTJob job) {
     constexpr int R = 32, M = 2048, H = 16, NH = M / 2, LINES = 8, NT = 512, TCH = 8;
     constexpr int RS = (R * W2K_PITCH) / 2 + 1;        // tile row in float2 (1553: the transpose scratch; >= NH positions; = 17 mod 32)
@@ -1482,15 +1027,12 @@ __global__ void __launch_bounds__(512, 2) rowTB2_pass_kernel(RowTJob job) {
     float2* tw = reinterpret_cast<float2*>(smem_raw);         // 2048
     float2* w64 = tw + M;                                     // 64
     float2* bf = w64 + 64;                                    // NH + 2
-    float2* bp = bf + NH + 2;                                 // NH
-    float2* bw = bp + NH;                                     // NH
-    float2* tile = CONV ? bp : bw + NH;                       // LINES * RS  (the convolution form needs neither P nor the chirp)
+    float2* tile = bf + NH + 2;                               // LINES * RS
     const int tid = threadIdx.x;
     const int N = job.n_line;
     for (int i = tid; i < M; i += NT) tw[lds_pos64(i)] = job.tw[i];
     if (tid < 64) w64[tid] = job.tw2[tid];
     for (int i = tid; i <= NH; i += NT) bf[i] = job.bf[i];
-    if constexpr (!CONV) { for (int i = tid; i < NH; i += NT) { bp[i] = job.pl[i]; bw[i] = job.bw[i]; } }
     __syncthreads();
     const int wv = tid >> 6, L = tid & 63, la = lam64(L);
     const float sgn = (L & 1) ? -1.f : 1.f;
@@ -1498,31 +1040,16 @@ __global__ void __launch_bounds__(512, 2) rowTB2_pass_kernel(RowTJob job) {
     float* scr = reinterpret_cast<float*>(myrow);
     const float2* fa = bf + la;                               // Bf[64 j + la],              j < 16
     const float2* fb = bf - la;                               // Bf[M - (64 j + la)] = bf[64 (32 - j) - la],  j >= 16
-    auto mul_filter = [&](float2 (&vv)[R], auto conj_c) {
-        constexpr bool CONJ = decltype(conj_c)::value;
+    auto mul_filter = [&](float2 (&vv)[R]) {
 #pragma unroll
         for (int c = 0; c < R; c += TCH) {
             float2 w[TCH];
 #pragma unroll
             for (int j = 0; j < TCH; ++j) w[j] = (c + j < H) ? fa[(c + j) * 64] : fb[(R - (c + j)) * 64];
 #pragma unroll
-            for (int j = 0; j < TCH; ++j) vv[c + j] = CONJ ? cmulf_conj(vv[c + j], w[j]) : cmulf(vv[c + j], w[j]);
+            for (int j = 0; j < TCH; ++j) vv[c + j] = cmulf(vv[c + j], w[j]);
             __builtin_amdgcn_sched_barrier(0);
         }
-    };
-    auto mul_half = [&](float2 (&vv)[R], const float2* tab, auto conj_c) {
-        constexpr bool CONJ = decltype(conj_c)::value;
-#pragma unroll
-        for (int c = 0; c < H; c += TCH) {
-            float2 w[TCH];
-#pragma unroll
-            for (int j = 0; j < TCH; ++j) w[j] = tab[(c + j) * 64 + la];
-#pragma unroll
-            for (int j = 0; j < TCH; ++j) vv[c + j] = CONJ ? cmulf_conj(vv[c + j], w[j]) : cmulf(vv[c + j], w[j]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int j = H; j < R; ++j) vv[j] = make_float2(0.f, 0.f);
     };
     const int lblocks = (job.n_lines + LINES - 1) / LINES;
     const int PC = job.pchunk;
@@ -1572,47 +1099,21 @@ __global__ void __launch_bounds__(512, 2) rowTB2_pass_kernel(RowTJob job) {
             }
             __builtin_amdgcn_sched_barrier(0);
         };
-        auto a_first = [&]() {
-            mul_half(v, bw, std::false_type{});
-            fft2048_wave<false, TCH>(v, scr, tw, w64, L, la, sgn);
-            mul_filter(v, std::false_type{});
-            fft2048_wave<true, TCH>(v, scr, tw, w64, L, la, sgn);
-        };
-        auto a_second = [&]() {
-            mul_half(v, bp, std::false_type{});
-            fft2048_wave<false, TCH>(v, scr, tw, w64, L, la, sgn);
-            mul_filter(v, std::true_type{});
-            fft2048_wave<true, TCH>(v, scr, tw, w64, L, la, sgn);
-            mul_half(v, bw, std::true_type{});
-        };
         auto a_conv = [&]() {                                   // see rowTB_pass_kernel
             fft2048_wave<false, TCH>(v, scr, tw, w64, L, la, sgn);
-            mul_filter(v, std::false_type{});
+            mul_filter(v);
             fft2048_wave<true, TCH>(v, scr, tw, w64, L, la, sgn);
 #pragma unroll
             for (int j = 0; j < H; ++j) if (j * 64 + la >= N) v[j] = make_float2(0.f, 0.f);
 #pragma unroll
             for (int j = H; j < R; ++j) v[j] = make_float2(0.f, 0.f);
         };
-        if constexpr (CONV) {
-            if (job.flags & P2_PRE_A) a_conv();
-            prefetch_part(MSL_IC(0), MSL_IC(8));
-#pragma unroll
-            for (int j = 0; j < H; ++j) v[j] = cmulf(v[j], tv[j]);
-            if (job.flags & P2_POST_A) a_conv();
-            prefetch_part(MSL_IC(8), MSL_IC(16));
-        } else {
-        if (job.flags & P2_PRE_A) a_first();
-        prefetch_part(MSL_IC(0), MSL_IC(4));
-        if (job.flags & P2_PRE_A) a_second();
-        prefetch_part(MSL_IC(4), MSL_IC(8));
+        if (job.flags & P2_PRE_A) a_conv();
+        prefetch_part(MSL_IC(0), MSL_IC(8));
 #pragma unroll
         for (int j = 0; j < H; ++j) v[j] = cmulf(v[j], tv[j]);
-        if (job.flags & P2_POST_A) a_first();
-        prefetch_part(MSL_IC(8), MSL_IC(12));
-        if (job.flags & P2_POST_A) a_second();
-        prefetch_part(MSL_IC(12), MSL_IC(16));
-        }
+        if (job.flags & P2_POST_A) a_conv();
+        prefetch_part(MSL_IC(8), MSL_IC(16));
         wave_lds_fence();
 #pragma unroll
         for (int j = 0; j < H; ++j) myrow[j * 64 + la] = v[j];
@@ -1654,128 +1155,18 @@ __global__ void __launch_bounds__(512, 2) rowTB2_pass_kernel(RowTJob job) {
     }
 }
 
-// Transposing pass A . t_k . A for lines of 1025 .. 2047 points (and 2048-point lines next to such an axis never use it): the
-// convolution form of rowTB2_pass_kernel with the cyclic length M = 4096, the 4096-point transforms built from fft2048_wave
-// by one radix-2 step that the zero padding makes half trivial.  A wave holds the line in two register sets lo / hi:
-//   forward  (x[n + 2048] = 0):  X[2k] = FFT_2048(x)[k],  X[2k+1] = FFT_2048(x W_4096^n)[k]        -> lo, hi
-//   filter in that split order:   lo *= Q[2k], hi *= Q[2k+1]   (both halves symmetric: Q[2k] about k = 1024, Q[2k+1] about 1023.5)
-//   inverse, outputs n < 2048 only:  y[n] = IFFT_2048(lo)[n] + conj(W_4096^n) IFFT_2048(hi)[n]
-// i.e. four 2048-point transforms per propagation, eight per pass -- per point the cost of the 513..1024 kernel.  No register is
-// left for a prefetch or for t_k (64 complex per lane): lines and t_k are loaded when needed, t_k into the idle hi set.  The tile
-// rows are the waves' transpose scratch (1553 float2): the transposed store goes in two halves of 1024 positions.
+// Transposing pass A . t_k . A for lines of 1025 .. 2047 points: the convolution form of rowTB2_pass_kernel with the cyclic length
+// M = 4096, the 4096-point transforms built from fft2048_wave by one radix-2 step that the zero padding makes half trivial:
+//   forward  (x[n + 2048] = 0):  X[2k] = FFT_2048(x)[k],  X[2k+1] = FFT_2048(x W_4096^n)[k]
+//   filter in that split order:   X[2k] *= Q[2k], X[2k+1] *= Q[2k+1]   (both halves symmetric: Q[2k] about k = 1024, Q[2k+1] about 1023.5)
+//   inverse, outputs n < 2048 only:  y[n] = IFFT_2048(X[2k])[n] + conj(W_4096^n) IFFT_2048(X[2k+1])[n]
+// i.e. four 2048-point transforms per propagation, eight per pass.  The two branches of the radix-2 step run on TWO waves: wave 2l
+// takes X[2k] (E = IFFT(FFT(x) Qe)), wave 2l + 1 takes X[2k+1] (O = conj(W) IFFT(FFT(x W) Qo)), the halves meet in the LDS
+// (y = E + O).  A wave then holds ONE set of 32 complex registers -- both branches in one wave spill 916 B per lane -- at the
+// price of four lines per workgroup (32-byte runs in the transposed store; the pass is bound by its eight 2048-point transforms
+// per line, not by the stores).  The two transpose-scratch rows of a pair (2 x 1553 float2) double as the pair's exchange buffer
+// (2048 float2) whenever neither wave is inside a transform.
 // job.bf: Q[2k] (k = 0..1024, padded to 1026) followed by Q[2k+1] (k = 0..1023); job.bw: W_4096^n, n < 2048; job.n_line = N.
-__global__ void __launch_bounds__(512, 2) rowTC_pass_kernel(RowTJob job) {
-    constexpr int R = 32, M2 = 2048, LINES = 8, NT = 512, TCH = 8;
-    constexpr int RS = (R * W2K_PITCH) / 2 + 1;
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float2* tw = reinterpret_cast<float2*>(smem_raw);         // 2048, lane order
-    float2* w64 = tw + M2;                                    // 64
-    float2* wq = w64 + 64;                                    // 2048: W_4096^n, lane order
-    float2* qe = wq + M2;                                     // 1026
-    float2* qo = qe + 1026;                                   // 1024 (+2)
-    float2* tile = qo + 1026;                                 // LINES * RS
-    const int tid = threadIdx.x;
-    const int N = job.n_line;
-    for (int i = tid; i < M2; i += NT) { tw[lds_pos64(i)] = job.tw[i]; wq[lds_pos64(i)] = job.bw[i]; }
-    if (tid < 64) w64[tid] = job.tw2[tid];
-    for (int i = tid; i < 2052; i += NT) qe[i] = job.bf[i];
-    __syncthreads();
-    const int wv = tid >> 6, L = tid & 63, la = lam64(L);
-    const float sgn = (L & 1) ? -1.f : 1.f;
-    const int li = tid % LINES, r0 = tid / LINES;
-    float2* myrow = tile + wv * RS;
-    float* scr = reinterpret_cast<float*>(myrow);
-    const float2* ea = qe + la;                               // Q[2 (64 j + la)],                      j < 16
-    const float2* eb = qe - la;                               // Q[2 (2048 - (64 j + la))] = qe[64 (32 - j) - la],  j >= 16
-    const float2* oa = qo + la;                               // Q[2 (64 j + la) + 1],                  j < 16
-    const float2* ob = qo + 63 - la;                          // Q[2 (2047 - (64 j + la)) + 1] = qo[64 (31 - j) + 63 - la],  j >= 16
-    const int lblocks = (job.n_lines + LINES - 1) / LINES;
-    const int n_items = lblocks * job.n_images;
-    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-        const int p = item / lblocks, lb = item - p * lblocks;
-        const int Lc = min(lb * LINES + wv, job.n_lines - 1);
-        float2 lo[R], hi[R];
-        {
-            const float2* r = job.in + (long long)p * job.in_image_stride + (long long)Lc * job.in_pitch;
-#pragma unroll
-            for (int j = 0; j < R; ++j) lo[j] = (j * 64 + la < N) ? ld_stream(r + (j * 64 + la)) : make_float2(0.f, 0.f);
-        }
-        auto conv = [&]() __attribute__((always_inline)) {
-#pragma unroll
-            for (int c = 0; c < R; c += TCH) {                 // hi = x W_4096^n
-                float2 w[TCH];
-#pragma unroll
-                for (int j = 0; j < TCH; ++j) w[j] = wq[(c + j) * 64 + L];
-#pragma unroll
-                for (int j = 0; j < TCH; ++j) hi[c + j] = cmulf(lo[c + j], w[j]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            fft2048_wave<false, TCH>(lo, scr, tw, w64, L, la, sgn);
-            __builtin_amdgcn_sched_barrier(0);              // one transform at a time: their temporaries do not fit side by side
-            fft2048_wave<false, TCH>(hi, scr, tw, w64, L, la, sgn);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int c = 0; c < R; c += TCH) {
-                float2 w[TCH];
-#pragma unroll
-                for (int j = 0; j < TCH; ++j) w[j] = (c + j < 16) ? ea[(c + j) * 64] : eb[(R - (c + j)) * 64];
-#pragma unroll
-                for (int j = 0; j < TCH; ++j) lo[c + j] = cmulf(lo[c + j], w[j]);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int j = 0; j < TCH; ++j) w[j] = (c + j < 16) ? oa[(c + j) * 64] : ob[(R - 1 - (c + j)) * 64];
-#pragma unroll
-                for (int j = 0; j < TCH; ++j) hi[c + j] = cmulf(hi[c + j], w[j]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            fft2048_wave<true, TCH>(lo, scr, tw, w64, L, la, sgn);
-            __builtin_amdgcn_sched_barrier(0);
-            fft2048_wave<true, TCH>(hi, scr, tw, w64, L, la, sgn);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int c = 0; c < R; c += TCH) {                 // y = lo + conj(W_4096^n) hi, outputs beyond N dropped
-                float2 w[TCH];
-#pragma unroll
-                for (int j = 0; j < TCH; ++j) w[j] = wq[(c + j) * 64 + L];
-#pragma unroll
-                for (int j = 0; j < TCH; ++j) {
-                    const float2 t = cmulf_conj(hi[c + j], w[j]);
-                    lo[c + j] = ((c + j) * 64 + la < N) ? make_float2(lo[c + j].x + t.x, lo[c + j].y + t.y) : make_float2(0.f, 0.f);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        };
-        if (job.flags & P2_PRE_A) conv();
-        {
-            const float2* trow = job.trans + frame_off(job, p) + (long long)Lc * N;       // t_k into the idle hi set
-#pragma unroll
-            for (int j = 0; j < R; ++j) hi[j] = (j * 64 + la < N) ? trow[j * 64 + la] : make_float2(0.f, 0.f);
-#pragma unroll
-            for (int j = 0; j < R; ++j) lo[j] = cmulf(lo[j], hi[j]);
-        }
-        if (job.flags & P2_POST_A) conv();
-        float2* dst = job.out + (long long)p * job.out_image_stride + lb * LINES + li;
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            wave_lds_fence();
-#pragma unroll
-            for (int j = 0; j < 16; ++j) myrow[j * 64 + la] = lo[c * 16 + j];
-            lds_barrier();
-#pragma unroll
-            for (int i = 0; i < 1024 / (NT / LINES); ++i) {
-                const int pos = r0 + (NT / LINES) * i;
-                if (c * 1024 + pos < N) dst[(long long)(c * 1024 + pos) * job.out_pitch] = tile[li * RS + pos];
-            }
-            lds_barrier();
-        }
-    }
-}
-
-// The same pass with the two branches of the radix-2 step on TWO waves: wave 2l takes X[2k] (E = IFFT(FFT(x) Qe)), wave 2l + 1
-// takes X[2k+1] (O = conj(W) IFFT(FFT(x W) Qo)), the halves meet in the LDS (y = E + O).  A wave then holds ONE set of 32 complex
-// registers -- no spills -- at the price of four lines per workgroup (32-byte runs in the transposed store; the pass is bound
-// by its eight 2048-point transforms per line, not by the stores).  The two transpose-scratch rows of a pair (2 x 1553 float2)
-// double as the pair's exchange buffer (2048 float2) whenever neither wave is inside a transform.
 __global__ void __launch_bounds__(512, 2) rowTC2_pass_kernel(RowTJob job) {
     constexpr int R = 32, M2 = 2048, LINES = 4, NT = 512, TCH = 8;
     constexpr int RS = (R * W2K_PITCH) / 2 + 1;
@@ -1799,7 +1190,7 @@ __global__ void __launch_bounds__(512, 2) rowTC2_pass_kernel(RowTJob job) {
     float* scr = reinterpret_cast<float*>(tile + wv * RS);
     float2* pair = tile + 2 * line * RS;                      // the pair's exchange buffer: 2048 float2, natural order
     const float2* fa = (role ? qo : qe) + la;                 // first half of this branch's filter
-    const float2* fb = role ? qo + 63 - la : qe - la;         // mirrored half (see rowTC_pass_kernel)
+    const float2* fb = role ? qo + 63 - la : qe - la;         // mirrored half: Q[2 (2048 - m)] = qe[.. - la], Q[2 (2047 - m) + 1] = qo[.. + 63 - la]
     const int lblocks = (job.n_lines + LINES - 1) / LINES;
     const int n_items = lblocks * job.n_images;
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
@@ -2030,7 +1421,7 @@ __global__ void __launch_bounds__(512, 2) rowTW_pass_kernel(RowTJob job) {
     }
 }
 
-// ---- lines of N = 2 R^2 points (512 = 2*16^2, 2048 = 2*32^2) ----------------------------------------------
+// ---- lines of N = 2 R^2 points (512 = 2*16^2) ---------------------------------------------------------------
 // One radix-2 step wrapped around two four-step transforms.  A group of R lanes holds two register sets; in the
 // natural domain set b, register j, lane l is element b*R^2 + j*R + l.  The forward transform is decimation in
 // frequency (a = x0 + x1, d = (x0 - x1) W_N^m, then N/2-point transforms of a and d give X[2k] and X[2k+1]); the
@@ -2082,57 +1473,25 @@ __device__ __forceinline__ void line2_transform(float2 (&v)[2 * R], float* scrat
     }
 }
 
-// Transposing pass A . t_k . A for N = 2 R^2.  R = 16 (N = 512): next line prefetched and t_k kept in registers like
-// rowT_pass_kernel, full-line tile.  R = 32 (N = 2048): a line is 64 complex per lane, so neither fits; t_k comes from
-// L2 per line and the transposed store goes through the tile in two position halves (set 0, set 1).
+// Transposing pass A . t_k . A for N = 2 R^2 with R = 16 (N = 512): next line prefetched and t_k kept in registers like
+// rowT_pass_kernel, full-line tile.  (2048 = 2 * 32^2 holds 64 complex per lane in this layout, with room for neither: 2048-point
+// lines run on the wave-per-line transform, rowTW_pass_kernel.)
 template <int R>
 __global__ void __launch_bounds__(16 * R, 2) rowT2_pass_kernel(RowTJob job) {      // two waves per SIMD: at most 256 VGPRs + AGPRs
+    static_assert(R == 16, "the 2 R^2 layout is used for 512-point lines only");
     constexpr int N2 = R * R, N = 2 * N2, NT = 16 * R;
-    constexpr bool BIG = (R == 32);
-    constexpr int CPOS = BIG ? N2 : N;                 // positions per store chunk
-    constexpr int NCHUNK = N / CPOS;
-    constexpr int XM = BIG ? 0 : 2;                    // exchange: 16-byte reads and add-tid stores (rows 16-byte aligned: even pitch)
-    constexpr int CS = BIG ? CPOS + 1 : CPOS + 2;      // tile line pitch: odd, or 2 mod 32 -- conflict-free staging either way
+    constexpr int XM = 2;                              // exchange: 16-byte reads and add-tid stores (rows 16-byte aligned: even pitch)
+    constexpr int CS = N + 2;                          // tile line pitch: 2 mod 32 -- conflict-free staging
     constexpr int POS_PER_IT = NT / 8;
-    constexpr int NIT = CPOS / POS_PER_IT;
+    constexpr int NIT = N / POS_PER_IT;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float2* tw = reinterpret_cast<float2*>(smem_raw);            // N2: four-step twiddles
     float2* tw2 = tw + N2;                                       // N2: W_N^m of the outer radix-2 step
-    float2* pl_lds = tw2 + N2;                                   // N (small variant only): propagator, split order
-    float2* tile = BIG ? pl_lds : pl_lds + N;                    // 16 * CS, also the groups' transpose scratch
+    float2* pl = tw2 + N2;                                       // N: propagator, split order
+    float2* tile = pl + N;                                       // 16 * CS, also the groups' transpose scratch
     const int tid = threadIdx.x;
     for (int i = tid; i < N2; i += NT) { tw[i] = job.tw[i]; tw2[i] = job.tw2[i]; }
-    if (!BIG) for (int i = tid; i < N; i += NT) pl_lds[i] = job.pl[i];
-    const float2* pl = pl_lds;          // small variant; the big one keeps P in the free upper quarter of the tile rows
-    __syncthreads();
-    // BIG: a tile row is CS = R^2 + 1 float2 long, the transforms only use the first R(R+1)/2 as scratch, the transposed
-    // store uses R^2.  The split-order propagator (N entries) is parked in the last N/16 entries of the 16 rows --
-    // entry m in row m / (N/16) -- and re-read from L2 after every store phase (16 KB per workgroup and iteration).
-    constexpr int PSEG = N / 16;                               // 128 entries per row
-    constexpr int POFF = CS - 1 - PSEG;                        // 896
-    static_assert(!BIG || POFF >= R * (R + 1) / 2, "propagator segment overlaps the transform scratch");
-    auto stage_p = [&]() {
-        if constexpr (BIG) {
-#pragma unroll
-            for (int i = 0; i < N / NT; ++i) {
-                const int m = tid + i * NT;
-                tile[(m / PSEG) * CS + POFF + (m % PSEG)] = job.pl[m];
-            }
-        }
-    };
-    // v[jj] *= P[jj*R + ln] from the parked copy, in chunks of 8 (register pressure, see mul_table)
-    auto mul_p_big = [&](float2 (&vv)[2 * R]) {
-#pragma unroll
-        for (int c = 0; c < 2 * R; c += 8) {
-            float2 w[8];
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) w[jj] = tile[((c + jj) * R / PSEG) * CS + POFF + ((c + jj) * R % PSEG) + (tid % R)];
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) vv[c + jj] = cmulf(vv[c + jj], w[jj]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    stage_p();
+    for (int i = tid; i < N; i += NT) pl[i] = job.pl[i];
     __syncthreads();
     const int grp = tid / R, ln = tid % R;
     const int q = tid & 7, r0 = tid >> 3;
@@ -2140,7 +1499,7 @@ __global__ void __launch_bounds__(16 * R, 2) rowT2_pass_kernel(RowTJob job) {   
     const float* wscr = reinterpret_cast<const float*>(tile + (grp - grp % (64 / R)) * CS);     // the wave's shared exchange scratch
     const unsigned wscr_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(tile + (grp - grp % (64 / R)) * CS));
     const int lblocks = job.n_lines / 16;
-    const int PC = BIG ? 1 : job.pchunk;
+    const int PC = job.pchunk;
     const int pchunks = (job.n_images + PC - 1) / PC;
     const int n_items = lblocks * pchunks;
     const int step_lb = (int)gridDim.x / pchunks, step_pc = (int)gridDim.x % pchunks;
@@ -2150,29 +1509,20 @@ __global__ void __launch_bounds__(16 * R, 2) rowT2_pass_kernel(RowTJob job) {   
     auto block_base = [&](int lbb, int pcc, int kk) {
         return job.in + ((long long)(pcc * PC + kk) * job.in_image_stride + (long long)lbb * 16 * job.in_pitch);
     };
-    float2 vn[BIG ? 1 : 2 * R];
-    float2 tv[BIG ? 1 : 2 * R];
-    if (!BIG && item < n_items) {
+    float2 vn[2 * R];
+    float2 tv[2 * R];
+    if (item < n_items) {
         const float2* r = block_base(lb, pc, 0);
 #pragma unroll
         for (int j = 0; j < 2 * R; ++j) vn[j] = ld_stream(r + (in_off + j * R));
     }
     while (item < n_items) {
         float2 v[2 * R];
-        if constexpr (BIG) {
-            const float2* r = block_base(lb, pc, k);
-            int ioff = tid;                             // re-derived every iteration (register limit, see below)
-            asm volatile("" : "+v"(ioff));
-            ioff = (ioff / R) * job.in_pitch + (ioff % R);
 #pragma unroll
-            for (int j = 0; j < 2 * R; ++j) v[j] = r[ioff + j * R];
-        } else {
-#pragma unroll
-            for (int j = 0; j < 2 * R; ++j) v[j] = vn[j];
-        }
+        for (int j = 0; j < 2 * R; ++j) v[j] = vn[j];
         const int p = pc * PC + k;
         const int cur_lb = lb;
-        if (!BIG && k == 0) {
+        if (k == 0) {
             const float2* trow = job.trans + frame_off(job, pc * PC) + (long long)lb * 16 * N;
             int toff = tid;                               // re-derived here (one chunk of probes in PC): not worth a register across the loop
             asm volatile("" : "+v"(toff));
@@ -2185,7 +1535,7 @@ __global__ void __launch_bounds__(16 * R, 2) rowT2_pass_kernel(RowTJob job) {   
             nk = 0; nitem = item + (int)gridDim.x; nlb = lb + step_lb; npc = pc + step_pc;
             if (npc >= pchunks) { npc -= pchunks; ++nlb; }
         }
-        if (!BIG && nitem < n_items) {                  // (a mid-iteration prefetch as in rowT_pass_kernel measured 3% slower here)
+        if (nitem < n_items) {                          // (a mid-iteration prefetch as in rowT_pass_kernel measured 3% slower here)
             const float2* r = block_base(nlb, npc, nk);
             int ioff = tid;                             // re-derived from the thread index every iteration: the kernel sits at
             asm volatile("" : "+v"(ioff));              // its register limit and would otherwise spill this offset
@@ -2195,51 +1545,37 @@ __global__ void __launch_bounds__(16 * R, 2) rowT2_pass_kernel(RowTJob job) {   
         }
         if (job.flags & P2_PRE_A) {
             line2_transform<R, false, XM>(v, scratch, tw, tw2, ln, wscr, wscr_lds, tid & 63);
-            if constexpr (BIG) mul_p_big(v); else mul_table<2 * R, 0, false, R>(v, pl, ln);
+            mul_table<2 * R, 0, false, R>(v, pl, ln);
             line2_transform<R, true, XM>(v, scratch, tw, tw2, ln, wscr, wscr_lds, tid & 63);
         }
-        if constexpr (BIG) {
-            // uniform 64-bit base (scalar registers) + one 32-bit per-thread offset, laundered so that the table addresses
-            // stay out of the loop-invariant set
-            int lnx = grp * N + ln;
-            asm volatile("" : "+v"(lnx));
-            mul_table<2 * R, 0, false, R>(v, job.trans + frame_off(job, p) + (long long)lb * 16 * N, lnx);
-        } else {
 #pragma unroll
-            for (int j = 0; j < 2 * R; ++j) v[j] = cmulf(v[j], tv[j]);
-        }
+        for (int j = 0; j < 2 * R; ++j) v[j] = cmulf(v[j], tv[j]);
         if (job.flags & P2_POST_A) {
             line2_transform<R, false, XM>(v, scratch, tw, tw2, ln, wscr, wscr_lds, tid & 63);
-            if constexpr (BIG) mul_p_big(v); else mul_table<2 * R, 0, false, R>(v, pl, ln);
+            mul_table<2 * R, 0, false, R>(v, pl, ln);
             line2_transform<R, true, XM>(v, scratch, tw, tw2, ln, wscr, wscr_lds, tid & 63);
         }
         float2* dst = job.out + ((long long)p * job.out_image_stride + cur_lb * 16);
         int off0 = 2 * q + r0 * job.out_pitch;
         asm volatile("" : "+v"(off0));
         const int ostep = POS_PER_IT * job.out_pitch;
-        if constexpr (BIG) lds_barrier();              // every wave is done with the parked propagator before rows are overwritten
+        wave_lds_fence();
+        float2* myrow = tile + grp * CS;
 #pragma unroll
-        for (int c = 0; c < NCHUNK; ++c) {
-            if (c > 0) lds_barrier();                  // the previous chunk has been read out
-            wave_lds_fence();
-            float2* myrow = tile + grp * CS;
+        for (int j = 0; j < N / R; ++j) myrow[j * R + ln] = v[j];
+        lds_barrier();
 #pragma unroll
-            for (int j = 0; j < CPOS / R; ++j) myrow[j * R + ln] = v[c * (CPOS / R) + j];
-            lds_barrier();
-#pragma unroll
-            for (int i = 0; i < NIT; ++i) {
-                const int pos = r0 + POS_PER_IT * i;
-                const float2 a = tile[(2 * q) * CS + pos], b = tile[(2 * q + 1) * CS + pos];
-                st_stream(dst + (off0 + (c * NIT + i) * ostep), a.x, a.y, b.x, b.y);
-            }
+        for (int i = 0; i < NIT; ++i) {
+            const int pos = r0 + POS_PER_IT * i;
+            const float2 a = tile[(2 * q) * CS + pos], b = tile[(2 * q + 1) * CS + pos];
+            st_stream(dst + (off0 + i * ostep), a.x, a.y, b.x, b.y);
         }
         lds_barrier();
-        if constexpr (BIG) { stage_p(); lds_barrier(); }       // the store phase overwrote the parked propagator
         item = nitem; lb = nlb; pc = npc; k = nk;
     }
 }
 
-// ---- stand-alone inverse FFT passes for lines of 2 R^2 points: the potential build on 512 / 2048 grids -------------------------
+// ---- stand-alone inverse FFT passes for lines of 2 R^2 = 512 points: the potential build on 512 x 512 grids ---------------------
 // V_s = Re ifft2(R_s) / (dx^2 dy^2), t_s = exp(i sigma V_s) (potentials.py:336-342, multislice.py:282) went through the generic LDS
 // kernel on these grids (two passes at 2.6 TB/s plus a transposition of every second slice; 0.35 of 0.73 ms per frame at 512^2 x
 // 100, which a single probe cannot amortise).  Two passes of this kernel instead: the line is loaded in the split order the
@@ -2255,17 +1591,22 @@ struct IfftT2Job {
     long long in_is, out_t_is, out_rows_is;
     int in_pitch, out_t_pitch, out_rows_pitch, n_lines, n_images;
     int potential;              // 1: V = Re(.) * scale, out = exp(i sigma V)
-    int rows_parity;            // potential: images with (img & 1) == rows_parity are stored as rows, the others transposed; -1: none
+    int rows_parity;            // potential: images whose slice number has this parity are stored as rows, the others transposed; -1: none
+    int slice_mod;              // slice number of image img = img % slice_mod (several frames' stacks in one launch); 0: img itself
     int herm;                   // 1: only elements 0 .. N/2 of an input line exist, the others are conj(line[N - e]) (spectrum of a real image)
     float scale, sigma_over_pi;
 };
 
+// slice number of an image of a potential-build launch (the stacks of several frames follow each other)
+template <typename Job>
+__device__ __forceinline__ int slice_of(const Job& job, int img) { return job.slice_mod > 0 ? img % job.slice_mod : img; }
+
 template <int R>
 __global__ void __launch_bounds__(16 * R, 2) ifftT2_kernel(IfftT2Job job) {
+    static_assert(R == 16, "512-point lines only (64 complex values per lane at R = 32 spill: 2048-point axes use ifftTW_kernel)");
     constexpr int N2 = R * R, N = 2 * N2, NT = 16 * R;
-    constexpr bool BIG = (R == 32);
-    constexpr int CPOS = BIG ? N2 : N;
-    constexpr int NCHUNK = N / CPOS;
+    constexpr int CPOS = N;
+    constexpr int NCHUNK = 1;
     constexpr int CS = CPOS + 1;
     constexpr int POS_PER_IT = NT / 8;
     constexpr int NIT = CPOS / POS_PER_IT;
@@ -2321,7 +1662,7 @@ __global__ void __launch_bounds__(16 * R, 2) ifftT2_kernel(IfftT2Job job) {
                 v[j] = trans_of(v[j]);
             }
         }
-        if (job.potential && (img & 1) == job.rows_parity) {       // workgroup-uniform
+        if (job.potential && (slice_of(job, img) & 1) == job.rows_parity) {       // workgroup-uniform
             float2* dst = job.out_rows + (long long)img * job.out_rows_is + (long long)(lb * 16 + grp) * job.out_rows_pitch;
 #pragma unroll
             for (int j = 0; j < 2 * R; ++j) dst[(j / R) * N2 + (j % R) * R + lnv] = v[j];
@@ -2367,7 +1708,8 @@ struct IfftTBJob {
     long long in_is, out_t_is, out_rows_is;
     int in_pitch, out_t_pitch, out_rows_pitch, n_lines, n_line, n_images;
     int potential;              // 1: V = Re(.) * scale, out = exp(i sigma V)
-    int rows_parity;            // potential: images with (img & 1) == rows_parity are stored as rows, the others transposed; -1: none
+    int rows_parity;            // potential: images whose slice number has this parity are stored as rows, the others transposed; -1: none
+    int slice_mod;              // slice number of image img = img % slice_mod (several frames' stacks in one launch); 0: img itself
     int herm;                   // 1: only elements 0 .. n_line/2 of an input line exist, the others are conj(line[n_line - e]) (spectrum of a real image)
     float scale, sigma_over_pi;
 };
@@ -2458,7 +1800,7 @@ __global__ void __launch_bounds__(16 * R, (R == 32) ? 2 : 4) ifftTB_kernel(IfftT
                 v[j] = make_float2(cs, sn);
             }
         }
-        if (job.potential && (img & 1) == job.rows_parity) {       // workgroup-uniform: this slice is kept as rows
+        if (job.potential && (slice_of(job, img) & 1) == job.rows_parity) {       // workgroup-uniform: this slice is kept as rows
             if (lb * LINES + grp < job.n_lines) {
                 float2* dst = job.out_rows + (long long)img * job.out_rows_is + (long long)L * job.out_rows_pitch;
 #pragma unroll
@@ -2570,7 +1912,7 @@ __global__ void __launch_bounds__(512, 2) ifftTB2_kernel(IfftTBJob job) {
                 v[j] = make_float2(cs, sn);
             }
         }
-        if (job.potential && (img & 1) == job.rows_parity) {
+        if (job.potential && (slice_of(job, img) & 1) == job.rows_parity) {
             if (lb * LINES + wv < job.n_lines) {
                 float2* dst = job.out_rows + (long long)img * job.out_rows_is + (long long)Lc * job.out_rows_pitch;
 #pragma unroll
@@ -2643,7 +1985,7 @@ __global__ void __launch_bounds__(512, 2) ifftTW_kernel(IfftTBJob job) {
                 v[j] = make_float2(cs, sn);
             }
         }
-        if (job.potential && (img & 1) == job.rows_parity) {
+        if (job.potential && (slice_of(job, img) & 1) == job.rows_parity) {
             float2* dst = job.out_rows + (long long)img * job.out_rows_is + (long long)(lb * LINES + wv) * job.out_rows_pitch;
 #pragma unroll
             for (int j = 0; j < R; ++j) dst[j * 64 + la] = v[j];

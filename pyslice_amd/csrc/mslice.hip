@@ -72,8 +72,6 @@ struct msl_handle {
     char* scratch = nullptr;       // reductions: partial sums / masks / index lists
     size_t scratch_bytes = 0;
     bool onepass = false;
-    bool sf_quad = true;            // structure factor on the quadrant kernel (decided at msl_create: the phase tables are then n/2 + 1 columns wide)
-    bool conv_form = true;          // any-length register kernels: propagation as a cyclic convolution (MSL_CHIRPZ=1: chirp-z DFTs)
     bool scheme_b = false;         // a direction of 2R^2 points: every pass transposes, first pass along y, final transpose if nz is odd
     // one-pass kernel per direction: R^2 register kernel, 2 R^2 (two) register kernel with its tables, or the generic LDS kernel
     // (breg: any length <= R^2/2 by Bluestein's chirp-z on the R^2 register FFTs, with its filter bf and chirp bw)
@@ -95,11 +93,8 @@ struct msl_handle {
     unsigned stage_pos = 0;
     float2* transT = nullptr;
     int pitchT = 0;
-    int rowT_variant = 4;
-    int rowT_paired = 0;           // MSL_ROWT_PAIRED=1: 8-line tiles in the paired-lines layout, two workgroups per CU (measured equal: DESIGN 4.1)
     int debug_flags_mask = -1;
-    int row_pchunk = 0;         // 0 = auto (MSL_ROW_PCHUNK)
-    int row_variant = 1;        // 0: plain row kernel, 1: software-pipelined (MSL_ROW_VARIANT)
+    int row_pchunk = 0;         // 0 = auto (MSL_ROW_PCHUNK, debug)
     int pitch = 0;              // row pitch (elements) of psi0/psi; > ny de-aliases the column pass's 128-byte segments
     // frame batching (msl_config.frame_batch): FB frames share one launch of every slice-loop kernel -- image index =
     // frame * P + probe, each frame with its own transmission stack.  Work buffers hold FB * P images (the probes are
@@ -161,6 +156,10 @@ int fail(msl_handle* h, int code, const char* fmt, ...) {
     if (h) h->err = buf; else g_create_error = buf;
     return code;
 }
+
+// Diagnostic switches (A/B runs, cross-checks of the tests) are read from the environment ONLY when MSL_DEBUG is set: a stray
+// MSL_* variable in a user's environment must not change which kernels run.
+const char* dbg_env(const char* name) { return getenv("MSL_DEBUG") ? getenv(name) : nullptr; }
 
 #define HIPCHK(h, expr)                                                                              \
     do {                                                                                             \
@@ -512,29 +511,20 @@ int make_tw4(msl_handle* h, float2** dst, int R) {
 template <int R>
 int launch_row_fast_r(msl_handle* h, const RowJob& job, int kind) {
     constexpr int N = R * R, G = 256 / R;
-    if (h->row_variant == 1) {
-        const size_t lds = (size_t)N * 16 + (size_t)G * R * (R + 1) * 4;
-        const int per_cu = std::max(1, std::min(2, (int)((size_t)h->lds_limit / lds)));
-        const long long slots = (long long)h->n_cus * per_cu;
-        // probes per work item: as many as possible (t_z reuse) while still giving every slot an item
-        RowJob j2 = job;
-        const long long xg = job.nx / G;
-        int pc = job.n_images;
-        while (pc > 1 && xg * ((job.n_images + pc - 1) / pc) < slots) pc = (pc + 1) / 2;
-        if (h->row_pchunk > 0) pc = std::min(h->row_pchunk, job.n_images);
-        if (job.t_group > 0) while (job.t_group % pc) --pc;          // a chunk of probes shares one t_k line: stay inside a frame
-        j2.pchunk = pc;
-        const long long items = xg * ((job.n_images + pc - 1) / pc);
-        const int grid = (int)std::min<long long>(items, slots);
-        hipLaunchKernelGGL(row_pass_pf_kernel<R>, dim3(grid), dim3(256), lds, h->stream, j2);
-        HIPCHK(h, hipGetLastError());
-        return mark_launch(h, kind);
-    }
-    const size_t lds = (size_t)N * 8 + (size_t)G * R * (R + 1) * 4;
-    const long long groups = (long long)(job.nx / G) * job.n_images;
-    const int per_cu = std::max(1, (int)((size_t)h->lds_limit / lds));
-    const int grid = (int)std::min<long long>(groups, (long long)h->n_cus * std::min(per_cu, 4));
-    hipLaunchKernelGGL(row_pass_kernel<R>, dim3(grid), dim3(256), lds, h->stream, job);
+    const size_t lds = (size_t)N * 16 + (size_t)G * R * (R + 1) * 4;
+    const int per_cu = std::max(1, std::min(2, (int)((size_t)h->lds_limit / lds)));
+    const long long slots = (long long)h->n_cus * per_cu;
+    // probes per work item: as many as possible (t_z reuse) while still giving every slot an item
+    RowJob j2 = job;
+    const long long xg = job.nx / G;
+    int pc = job.n_images;
+    while (pc > 1 && xg * ((job.n_images + pc - 1) / pc) < slots) pc = (pc + 1) / 2;
+    if (h->row_pchunk > 0) pc = std::min(h->row_pchunk, job.n_images);
+    if (job.t_group > 0) while (job.t_group % pc) --pc;          // a chunk of probes shares one t_k line: stay inside a frame
+    j2.pchunk = pc;
+    const long long items = xg * ((job.n_images + pc - 1) / pc);
+    const int grid = (int)std::min<long long>(items, slots);
+    hipLaunchKernelGGL(row_pass_pf_kernel<R>, dim3(grid), dim3(256), lds, h->stream, j2);
     HIPCHK(h, hipGetLastError());
     return mark_launch(h, kind);
 }
@@ -707,14 +697,14 @@ int transpose_odd_slices(msl_handle* h) {
     return MSL_OK;
 }
 
-template <int R, int LINES, int XCH>
-int launch_rowT_v(msl_handle* h, RowTJob job, int kind) {
-    constexpr int N = R * R;
-    constexpr int CS = (XCH < 2) ? R * (R + 1) + 1 : ((xch_scratch_float2<R, XCH>() > R * R ? xch_scratch_float2<R, XCH>() : R * R) + 33) / 32 * 32 + 2;
+// transposing pass on R^2-point lines (1024 / 256): add-tid exchange, 16-line tiles
+template <int R>
+int launch_rowT_r(msl_handle* h, RowTJob job, int kind) {
+    constexpr int N = R * R, LINES = 16;
+    constexpr int CS = (R * R + 33) / 32 * 32 + 2;
     const size_t lds = ((size_t)2 * N + (size_t)LINES * CS) * 8;
-    // R = 32: ~250 VGPRs, 152-156 KB -> one workgroup per CU; R = 16: 135 VGPRs, 39 KB -> three (MSL_ROWT_PER_CU overrides)
-    int cap = (R == 16) ? 3 : 2;
-    { const char* e = getenv("MSL_ROWT_PER_CU"); if (e && atoi(e) > 0) cap = atoi(e); }
+    // R = 32: ~250 VGPRs, 152-156 KB -> one workgroup per CU; R = 16: 135 VGPRs, 39 KB -> three
+    const int cap = (R == 16) ? 3 : 2;
     const int per_cu = std::max(1, std::min(cap, (int)((size_t)h->lds_limit / lds)));
     const long long slots = (long long)h->n_cus * per_cu;
     const long long lb = job.n_lines / LINES;
@@ -723,84 +713,21 @@ int launch_rowT_v(msl_handle* h, RowTJob job, int kind) {
     job.pchunk = pc;
     const long long items = lb * ((job.n_images + pc - 1) / pc);
     const int grid = (int)std::min<long long>(items, slots);
-    (void)hipFuncSetAttribute((const void*)rowT_pass_kernel<R, LINES, XCH>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
-    hipLaunchKernelGGL((rowT_pass_kernel<R, LINES, XCH>), dim3(grid), dim3(LINES * R), lds, h->stream, job);
+    (void)hipFuncSetAttribute((const void*)rowT_pass_kernel<R, LINES>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
+    hipLaunchKernelGGL((rowT_pass_kernel<R, LINES>), dim3(grid), dim3(LINES * R), lds, h->stream, job);
     HIPCHK(h, hipGetLastError());
     return mark_launch(h, kind);
 }
 
-// MSL_ROWT_VARIANT = exchange through the LDS inside the four-step transforms: 0 = real and imaginary parts one after the
-// other, 1 = complex, 2 / 3 = the same with 16-byte reads, 4 = 16-byte reads and ds_write_addtid_b32 stores (default:
-// 288 -> 280 -> 273 us per 1024^2 x 64 pass for 0 -> 2 -> 4)
-template <int R>
-int launch_rowT_r(msl_handle* h, RowTJob job, int kind) {
-    switch (h->rowT_variant) {
-        case 0: return launch_rowT_v<R, 16, 0>(h, job, kind);
-        case 1: return launch_rowT_v<R, 16, 1>(h, job, kind);
-        case 2: return launch_rowT_v<R, 16, 2>(h, job, kind);
-        case 3: return launch_rowT_v<R, 16, 3>(h, job, kind);
-        default: return launch_rowT_v<R, 16, 4>(h, job, kind);
-    }
-}
-
-// paired-lines transposing pass (1024-point lines in both directions): two 256-thread workgroups per CU
-template <bool IN_P, bool OUT_P>
-int launch_rowTP_io(msl_handle* h, RowTJob job, int kind) {
-    constexpr int R = 32, N = R * R, CS = R * (R + 1) + 1, LINES = 8;
-    const size_t lds = ((size_t)N + N / 2 + 2 + (size_t)LINES * CS) * 8;
-    const int per_cu = std::max(1, std::min(2, (int)((size_t)h->lds_limit / lds)));
-    const long long slots = (long long)h->n_cus * per_cu;
-    const long long lb = job.n_lines / LINES;
-    int pc = choose_pchunk(lb, job.n_images, slots, job.t_group);
-    if (h->row_pchunk > 0) { pc = std::min(h->row_pchunk, job.n_images); if (job.t_group > 0) while (job.t_group % pc) --pc; }
-    job.pchunk = pc;
-    const long long items = lb * ((job.n_images + pc - 1) / pc);
-    const int grid = (int)std::min<long long>(items, slots);
-    (void)hipFuncSetAttribute((const void*)rowTP_pass_kernel<R, IN_P, OUT_P>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
-    hipLaunchKernelGGL((rowTP_pass_kernel<R, IN_P, OUT_P>), dim3(grid), dim3(LINES * R), lds, h->stream, job);
-    HIPCHK(h, hipGetLastError());
-    return mark_launch(h, kind);
-}
-// 1024-point lines, three 256-thread workgroups per CU (paired-lines layout, two-phase store, t_k from L2)
-template <bool IN_P, bool OUT_P>
-int launch_rowT3_io(msl_handle* h, RowTJob job, int kind) {
-    constexpr int R = 32, N = R * R, RS = R * (R + 1) / 2 + 1, LINES = 8;
-    const size_t lds = ((size_t)N + N / 2 + 2 + (size_t)LINES * RS) * 8;
-    const int per_cu = std::max(1, std::min(3, (int)((size_t)h->lds_limit / lds)));
-    const long long slots = (long long)h->n_cus * per_cu;
-    const long long lb = job.n_lines / LINES;
-    // no t_k reuse across probes here: one probe per work item chunk would do, but items are dealt line block major so that
-    // neighbouring workgroups share the t_k lines in L2; keep the chunk rule (it balances the rounds)
-    int pc = choose_pchunk(lb, job.n_images, slots, job.t_group);
-    if (h->row_pchunk > 0) { pc = std::min(h->row_pchunk, job.n_images); if (job.t_group > 0) while (job.t_group % pc) --pc; }
-    job.pchunk = pc;
-    const long long items = lb * ((job.n_images + pc - 1) / pc);
-    const int grid = (int)std::min<long long>(items, slots);
-    (void)hipFuncSetAttribute((const void*)rowT3_pass_kernel<IN_P, OUT_P>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
-    hipLaunchKernelGGL((rowT3_pass_kernel<IN_P, OUT_P>), dim3(grid), dim3(LINES * R), lds, h->stream, job);
-    HIPCHK(h, hipGetLastError());
-    return mark_launch(h, kind);
-}
-int launch_rowTP(msl_handle* h, const RowTJob& job, bool in_p, bool out_p, int kind) {
-    if (h->rowT_paired == 3) {
-        if (in_p) return out_p ? launch_rowT3_io<true, true>(h, job, kind) : launch_rowT3_io<true, false>(h, job, kind);
-        return out_p ? launch_rowT3_io<false, true>(h, job, kind) : launch_rowT3_io<false, false>(h, job, kind);
-    }
-    if (in_p) return out_p ? launch_rowTP_io<true, true>(h, job, kind) : launch_rowTP_io<true, false>(h, job, kind);
-    return out_p ? launch_rowTP_io<false, true>(h, job, kind) : launch_rowTP_io<false, false>(h, job, kind);
-}
-
-// lines of 2 R^2 points (512, 2048)
-template <int R>
-int launch_rowT2_r(msl_handle* h, RowTJob job, int kind) {
-    constexpr int N2 = R * R, N = 2 * N2;
-    constexpr bool BIG = (R == 32);
-    const size_t lds = BIG ? ((size_t)2 * N2 + (size_t)16 * (N2 + 1)) * 8 : ((size_t)2 * N2 + N + (size_t)16 * (N + 2)) * 8;
+// lines of 2 R^2 = 512 points
+int launch_rowT2(msl_handle* h, RowTJob job, int kind) {
+    constexpr int R = 16, N2 = R * R, N = 2 * N2;
+    const size_t lds = ((size_t)2 * N2 + N + (size_t)16 * (N + 2)) * 8;
     const int per_cu = std::max(1, std::min(2, (int)((size_t)h->lds_limit / lds)));
     const long long slots = (long long)h->n_cus * per_cu;
     const long long lb = job.n_lines / 16;
-    int pc = BIG ? 1 : choose_pchunk(lb, job.n_images, slots, job.t_group);
-    if (!BIG && h->row_pchunk > 0) { pc = std::min(h->row_pchunk, job.n_images); if (job.t_group > 0) while (job.t_group % pc) --pc; }
+    int pc = choose_pchunk(lb, job.n_images, slots, job.t_group);
+    if (h->row_pchunk > 0) { pc = std::min(h->row_pchunk, job.n_images); if (job.t_group > 0) while (job.t_group % pc) --pc; }
     job.pchunk = pc;
     const long long items = lb * ((job.n_images + pc - 1) / pc);
     const int grid = (int)std::min<long long>(items, slots);
@@ -810,11 +737,11 @@ int launch_rowT2_r(msl_handle* h, RowTJob job, int kind) {
     return mark_launch(h, kind);
 }
 
-// lines of any length <= R^2/2: Bluestein on the register FFTs
-template <int R, bool CONV>
+// lines of any length <= R^2/2: zero-padded cyclic convolution on the register FFTs
+template <int R>
 int launch_rowTB_r(msl_handle* h, RowTJob job, int kind) {
     constexpr int M = R * R, NH = M / 2, CS = R * (R + 1) + 2;
-    const size_t lds = ((size_t)M + NH + 2 + (CONV ? 0 : NH + NH) + (size_t)16 * CS) * 8;
+    const size_t lds = ((size_t)M + NH + 2 + (size_t)16 * CS) * 8;
     const int per_cu = std::max(1, std::min(R == 16 ? 4 : 1, (int)((size_t)h->lds_limit / lds)));
     const long long slots = (long long)h->n_cus * per_cu;
     const long long lb = (job.n_lines + 15) / 16;
@@ -823,17 +750,17 @@ int launch_rowTB_r(msl_handle* h, RowTJob job, int kind) {
     job.pchunk = pc;
     const long long items = lb * ((job.n_images + pc - 1) / pc);
     const int grid = (int)std::min<long long>(items, slots);
-    (void)hipFuncSetAttribute((const void*)rowTB_pass_kernel<R, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
-    hipLaunchKernelGGL((rowTB_pass_kernel<R, CONV>), dim3(grid), dim3(16 * R), lds, h->stream, job);
+    (void)hipFuncSetAttribute((const void*)rowTB_pass_kernel<R>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
+    hipLaunchKernelGGL((rowTB_pass_kernel<R>), dim3(grid), dim3(16 * R), lds, h->stream, job);
     HIPCHK(h, hipGetLastError());
     return mark_launch(h, kind);
 }
 
-// lines of 513..1024 points: Bluestein on the wave-per-line 2048-point register FFT
-template <bool IN_P, bool OUT_P, bool CONV>
+// lines of 513..1024 points: the same convolution on the wave-per-line 2048-point register FFT
+template <bool IN_P, bool OUT_P>
 int launch_rowTB2_io(msl_handle* h, RowTJob job, int kind) {
     constexpr int M = 2048, NH = M / 2, RS = (32 * W2K_PITCH) / 2 + 1;
-    const size_t lds = ((size_t)M + 64 + NH + 2 + (CONV ? 0 : NH + NH) + (size_t)8 * RS) * 8;
+    const size_t lds = ((size_t)M + 64 + NH + 2 + (size_t)8 * RS) * 8;
     const long long slots = h->n_cus;
     const long long lb = (job.n_lines + 7) / 8;
     int pc = choose_pchunk(lb, job.n_images, slots, job.t_group);
@@ -841,8 +768,8 @@ int launch_rowTB2_io(msl_handle* h, RowTJob job, int kind) {
     job.pchunk = pc;
     const long long items = lb * ((job.n_images + pc - 1) / pc);
     const int grid = (int)std::min<long long>(items, slots);
-    (void)hipFuncSetAttribute((const void*)rowTB2_pass_kernel<IN_P, OUT_P, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
-    hipLaunchKernelGGL((rowTB2_pass_kernel<IN_P, OUT_P, CONV>), dim3(grid), dim3(512), lds, h->stream, job);
+    (void)hipFuncSetAttribute((const void*)rowTB2_pass_kernel<IN_P, OUT_P>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
+    hipLaunchKernelGGL((rowTB2_pass_kernel<IN_P, OUT_P>), dim3(grid), dim3(512), lds, h->stream, job);
     HIPCHK(h, hipGetLastError());
     return mark_launch(h, kind);
 }
@@ -900,41 +827,28 @@ int launch_rowT_dir(msl_handle* h, const msl_handle::OpDir& o, RowTJob job, int 
     job.tw = o.tw;
     if (o.wave2k) { job.tw2 = o.tw2; return launch_rowTW(h, job, kind); }
     job.flags &= ~(P2_IN_PAIRED | P2_OUT_PAIRED);
-    if (o.breg4) {
+    if (o.breg4) {                          // 1025 .. 2047 points: cyclic convolution of length 4096, two waves per line
         job.n_line = (&o == &h->opx) ? h->cfg.nx : h->cfg.ny;
         job.tw2 = o.tw2; job.bf = o.qf; job.bw = o.bw; job.pl = nullptr;
         constexpr int RS = (32 * W2K_PITCH) / 2 + 1;
         const size_t lds = ((size_t)2048 + 64 + 2048 + 2052 + (size_t)8 * RS) * 8;
         job.pchunk = 1;
-        if (!(getenv("MSL_CONV4096") && atoi(getenv("MSL_CONV4096")) == 1)) {       // default form: two waves per line (no spills)
-            const long long items2 = (long long)((job.n_lines + 3) / 4) * job.n_images;
-            const int grid2 = (int)std::min<long long>(items2, (long long)h->n_cus);
-            (void)hipFuncSetAttribute((const void*)rowTC2_pass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
-            hipLaunchKernelGGL(rowTC2_pass_kernel, dim3(grid2), dim3(512), lds, h->stream, job);
-            HIPCHK(h, hipGetLastError());
-            return mark_launch(h, kind);
-        }
-        const long long items = (long long)((job.n_lines + 7) / 8) * job.n_images;
-        const int grid = (int)std::min<long long>(items, (long long)h->n_cus);
-        (void)hipFuncSetAttribute((const void*)rowTC_pass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
-        hipLaunchKernelGGL(rowTC_pass_kernel, dim3(grid), dim3(512), lds, h->stream, job);
+        const long long items2 = (long long)((job.n_lines + 3) / 4) * job.n_images;
+        const int grid2 = (int)std::min<long long>(items2, (long long)h->n_cus);
+        (void)hipFuncSetAttribute((const void*)rowTC2_pass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
+        hipLaunchKernelGGL(rowTC2_pass_kernel, dim3(grid2), dim3(512), lds, h->stream, job);
         HIPCHK(h, hipGetLastError());
         return mark_launch(h, kind);
     }
-    if (o.breg || o.breg2) {
+    if (o.breg || o.breg2) {                // A as one cyclic convolution of length M (two FFTs); bf = its filter
         job.n_line = (&o == &h->opx) ? h->cfg.nx : h->cfg.ny;
-        if (h->conv_form) {                 // A as one cyclic convolution of length M (two FFTs); bf = its filter
-            job.pl = nullptr; job.bf = o.qf; job.bw = nullptr;
-            if (o.breg2) { job.tw2 = o.tw2; return launch_rowTB2_io<false, false, true>(h, job, kind); }
-            return o.R == 32 ? launch_rowTB_r<32, true>(h, job, kind) : launch_rowTB_r<16, true>(h, job, kind);
-        }
-        job.pl = o.ptab; job.bf = o.bf; job.bw = o.bw;       // MSL_CHIRPZ=1: every N-point DFT by chirp-z (four FFTs per A)
-        if (o.breg2) { job.tw2 = o.tw2; return launch_rowTB2_io<false, false, false>(h, job, kind); }
-        return o.R == 32 ? launch_rowTB_r<32, false>(h, job, kind) : launch_rowTB_r<16, false>(h, job, kind);
+        job.pl = nullptr; job.bf = o.qf; job.bw = nullptr;
+        if (o.breg2) { job.tw2 = o.tw2; return launch_rowTB2_io<false, false>(h, job, kind); }
+        return o.R == 32 ? launch_rowTB_r<32>(h, job, kind) : launch_rowTB_r<16>(h, job, kind);
     }
     if (o.two) {
         job.tw2 = o.tw2; job.pl = o.ptab;
-        return o.R == 32 ? launch_rowT2_r<32>(h, job, kind) : launch_rowT2_r<16>(h, job, kind);
+        return launch_rowT2(h, job, kind);
     }
     return o.R == 32 ? launch_rowT_r<32>(h, job, kind) : launch_rowT_r<16>(h, job, kind);
 }
@@ -1045,20 +959,16 @@ int slice_loop_onepass(msl_handle* h, int fused_slot, int groups, int first_grou
         RowTJob j{};
         j.flags = flags; j.n_images = P;
         if (groups > 1) { j.t_group = c.n_probes; j.t_magic = (unsigned)((1ull << 32) / (unsigned)c.n_probes + 1); j.t_stride = (long long)c.nz * npix; }
-        // 1024-point lines in both directions: paired-lines kernel, work buffers between two transposing passes in the
-        // paired layout (the first pass reads, the last one writes the natural layout)
-        const bool paired = h->rowT_paired && h->Rx == 32 && h->Ry == 32;
-        const bool in_p = paired && k > 0, out_p = paired && k < nz - 2;
         if (along_y) {
             j.in = (k == 0) ? h->psi0 : h->psi; j.out = h->psiT;
             j.trans = h->trans + toff + (size_t)k * npix; j.pl = h->pyt; j.tw = h->tw4_y;
             j.in_image_stride = isA; j.out_image_stride = isB; j.in_pitch = h->pitch; j.out_pitch = h->pitchT; j.n_lines = c.nx;
-            rc = paired ? launch_rowTP(h, j, in_p, out_p, K_ROW) : (h->Ry == 32 ? launch_rowT_r<32>(h, j, K_ROW) : launch_rowT_r<16>(h, j, K_ROW));
+            rc = h->Ry == 32 ? launch_rowT_r<32>(h, j, K_ROW) : launch_rowT_r<16>(h, j, K_ROW);
         } else {
             j.in = (k == 0) ? h->psi0T : h->psiT; j.out = h->psi;
             j.trans = h->transT + toff + (size_t)k * npix; j.pl = h->pxt; j.tw = h->tw4_x;
             j.in_image_stride = isB; j.out_image_stride = isA; j.in_pitch = h->pitchT; j.out_pitch = h->pitch; j.n_lines = c.ny;
-            rc = paired ? launch_rowTP(h, j, in_p, out_p, K_COL) : (h->Rx == 32 ? launch_rowT_r<32>(h, j, K_COL) : launch_rowT_r<16>(h, j, K_COL));
+            rc = h->Rx == 32 ? launch_rowT_r<32>(h, j, K_COL) : launch_rowT_r<16>(h, j, K_COL);
         }
         if (rc) return rc;
     }
@@ -1081,8 +991,8 @@ int ensure_atoms(msl_handle* h, size_t n) {
     if ((rc = dalloc(h, &h->d_u1, cap))) return rc;
     if ((rc = dalloc(h, &h->d_u2, cap))) return rc;
     // phase tables: the quadrant kernel reads the columns 0 .. n/2 only
-    if ((rc = dalloc(h, &h->d_ex, cap * (size_t)(h->sf_quad ? h->cfg.nx / 2 + 1 : h->cfg.nx)))) return rc;
-    if ((rc = dalloc(h, &h->d_ey, cap * (size_t)(h->sf_quad ? h->cfg.ny / 2 + 1 : h->cfg.ny)))) return rc;
+    if ((rc = dalloc(h, &h->d_ex, cap * (size_t)(h->cfg.nx / 2 + 1)))) return rc;
+    if ((rc = dalloc(h, &h->d_ey, cap * (size_t)(h->cfg.ny / 2 + 1)))) return rc;
     h->atom_cap = cap;
     return MSL_OK;
 }
@@ -1175,18 +1085,9 @@ int fill_propagator(msl_handle* h) {
     };
     if (h->opx.two && (rc = fill_split(h->opx.ptab, c.nx, c.dx))) return rc;
     if (h->opy.two && (rc = fill_split(h->opy.ptab, c.ny, c.dy))) return rc;
-    // zero-padded copies for the chirp-z kernels: R^2/2 entries, P[m] for m < n
+    // any-length register kernels: filter of the zero-padded cyclic convolution that IS the propagation along one axis
     auto fill_padded = [&](const msl_handle::OpDir& o, int n, double d) -> int {
         const int NH = o.breg2 ? 1024 : o.R * o.R / 2;
-        std::vector<float2> v(NH, make_float2(0.f, 0.f));
-        for (int m = 0; m < n; ++m) {
-            const int f = (m < (n + 1) / 2) ? m : m - n;
-            const double k = f * (1.0 / (n * d));
-            const double ph = -M_PI * c.wavelength * c.dz * k * k;
-            v[m] = make_float2((float)(cos(ph) / n), (float)(sin(ph) / n));
-        }
-        HIPCHK(h, hipMemcpyAsync(o.ptab, v.data(), NH * sizeof(float2), hipMemcpyHostToDevice, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
         // convolution form: a = ifft_n(P) (float64), wrapped to the cyclic length M = 2 NH, filter = FFT_M(q) / M, first half + 1
         {
             const int M = 2 * NH;
@@ -1286,7 +1187,6 @@ int msl_create(const msl_config* cfg, msl_handle** out) {
     msl_handle* h = new (std::nothrow) msl_handle();
     if (!h) return fail(nullptr, MSL_ERR_NOMEM, "msl_create: out of host memory");
     h->cfg = *cfg;
-    h->sf_quad = !getenv("MSL_NO_QUAD") && !getenv("MSL_NO_MFMA") && !getenv("MSL_NO_HERMITIAN");
     h->FB = (cfg->frame_batch > 1 && !cfg->keep_potential) ? cfg->frame_batch : 1;
     // k-window, centred on the DC pixel of the fftshifted spectrum (index n/2): [n/2 - w/2, n/2 - w/2 + w)
     h->wx = cfg->window_nx ? cfg->window_nx : cfg->nx;
@@ -1320,32 +1220,29 @@ int msl_create(const msl_config* cfg, msl_handle** out) {
         int ry = fast_radix(cfg->ny), rx = fast_radix(cfg->nx);
         if (ry && cfg->nx % (256 / ry) == 0) { h->Ry = ry; if ((rc = make_tw4(h, &h->tw4_y, ry))) return bail(rc); }
         if (rx && cfg->ny % 16 == 0 && cfg->ny >= 32) { h->Rx = rx; if ((rc = make_tw4(h, &h->tw4_x, rx))) return bail(rc); }
-        { const char* e = getenv("MSL_ROW_VARIANT"); if (e) h->row_variant = atoi(e) ? 1 : 0; }
-        { const char* e = getenv("MSL_ROW_PCHUNK"); if (e) h->row_pchunk = atoi(e); }
+        { const char* e = dbg_env("MSL_ROW_PCHUNK"); if (e) h->row_pchunk = atoi(e); }
         (void)hipFuncSetAttribute((const void*)row_pass_pf_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
         (void)hipFuncSetAttribute((const void*)row_pass_pf_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
-        (void)hipFuncSetAttribute((const void*)row_pass_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
-        (void)hipFuncSetAttribute((const void*)row_pass_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
         (void)hipFuncSetAttribute((const void*)col_pass_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
         (void)hipFuncSetAttribute((const void*)col_pass_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
     }
     const size_t npix = (size_t)cfg->nx * cfg->ny;
     {
-        const char* e = getenv("MSL_PITCH_PAD");
+        const char* e = dbg_env("MSL_PITCH_PAD");
         int pad = e ? atoi(e) : 16;
         if (pad < 0 || (pad & 1)) pad = 16;
         h->pitch = cfg->ny + ((h->Rx || h->Ry) ? pad : 0);
     }
     {
-        const char* e = getenv("MSL_SLICE_PATH");           // 2 = force the two-pass four-step loop
+        const char* e = dbg_env("MSL_SLICE_PATH");           // 2 = force the two-pass four-step loop
         const bool want = cfg->fft_path == 0 && !(e && atoi(e) == 2);
         // n = line length of the direction, n_other = number of lines per image (the register kernels take 16 at a time)
         auto setup_dir = [&](msl_handle::OpDir& o, int n, int n_other, int Rfast, float2* tw4) -> int {
             const bool lines_ok = (n_other % 16 == 0);
             if (Rfast && lines_ok) { o.R = Rfast; o.two = false; o.tw = tw4; return MSL_OK; }
             const int R2 = (n == 512) ? 16 : (n == 2048 ? 32 : 0);
-            const bool two_ok = R2 && lines_ok && want && !getenv("MSL_NO_TWO");
-            if (n == 2048 && two_ok && n_other % 8 == 0 && !(getenv("MSL_WAVE2K") && atoi(getenv("MSL_WAVE2K")) == 0)) {
+            const bool two_ok = R2 && lines_ok && want && !dbg_env("MSL_NO_TWO");
+            if (n == 2048 && two_ok) {
                 // 2048-point lines on the wave-per-line FFT (tables: T[k1*64+n2], W_64; the natural Fresnel table serves as is)
                 o.R = 32; o.wave2k = true;
                 std::vector<float2> T(2048), W(64);
@@ -1372,7 +1269,7 @@ int msl_create(const msl_config* cfg, msl_handle** out) {
             // and from n ~ 190 up (M = 1024; 64 probes x 50 slices: 160^2 1.83 M vs 1.72 M slice-steps/s, 200^2 1.23 vs 1.31 M,
             // 240^2 0.84 vs 1.13 M), and everywhere the generic kernel would need its own LDS-resident Bluestein transform
             const bool smooth = ((&o == &h->opx) ? h->plan_x : h->plan_y).M == n;
-            if (!two_ok && want && n >= 33 && n <= 512 && (n <= 128 || n >= 192 || !smooth) && !getenv("MSL_NO_BLUESTEIN_REG")) {
+            if (!two_ok && want && n >= 33 && n <= 512 && (n <= 128 || n >= 192 || !smooth) && !dbg_env("MSL_NO_BLUESTEIN_REG")) {
                 const int Rb = (n <= 128) ? 16 : 32, M = Rb * Rb, NH = M / 2;
                 o.R = Rb; o.breg = true;
                 int r = make_tw4(h, &o.tw, Rb);
@@ -1390,14 +1287,13 @@ int msl_create(const msl_config* cfg, msl_handle** out) {
                 for (int j = 0; j <= NH; ++j) bf[j] = make_float2((float)(cr[j] / M), (float)(ci[j] / M));
                 if ((r = dalloc(h, &o.bw, (size_t)NH))) return r;
                 if ((r = dalloc(h, &o.bf, (size_t)NH + 2))) return r;
-                if ((r = dalloc(h, &o.ptab, (size_t)NH))) return r;
                 if ((r = dalloc(h, &o.qf, (size_t)NH + 2))) return r;
                 if (hipMemcpy(o.bw, bw.data(), NH * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess ||
                     hipMemcpy(o.bf, bf.data(), (NH + 2) * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess)
                     return fail(h, MSL_ERR_HIP, "chirp table upload failed");
                 return MSL_OK;
             }
-            if (!two_ok && want && n >= 513 && n <= 1024 && !getenv("MSL_NO_BLUESTEIN_REG")) {
+            if (!two_ok && want && n >= 513 && n <= 1024 && !dbg_env("MSL_NO_BLUESTEIN_REG")) {
                 // 513..1024: the same on the wave-per-line 2048-point register FFT, every length (convolution form against the
                 // Stockham kernel: 540^2 102 k -> 186 k slice-steps/s, 600^2 85 k -> 160 k, 768^2 73 k -> 130 k)
                 constexpr int M = 2048, NH = 1024;
@@ -1428,7 +1324,6 @@ int msl_create(const msl_config* cfg, msl_handle** out) {
                 if ((r = dalloc(h, &o.tw2, (size_t)64))) return r;
                 if ((r = dalloc(h, &o.bw, (size_t)NH))) return r;
                 if ((r = dalloc(h, &o.bf, (size_t)NH + 2))) return r;
-                if ((r = dalloc(h, &o.ptab, (size_t)NH))) return r;
                 if ((r = dalloc(h, &o.qf, (size_t)NH + 2))) return r;
                 if (hipMemcpy(o.tw, T.data(), M * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess ||
                     hipMemcpy(o.tw2, W.data(), 64 * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess ||
@@ -1437,7 +1332,7 @@ int msl_create(const msl_config* cfg, msl_handle** out) {
                     return fail(h, MSL_ERR_HIP, "chirp table upload failed");
                 return MSL_OK;
             }
-            if (!two_ok && want && n >= 1025 && n <= 2047 && !getenv("MSL_NO_CONV4096") && !getenv("MSL_NO_BLUESTEIN_REG")) {
+            if (!two_ok && want && n >= 1025 && n <= 2047 && !dbg_env("MSL_NO_CONV4096") && !dbg_env("MSL_NO_BLUESTEIN_REG")) {
                 // 1025..2047: cyclic convolution of length 4096 on pairs of 2048-point wave FFTs, the two branches of the radix-2
                 // step on two waves (rowTC2_pass_kernel): 16 probes x 20 slices, slice-steps/s against the generic two-pass loop:
                 // 1100^2 19.6 k -> 27.5 k, 1500^2 12.6 k -> 18.3 k, 2000^2 6.8 k -> 11.4 k.  MSL_CONV4096=1 selects the first
@@ -1474,7 +1369,7 @@ int msl_create(const msl_config* cfg, msl_handle** out) {
             if (!two_ok) {
                 // generic LDS kernel with a transposing store: tiles of >= 8 lines keep the stores at 64 bytes or more
                 const int M = (&o == &h->opx) ? h->plan_x.M : h->plan_y.M;
-                o.generic = want && M <= 1024 && !getenv("MSL_NO_GENERIC_ONEPASS");
+                o.generic = want && M <= 1024 && !dbg_env("MSL_NO_GENERIC_ONEPASS");
                 return MSL_OK;
             }
             o.R = R2; o.two = true;
@@ -1515,10 +1410,7 @@ int msl_create(const msl_config* cfg, msl_handle** out) {
             h->need_psi0T = !h->scheme_b && (cfg->nz % 2 == 0);
             if (h->need_psi0T && (rc = dalloc(h, &h->psi0T, (size_t)cfg->ny * h->pitchT * images))) return bail(rc);
             if ((rc = dalloc(h, &h->transT, npix * cfg->nz * h->FB))) return bail(rc);
-            { const char* ev = getenv("MSL_ROWT_VARIANT"); if (ev) h->rowT_variant = atoi(ev); }
-            h->conv_form = !getenv("MSL_CHIRPZ");
-            { const char* ev = getenv("MSL_ROWT_PAIRED"); if (ev) h->rowT_paired = atoi(ev); }
-            { const char* ev = getenv("MSL_DEBUG_FLAGS_MASK"); if (ev) h->debug_flags_mask = atoi(ev); }
+            { const char* ev = dbg_env("MSL_DEBUG_FLAGS_MASK"); if (ev) h->debug_flags_mask = atoi(ev); }
             (void)hipFuncSetAttribute((const void*)row_pass2_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
             (void)hipFuncSetAttribute((const void*)row_pass2_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
         }
@@ -1689,18 +1581,16 @@ int msl_upload_probes(msl_handle* h, const float* c64, int32_t n_probes) {
     return MSL_OK;
 }
 
-int msl_build_potential(msl_handle* h, const double* pos, const int32_t* Z, int64_t n, int32_t ax1, int32_t ax2, int32_t axs) {
-    if (!h || (n > 0 && (!pos || !Z))) return fail(h, MSL_ERR_INVALID, "msl_build_potential: null argument");
-    if (!h->have_kirkland) return fail(h, MSL_ERR_STATE, "msl_build_potential: call msl_set_kirkland first");
-    if (!h->have_slices) return fail(h, MSL_ERR_STATE, "msl_build_potential: call msl_set_slices first");
-    if (n < 0 || n > 0x7fffffff) return fail(h, MSL_ERR_INVALID, "msl_build_potential: bad atom count");
-    if (ax1 < 0 || ax1 > 2 || ax2 < 0 || ax2 > 2 || axs < 0 || axs > 2 || ((1 << ax1) | (1 << ax2) | (1 << axs)) != 7)
-        return fail(h, MSL_ERR_INVALID, "msl_build_potential: axes must be a permutation of 0,1,2");
+// Projected potentials + transmission functions of `count` MD frames (the same atoms, `count` sets of positions) into the batch
+// slots first_slot .. first_slot + count - 1: ONE launch each of the atom preparation, the stable counting sort (keys = frame x
+// slice x species), the two phase tables, the structure factor and the two inverse-transform passes for as many frames as the
+// phase tables of a group may take (6 GB), instead of that sequence per frame.  The reference builds one Potential per frame
+// (calculators.py:172-186, potentials.py:188-348); with its default single probe that build IS the frame (round 2: 0.43 of
+// 0.62 ms at 512^2 x 100 slices, of which ~110 us were launches of 5-15 us kernels and four small copies per frame).
+static int build_potentials(msl_handle* h, const double* pos, const int32_t* Z, int64_t n, int count, int first_slot, int32_t ax1,
+                            int32_t ax2, int32_t axs) {
     const msl_config& c = h->cfg;
-    HIPCHK(h, hipSetDevice(c.device));
     const size_t npix = (size_t)c.nx * c.ny;
-    float2* const TR = h->trans + (size_t)h->cur_batch * c.nz * npix;                 // batch slot this frame's stack goes to
-    float2* const TRT = h->transT ? h->transT + (size_t)h->cur_batch * c.nz * npix : nullptr;
     // species present (sorted ascending, like np.unique)
     int z2s[104];
     for (int i = 0; i < 104; ++i) z2s[i] = -1;
@@ -1723,251 +1613,251 @@ int msl_build_potential(msl_handle* h, const double* pos, const int32_t* Z, int6
         h->ff_species_cap = nsp;
         h->ff_n = 0;
     }
-    const int nkeys = c.nz * std::max(nsp, 1);
-    if (nkeys > h->keys_cap) {
-        if ((rc = dalloc(h, &h->d_counts, (size_t)nkeys + 1))) return rc;
-        if ((rc = dalloc(h, &h->d_start, (size_t)nkeys + 1))) return rc;
-        h->keys_cap = nkeys;
+    // frames per group: the phase tables of a group (n atoms x (nx/2 + 1 + ny/2 + 1) x 8 bytes per frame) stay under 6 GB
+    const int cx = c.nx / 2 + 1, cy = c.ny / 2 + 1;             // table columns the quadrant kernel reads
+    const size_t table_bytes_per_frame = std::max<size_t>(1, (size_t)n * (size_t)(cx + cy) * sizeof(float2));
+    const int G = (int)std::max<size_t>(1, std::min<size_t>((size_t)count, (size_t)6e9 / table_bytes_per_frame));
+    const int keys_per_frame = c.nz * std::max(nsp, 1);
+    const int nkeys_cap = keys_per_frame * G;
+    if (nkeys_cap > h->keys_cap) {
+        if ((rc = dalloc(h, &h->d_counts, (size_t)nkeys_cap + 1))) return rc;
+        if ((rc = dalloc(h, &h->d_start, (size_t)nkeys_cap + 1))) return rc;
+        h->keys_cap = nkeys_cap;
     }
-    if ((rc = ensure_atoms(h, (size_t)n))) return rc;
-    HIPCHK(h, hipMemsetAsync(h->d_counts, 0, ((size_t)nkeys + 1) * sizeof(int), h->stream));
-    bool recip_written = false;     // the structure-factor kernels write every bin of R_s; zero-fill only when none runs
-    // R_s is Hermitian (real V): with the quadrant kernel and four-step transforms on both axes only the rows kx <= nx/2 are
-    // written and row-transformed, and the column pass mirrors them while staging (col_pass_kernel<.., HERM>)
-    bool herm_ifft = false, herm_tb = false, herm_t2 = false, herm_tw = false;
-    const bool tw_axes = h->onepass && h->opx.wave2k && h->opy.wave2k && !h->V && h->transT && !getenv("MSL_NO_IFFT_TW");
-    const bool t2_axes = h->onepass && h->opx.two && h->opy.two && h->opx.R == 16 && h->opy.R == 16 && !h->V && !getenv("MSL_NO_IFFT_T2");
-    // (the chirp-z inverse transform of the potential runs when both axes have chirp-z tables: see ifft_tb below)
-    const bool tb_axes = h->onepass && !h->V && h->transT && !getenv("MSL_NO_IFFT_TB") &&
+    if ((rc = ensure_atoms(h, (size_t)n * G))) return rc;
+    // R_s is Hermitian (real V): only the rows kx <= nx/2 are written and row-transformed when the inverse transform mirrors them
+    // itself (every register-kernel path: col_pass_kernel<.., HERM>, ifftT2 / ifftTB / ifftTW with job.herm)
+    const bool tw_axes = h->onepass && h->opx.wave2k && h->opy.wave2k && !h->V && h->transT;
+    const bool t2_axes = h->onepass && h->opx.two && h->opy.two && h->opx.R == 16 && h->opy.R == 16 && !h->V;
+    const bool tb_axes = h->onepass && !h->V && h->transT &&
                          (h->opx.breg || h->opx.breg2 || h->opx.cz_R) && (h->opy.breg || h->opy.breg2 || h->opy.cz_R);
-    if (n > 0 && nsp > 0) {
-        {
-            msl_handle::HostStage& st = h->stage[h->stage_pos++ & 1];
-            if (!st.ev) HIPCHK(h, hipEventCreateWithFlags(&st.ev, hipEventDisableTiming));
-            if (st.used) HIPCHK(h, hipEventSynchronize(st.ev));            // the copies queued from this slot two calls ago
-            const size_t off_sp = sizeof z2s, off_pos = (off_sp + sizeof species + 7) & ~(size_t)7;
-            const size_t off_Z = off_pos + (size_t)n * 3 * sizeof(double), need = off_Z + (size_t)n * sizeof(int);
-            if (need > st.bytes) {
-                if (st.buf) (void)hipHostFree(st.buf);
-                st.buf = nullptr; st.bytes = 0;
-                const size_t cap = need + need / 4;
-                if (hipHostMalloc((void**)&st.buf, cap, hipHostMallocDefault) != hipSuccess)
-                    return fail(h, MSL_ERR_NOMEM, "hipHostMalloc(%zu bytes) failed", cap);
-                st.bytes = cap;
-            }
-            memcpy(st.buf, z2s, sizeof z2s);
-            memcpy(st.buf + off_sp, species, sizeof species);
-            memcpy(st.buf + off_pos, pos, (size_t)n * 3 * sizeof(double));
-            memcpy(st.buf + off_Z, Z, (size_t)n * sizeof(int));
-            HIPCHK(h, hipMemcpyAsync(h->d_z2s, st.buf, sizeof z2s, hipMemcpyHostToDevice, h->stream));
-            HIPCHK(h, hipMemcpyAsync(h->d_species, st.buf + off_sp, nsp * sizeof(int), hipMemcpyHostToDevice, h->stream));
-            HIPCHK(h, hipMemcpyAsync(h->d_pos, st.buf + off_pos, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
-            HIPCHK(h, hipMemcpyAsync(h->d_Z, st.buf + off_Z, (size_t)n * sizeof(int), hipMemcpyHostToDevice, h->stream));
-            HIPCHK(h, hipEventRecord(st.ev, h->stream));
-            st.used = true;
-        }
-        const double lx = c.nx * c.dx, ly = c.ny * c.dy;
-        // f_Z(q^2) depends on the grid and the species only (potentials.py:283-293 recomputes it per frame): build the table
-        // when the species list changes, i.e. once per run
-        if (nsp != h->ff_n || memcmp(species, h->ff_species, nsp * sizeof(int)) != 0) {
-            long long tot = (long long)npix * nsp;
-            hipLaunchKernelGGL(formfactor_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, h->d_ff, h->d_abcd,
-                               h->d_species, nsp, c.nx, c.ny, 1.0 / lx, 1.0 / ly);
-            memcpy(h->ff_species, species, nsp * sizeof(int));
-            h->ff_n = nsp;
-        }
-        hipLaunchKernelGGL(atom_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d_pos, h->d_Z,
-                           (long long)n, h->d_z2s, h->d_lo, h->d_hi, c.nz, nsp, ax1, ax2, axs, 1.0 / lx, 1.0 / ly, h->d_key,
-                           h->d_u1, h->d_u2, h->d_counts);
-        hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(64), 0, h->stream, h->d_counts, h->d_start, nkeys);
-        hipLaunchKernelGGL(bin_fill_kernel, dim3(nkeys), dim3(1024), 0, h->stream, h->d_key, (long long)n, h->d_start, h->d_order);
-        HIPCHK(h, hipGetLastError());
-        {
-            // atoms that fell into a slice: d_start[nkeys], read by the kernels themselves (grids sized for all n atoms)
-            const int* n_sorted = h->d_start + nkeys;
-            recip_written = true;
-            // default: matrix-core kernel over the quadrant of non-negative frequencies (any nx, ny); the older forms are A/B switches
-            const bool quad = h->sf_quad;                   // (MSL_NO_QUAD / MSL_NO_MFMA / MSL_NO_HERMITIAN, read at msl_create)
-            const int cx = quad ? c.nx / 2 + 1 : c.nx, cy = quad ? c.ny / 2 + 1 : c.ny;     // table columns the kernels read
-            long long tx = (long long)n * cx, ty = (long long)n * cy;
-            hipLaunchKernelGGL(phase_table_kernel, dim3((unsigned)((tx + 255) / 256)), dim3(256), 0, h->stream, h->d_ex, h->d_u1,
-                               h->d_order, n_sorted, c.nx, cx, cx);
-            hipLaunchKernelGGL(phase_table_kernel, dim3((unsigned)((ty + 255) / 256)), dim3(256), 0, h->stream, h->d_ey, h->d_u2,
-                               h->d_order, n_sorted, c.ny, cy, cy);
-            const int tiles_y = (c.ny + SF_TILE - 1) / SF_TILE;
-            const bool hermitian = !quad && (c.nx % (2 * SF_TILE) == 0) && (c.ny % 2 == 0) && !getenv("MSL_NO_HERMITIAN");
-            const int tiles_x = hermitian ? c.nx / 2 / SF_TILE : (c.nx + SF_TILE - 1) / SF_TILE;
-            // Hermitian matrix-core variant: whole 32x32 tiles only (rows kx < nx/2, ny % 32 == 0)
-            const bool use_mfma = hermitian && (c.ny % 32 == 0) && !getenv("MSL_NO_MFMA");
-            if (quad) {
-                const int qy = (c.ny / 2 + 32) / 32, n_tiles = ((c.nx / 2 + 32) / 32) * qy;      // ceil((n/2 + 1) / 32) per axis
-                herm_ifft = h->Rx && h->Ry && !getenv("MSL_NO_HERM_IFFT");       // four-step kernels on both axes (256 / 1024)
-                herm_tb = tb_axes && !getenv("MSL_NO_HERM_IFFT");                   // chirp-z inverse transform: rows kx <= nx/2 only, too
-                herm_t2 = t2_axes && !getenv("MSL_NO_HERM_IFFT");                   // and the 512-point register transform
-                herm_tw = tw_axes && !getenv("MSL_NO_HERM_IFFT");                   // and the 2048-point one
-                hipLaunchKernelGGL(structure_factor_quad_kernel, dim3((n_tiles + 3) / 4, c.nz), dim3(256), 0, h->stream, TR,
-                                   h->d_ex, h->d_ey, h->d_ff, h->d_start, nsp, c.nx, c.ny, qy, n_tiles, (int)n, (herm_ifft || herm_tb || herm_t2 || herm_tw) ? 0 : 1, cx, cy);
-            } else if (use_mfma) {
-                const int ty32 = c.ny / 32, n_tiles = (c.nx / 2 / 32) * ty32;
-                hipLaunchKernelGGL(structure_factor_mfma_kernel, dim3((n_tiles + 3) / 4, c.nz), dim3(256), 0, h->stream, TR,
-                                   h->d_ex, h->d_ey, h->d_ff, h->d_start, nsp, c.nx, c.ny, ty32, n_tiles);
-            } else {
-                hipLaunchKernelGGL(structure_factor_kernel, dim3(tiles_x * tiles_y, c.nz), dim3(256), 0, h->stream, TR, h->d_ex,
-                                   h->d_ey, h->d_ff, h->d_start, nsp, c.nx, c.ny, tiles_y);
-            }
-            if (hermitian) {
-                const int nb = c.ny + c.nx / 2 - 1;
-                hipLaunchKernelGGL(structure_factor_nyquist_kernel, dim3((nb + 127) / 128, c.nz), dim3(128), 0, h->stream, TR,
-                                   h->d_ex, h->d_ey, h->d_ff, h->d_start, nsp, c.nx, c.ny);
-                hipLaunchKernelGGL(structure_factor_mirror_kernel, dim3((c.ny + 255) / 256, c.nx / 2 - 1, c.nz), dim3(256), 0,
-                                   h->stream, TR, c.nx, c.ny);
-            }
-            HIPCHK(h, hipGetLastError());
-        }
-    }
-    if (!recip_written) HIPCHK(h, hipMemsetAsync(TR, 0, npix * c.nz * sizeof(float2), h->stream));
-    h->n_species = nsp;
-    // V_s = Re ifft2(R_s) / (dx^2 dy^2);  t_s = exp(i sigma V_s)  -- in place over the (nz,nx,ny) buffer
+    const bool herm_ifft = h->Rx && h->Ry;                      // four-step kernels on both axes (256 / 1024)
+    const bool herm_tb = tb_axes, herm_t2 = t2_axes, herm_tw = tw_axes;
+    const bool half_rows = herm_ifft || herm_tb || herm_t2 || herm_tw;
     const float vscale = (float)(1.0 / ((double)c.nx * c.ny) / (c.dx * c.dx * c.dy * c.dy));
-    h->cur = nullptr;
-    // (512-point lines only: with 64 complex values per lane the 2048-point instantiation spills and is slower than the generic kernel)
-    const bool ifft_t2 = h->onepass && h->opx.two && h->opy.two && h->opx.R == 16 && h->opy.R == 16 && !h->V && !getenv("MSL_NO_IFFT_T2");
-    // any length up to 512 on both axes (the register chirp-z tables exist): two transposing chirp-z passes, see ifftTB_kernel
     struct CzRef { int R; const float2 *tw, *tw2, *bf, *bw; };      // R = 64: the 2048-point wave FFT
     auto cz_of = [](const msl_handle::OpDir& o) -> CzRef {
         if (o.breg2) return {64, o.tw, o.tw2, o.bf, o.bw};
         if (o.breg) return {o.R, o.tw, nullptr, o.bf, o.bw};
         return {o.cz_R, o.cz_tw, o.cz_tw2, o.cz_bf, o.cz_bw};
     };
-    const bool ifft_tb = h->onepass && cz_of(h->opx).R && cz_of(h->opy).R && !h->V && TRT && !getenv("MSL_NO_IFFT_TB");
-    // 2048 x 2048: the same two passes on the wave-per-line FFT (ifftTW_kernel)
-    const bool ifft_tw = h->onepass && h->opx.wave2k && h->opy.wave2k && !h->V && TRT && !getenv("MSL_NO_IFFT_TW");
-    if (ifft_tw) {
-        auto passw = [&](const msl_handle::OpDir& o, IfftTBJob j) -> int {
-            constexpr int N2 = 2048;
-            const size_t lds = ((size_t)N2 + 64 + (size_t)8 * (N2 + 1)) * 8;
-            const long long items = (long long)(j.n_lines / 8) * j.n_images;
-            const int grid = (int)std::min<long long>(items, (long long)h->n_cus);
-            j.tw = o.tw; j.tw2 = o.tw2;
-            (void)hipFuncSetAttribute((const void*)ifftTW_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
-            hipLaunchKernelGGL(ifftTW_kernel, dim3(grid), dim3(512), lds, h->stream, j);
+    const bool ifft_t2 = t2_axes;
+    const bool ifft_tb = h->onepass && cz_of(h->opx).R && cz_of(h->opy).R && !h->V && h->transT;
+    const bool ifft_tw = tw_axes;
+    bool maps_sent = false;
+    for (int f0 = 0; f0 < count; f0 += G) {
+        const int g = std::min(G, count - f0);
+        const int slot = first_slot + f0;
+        float2* const TR = h->trans + (size_t)slot * c.nz * npix;                 // batch slots this group's stacks go to
+        float2* const TRT = h->transT ? h->transT + (size_t)slot * c.nz * npix : nullptr;
+        const int n_slices = c.nz * g, nkeys = keys_per_frame * g;
+        const long long rows = (long long)n * g;
+        bool recip_written = false;
+        if (n > 0 && nsp > 0) {
+            {
+                msl_handle::HostStage& st = h->stage[h->stage_pos++ & 1];
+                if (!st.ev) HIPCHK(h, hipEventCreateWithFlags(&st.ev, hipEventDisableTiming));
+                if (st.used) HIPCHK(h, hipEventSynchronize(st.ev));            // the copies queued from this slot two calls ago
+                const size_t off_sp = sizeof z2s, off_Z = (off_sp + sizeof species + 7) & ~(size_t)7;
+                const size_t off_pos = (off_Z + (size_t)n * sizeof(int) + 7) & ~(size_t)7, need = off_pos + (size_t)rows * 3 * sizeof(double);
+                if (need > st.bytes) {
+                    if (st.buf) (void)hipHostFree(st.buf);
+                    st.buf = nullptr; st.bytes = 0;
+                    const size_t cap = need + need / 4;
+                    if (hipHostMalloc((void**)&st.buf, cap, hipHostMallocDefault) != hipSuccess)
+                        return fail(h, MSL_ERR_NOMEM, "hipHostMalloc(%zu bytes) failed", cap);
+                    st.bytes = cap;
+                }
+                memcpy(st.buf + off_pos, pos + (size_t)f0 * n * 3, (size_t)rows * 3 * sizeof(double));
+                if (!maps_sent) {
+                    memcpy(st.buf, z2s, sizeof z2s);
+                    memcpy(st.buf + off_sp, species, sizeof species);
+                    memcpy(st.buf + off_Z, Z, (size_t)n * sizeof(int));
+                    HIPCHK(h, hipMemcpyAsync(h->d_z2s, st.buf, sizeof z2s, hipMemcpyHostToDevice, h->stream));
+                    HIPCHK(h, hipMemcpyAsync(h->d_species, st.buf + off_sp, nsp * sizeof(int), hipMemcpyHostToDevice, h->stream));
+                    HIPCHK(h, hipMemcpyAsync(h->d_Z, st.buf + off_Z, (size_t)n * sizeof(int), hipMemcpyHostToDevice, h->stream));
+                    maps_sent = true;
+                }
+                HIPCHK(h, hipMemcpyAsync(h->d_pos, st.buf + off_pos, (size_t)rows * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+                HIPCHK(h, hipEventRecord(st.ev, h->stream));
+                st.used = true;
+            }
+            HIPCHK(h, hipMemsetAsync(h->d_counts, 0, ((size_t)nkeys + 1) * sizeof(int), h->stream));
+            const double lx = c.nx * c.dx, ly = c.ny * c.dy;
+            // f_Z(q^2) depends on the grid and the species only (potentials.py:283-293 recomputes it per frame): build the table
+            // when the species list changes, i.e. once per run
+            if (nsp != h->ff_n || memcmp(species, h->ff_species, nsp * sizeof(int)) != 0) {
+                long long tot = (long long)npix * nsp;
+                hipLaunchKernelGGL(formfactor_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, h->d_ff, h->d_abcd,
+                                   h->d_species, nsp, c.nx, c.ny, 1.0 / lx, 1.0 / ly);
+                memcpy(h->ff_species, species, nsp * sizeof(int));
+                h->ff_n = nsp;
+            }
+            hipLaunchKernelGGL(atom_prep_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, h->stream, h->d_pos, h->d_Z,
+                               (long long)n, g, h->d_z2s, h->d_lo, h->d_hi, c.nz, nsp, ax1, ax2, axs, 1.0 / lx, 1.0 / ly, h->d_key,
+                               h->d_u1, h->d_u2, h->d_counts);
+            hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, h->stream, h->d_counts, h->d_start, nkeys);
+            hipLaunchKernelGGL(bin_fill_kernel, dim3(nkeys), dim3(1024), 0, h->stream, h->d_key, (long long)n, keys_per_frame, h->d_start, h->d_order);
             HIPCHK(h, hipGetLastError());
-            return mark_launch(h, K_OTHER);
-        };
-        IfftTBJob a{};
-        a.in = TR; a.out_t = TRT; a.out_rows = nullptr;
-        a.in_is = a.out_t_is = (long long)npix; a.in_pitch = c.ny; a.out_t_pitch = c.nx; a.n_lines = c.nx; a.n_line = c.ny; a.n_images = c.nz;
-        a.potential = 0; a.rows_parity = -1;
-        if (herm_tw) a.n_lines = (c.nx / 2 + 1 + 7) / 8 * 8;
-        if ((rc = passw(h->opy, a))) return rc;
-        IfftTBJob b{};
-        b.in = TRT; b.out_t = TR; b.out_rows = TRT;
-        b.in_is = b.out_t_is = b.out_rows_is = (long long)npix; b.in_pitch = c.nx; b.out_t_pitch = c.ny; b.out_rows_pitch = c.nx;
-        b.n_lines = c.ny; b.n_line = c.nx; b.n_images = c.nz; b.potential = 1; b.herm = herm_tw ? 1 : 0;
-        b.rows_parity = slice_is_transposed(h, 1) ? 1 : 0;
-        b.scale = vscale; b.sigma_over_pi = (float)(c.sigma / M_PI);
-        if ((rc = passw(h->opx, b))) return rc;
-    } else if (ifft_tb) {
-        auto pass = [&](const CzRef& o, IfftTBJob j) -> int {
-            if (o.R == 64) {                                // 513 .. 1024 points: the wave-per-line 2048-point FFT
-                constexpr int M2 = 2048, NH2 = 1024, RS = (32 * W2K_PITCH) / 2 + 1;
-                const size_t lds2 = ((size_t)M2 + 64 + NH2 + 2 + NH2 + (size_t)8 * RS) * 8;
-                const long long items2 = (long long)((j.n_lines + 7) / 8) * j.n_images;
-                const int grid2 = (int)std::min<long long>(items2, (long long)h->n_cus);
-                j.tw = o.tw; j.tw2 = o.tw2; j.bf = o.bf; j.bw = o.bw;
-                (void)hipFuncSetAttribute((const void*)ifftTB2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
-                hipLaunchKernelGGL(ifftTB2_kernel, dim3(grid2), dim3(512), lds2, h->stream, j);
+            // atoms that fell into a slice: d_start[nkeys], read by the kernels themselves (grids sized for all atoms of the group)
+            const int* n_sorted = h->d_start + nkeys;
+            recip_written = true;
+            const long long tx = rows * cx, ty = rows * cy;
+            hipLaunchKernelGGL(phase_table_kernel, dim3((unsigned)((tx + 255) / 256)), dim3(256), 0, h->stream, h->d_ex, h->d_u1,
+                               h->d_order, n_sorted, c.nx, cx, cx);
+            hipLaunchKernelGGL(phase_table_kernel, dim3((unsigned)((ty + 255) / 256)), dim3(256), 0, h->stream, h->d_ey, h->d_u2,
+                               h->d_order, n_sorted, c.ny, cy, cy);
+            // matrix-core kernel over the quadrant of non-negative frequencies 0 .. n/2 in 32 x 32 tiles; on power-of-two grids
+            // (n/2 + 1 = 32 k + 1) the Nyquist row / column goes to the edge kernel instead of a tile row of its own
+            const bool edge_x = (c.nx % 2 == 0) && (cx % 32 == 1) && cx > 1, edge_y = (c.ny % 2 == 0) && (cy % 32 == 1) && cy > 1;
+            const int tiles_x = edge_x ? cx / 32 : (cx + 31) / 32, tiles_y = edge_y ? cy / 32 : (cy + 31) / 32;
+            const int n_tiles = tiles_x * tiles_y, wg_per_slice = (n_tiles + 3) / 4;
+            const long long n_wg = (long long)wg_per_slice * ((n_slices + 7) / 8 * 8);
+            if (n_wg > 0x7fffffffLL) return fail(h, MSL_ERR_UNSUPPORTED, "structure factor: too many workgroups");
+            hipLaunchKernelGGL(structure_factor_quad_kernel, dim3((unsigned)n_wg), dim3(256), 0, h->stream, TR, h->d_ex, h->d_ey, h->d_ff,
+                               h->d_start, nsp, c.nx, c.ny, tiles_y, n_tiles, (int)rows, half_rows ? 0 : 1, cx, cy, n_slices, wg_per_slice);
+            if (edge_x || edge_y) {
+                const int bins = (edge_x ? cy : 0) + (edge_y ? (edge_x ? cx - 1 : cx) : 0);
+                for (int s0 = 0; s0 < n_slices; s0 += 65535) {
+                    const int ns = std::min(65535, n_slices - s0);
+                    hipLaunchKernelGGL(structure_factor_edge_kernel, dim3((bins + 127) / 128, ns), dim3(128), 0, h->stream,
+                                       TR + (size_t)s0 * npix, h->d_ex, h->d_ey, h->d_ff, h->d_start + (size_t)s0 * nsp, nsp, c.nx, c.ny,
+                                       edge_x ? 1 : 0, edge_y ? 1 : 0, half_rows ? 0 : 1, cx, cy);
+                }
+            }
+            HIPCHK(h, hipGetLastError());
+        }
+        if (!recip_written) HIPCHK(h, hipMemsetAsync(TR, 0, npix * n_slices * sizeof(float2), h->stream));
+        // V_s = Re ifft2(R_s) / (dx^2 dy^2);  t_s = exp(i sigma V_s)  -- in place over the (frames, nz, nx, ny) stacks of the group.
+        // Slices a pass along x reads are kept transposed (scheme b: odd slices; alternating scheme: odd distance to the last one):
+        // with several frames per launch the slice number is the image index modulo nz (slice_mod).
+        h->cur = nullptr;
+        if (ifft_tw) {
+            auto passw = [&](const msl_handle::OpDir& o, IfftTBJob j) -> int {
+                constexpr int N2 = 2048;
+                const size_t lds = ((size_t)N2 + 64 + (size_t)8 * (N2 + 1)) * 8;
+                const long long items = (long long)(j.n_lines / 8) * j.n_images;
+                const int grid = (int)std::min<long long>(items, (long long)h->n_cus);
+                j.tw = o.tw; j.tw2 = o.tw2;
+                (void)hipFuncSetAttribute((const void*)ifftTW_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
+                hipLaunchKernelGGL(ifftTW_kernel, dim3(grid), dim3(512), lds, h->stream, j);
                 HIPCHK(h, hipGetLastError());
                 return mark_launch(h, K_OTHER);
-            }
-            const int R = o.R, M = R * R, NH = M / 2, CS = R * (R + 1) + 2;
-            const size_t lds = ((size_t)M + NH + 2 + NH + (size_t)16 * CS) * 8;
-            const int per_cu = std::max(1, std::min(R == 16 ? 4 : 1, (int)((size_t)h->lds_limit / lds)));
-            const long long items = (long long)((j.n_lines + 15) / 16) * j.n_images;
-            const int grid = (int)std::min<long long>(items, (long long)h->n_cus * per_cu);
-            j.tw = o.tw; j.bf = o.bf; j.bw = o.bw;
-            if (R == 32) {
-                (void)hipFuncSetAttribute((const void*)ifftTB_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
-                hipLaunchKernelGGL(ifftTB_kernel<32>, dim3(grid), dim3(512), lds, h->stream, j);
-            } else {
-                (void)hipFuncSetAttribute((const void*)ifftTB_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
-                hipLaunchKernelGGL(ifftTB_kernel<16>, dim3(grid), dim3(256), lds, h->stream, j);
-            }
-            HIPCHK(h, hipGetLastError());
-            return mark_launch(h, K_OTHER);
-        };
-        IfftTBJob a{};
-        a.in = TR; a.out_t = TRT; a.out_rows = nullptr;
-        a.in_is = a.out_t_is = (long long)npix; a.in_pitch = c.ny; a.out_t_pitch = c.nx; a.n_lines = c.nx; a.n_line = c.ny; a.n_images = c.nz;
-        a.potential = 0; a.rows_parity = -1;
-        if (herm_tb) a.n_lines = c.nx / 2 + 1;                  // the other rows are their mirror images (taken by the second pass's loads)
-        if ((rc = pass(cz_of(h->opy), a))) return rc;
-        IfftTBJob b{};
-        b.in = TRT; b.out_t = TR; b.out_rows = TRT;
-        b.in_is = b.out_t_is = b.out_rows_is = (long long)npix; b.in_pitch = c.nx; b.out_t_pitch = c.ny; b.out_rows_pitch = c.nx;
-        b.n_lines = c.ny; b.n_line = c.nx; b.n_images = c.nz; b.potential = 1; b.herm = herm_tb ? 1 : 0;
-        b.rows_parity = slice_is_transposed(h, 1) ? 1 : 0;       // the slices a pass along x reads stay in TRT as rows
-        b.scale = vscale; b.sigma_over_pi = (float)(c.sigma / M_PI);
-        if ((rc = pass(cz_of(h->opx), b))) return rc;
-    } else if (ifft_t2) {
-        // 512 / 2048 grids: two transposing inverse-FFT passes on the register kernels (TR -> TRT along y, TRT -> TR / TRT along
-        // x with the potential epilogue; slices a pass along x reads stay in TRT as rows)
-        auto pass = [&](int R, const IfftT2Job& j) -> int {
-            const int N2 = R * R, N = 2 * N2;
-            const size_t lds = (R == 32) ? ((size_t)2 * N2 + (size_t)16 * (N2 + 1)) * 8 : ((size_t)2 * N2 + (size_t)16 * (N + 1)) * 8;
-            const int per_cu = std::max(1, std::min(2, (int)((size_t)h->lds_limit / lds)));
-            const long long items = (long long)(j.n_lines / 16) * j.n_images;
-            const int grid = (int)std::min<long long>(items, (long long)h->n_cus * per_cu);
-            if (R == 32) {
-                (void)hipFuncSetAttribute((const void*)ifftT2_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
-                hipLaunchKernelGGL(ifftT2_kernel<32>, dim3(grid), dim3(512), lds, h->stream, j);
-            } else {
+            };
+            IfftTBJob a{};
+            a.in = TR; a.out_t = TRT; a.out_rows = nullptr;
+            a.in_is = a.out_t_is = (long long)npix; a.in_pitch = c.ny; a.out_t_pitch = c.nx; a.n_lines = c.nx; a.n_line = c.ny; a.n_images = n_slices;
+            a.potential = 0; a.rows_parity = -1; a.slice_mod = c.nz;
+            if (herm_tw) a.n_lines = (c.nx / 2 + 1 + 7) / 8 * 8;
+            if ((rc = passw(h->opy, a))) return rc;
+            IfftTBJob b{};
+            b.in = TRT; b.out_t = TR; b.out_rows = TRT;
+            b.in_is = b.out_t_is = b.out_rows_is = (long long)npix; b.in_pitch = c.nx; b.out_t_pitch = c.ny; b.out_rows_pitch = c.nx;
+            b.n_lines = c.ny; b.n_line = c.nx; b.n_images = n_slices; b.potential = 1; b.herm = herm_tw ? 1 : 0; b.slice_mod = c.nz;
+            b.rows_parity = slice_is_transposed(h, 1) ? 1 : 0;
+            b.scale = vscale; b.sigma_over_pi = (float)(c.sigma / M_PI);
+            if ((rc = passw(h->opx, b))) return rc;
+        } else if (ifft_tb) {
+            auto pass = [&](const CzRef& o, IfftTBJob j) -> int {
+                if (o.R == 64) {                                // 513 .. 1024 points: the wave-per-line 2048-point FFT
+                    constexpr int M2 = 2048, NH2 = 1024, RS = (32 * W2K_PITCH) / 2 + 1;
+                    const size_t lds2 = ((size_t)M2 + 64 + NH2 + 2 + NH2 + (size_t)8 * RS) * 8;
+                    const long long items2 = (long long)((j.n_lines + 7) / 8) * j.n_images;
+                    const int grid2 = (int)std::min<long long>(items2, (long long)h->n_cus);
+                    j.tw = o.tw; j.tw2 = o.tw2; j.bf = o.bf; j.bw = o.bw;
+                    (void)hipFuncSetAttribute((const void*)ifftTB2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
+                    hipLaunchKernelGGL(ifftTB2_kernel, dim3(grid2), dim3(512), lds2, h->stream, j);
+                    HIPCHK(h, hipGetLastError());
+                    return mark_launch(h, K_OTHER);
+                }
+                const int R = o.R, M = R * R, NH = M / 2, CS = R * (R + 1) + 2;
+                const size_t lds = ((size_t)M + NH + 2 + NH + (size_t)16 * CS) * 8;
+                const int per_cu = std::max(1, std::min(R == 16 ? 4 : 1, (int)((size_t)h->lds_limit / lds)));
+                const long long items = (long long)((j.n_lines + 15) / 16) * j.n_images;
+                const int grid = (int)std::min<long long>(items, (long long)h->n_cus * per_cu);
+                j.tw = o.tw; j.bf = o.bf; j.bw = o.bw;
+                if (R == 32) {
+                    (void)hipFuncSetAttribute((const void*)ifftTB_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
+                    hipLaunchKernelGGL(ifftTB_kernel<32>, dim3(grid), dim3(512), lds, h->stream, j);
+                } else {
+                    (void)hipFuncSetAttribute((const void*)ifftTB_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
+                    hipLaunchKernelGGL(ifftTB_kernel<16>, dim3(grid), dim3(256), lds, h->stream, j);
+                }
+                HIPCHK(h, hipGetLastError());
+                return mark_launch(h, K_OTHER);
+            };
+            IfftTBJob a{};
+            a.in = TR; a.out_t = TRT; a.out_rows = nullptr;
+            a.in_is = a.out_t_is = (long long)npix; a.in_pitch = c.ny; a.out_t_pitch = c.nx; a.n_lines = c.nx; a.n_line = c.ny; a.n_images = n_slices;
+            a.potential = 0; a.rows_parity = -1; a.slice_mod = c.nz;
+            if (herm_tb) a.n_lines = c.nx / 2 + 1;                  // the other rows are their mirror images (taken by the second pass's loads)
+            if ((rc = pass(cz_of(h->opy), a))) return rc;
+            IfftTBJob b{};
+            b.in = TRT; b.out_t = TR; b.out_rows = TRT;
+            b.in_is = b.out_t_is = b.out_rows_is = (long long)npix; b.in_pitch = c.nx; b.out_t_pitch = c.ny; b.out_rows_pitch = c.nx;
+            b.n_lines = c.ny; b.n_line = c.nx; b.n_images = n_slices; b.potential = 1; b.herm = herm_tb ? 1 : 0; b.slice_mod = c.nz;
+            b.rows_parity = slice_is_transposed(h, 1) ? 1 : 0;       // the slices a pass along x reads stay in TRT as rows
+            b.scale = vscale; b.sigma_over_pi = (float)(c.sigma / M_PI);
+            if ((rc = pass(cz_of(h->opx), b))) return rc;
+        } else if (ifft_t2) {
+            // 512 x 512 grids: two transposing inverse-FFT passes on the register kernels (TR -> TRT along y, TRT -> TR / TRT along
+            // x with the potential epilogue; slices a pass along x reads stay in TRT as rows)
+            auto pass = [&](const IfftT2Job& j) -> int {
+                constexpr int R = 16, N2 = R * R, N = 2 * N2;
+                const size_t lds = ((size_t)2 * N2 + (size_t)16 * (N + 1)) * 8;
+                const int per_cu = std::max(1, std::min(2, (int)((size_t)h->lds_limit / lds)));
+                const long long items = (long long)(j.n_lines / 16) * j.n_images;
+                const int grid = (int)std::min<long long>(items, (long long)h->n_cus * per_cu);
                 (void)hipFuncSetAttribute((const void*)ifftT2_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
                 hipLaunchKernelGGL(ifftT2_kernel<16>, dim3(grid), dim3(256), lds, h->stream, j);
-            }
-            HIPCHK(h, hipGetLastError());
-            return mark_launch(h, K_OTHER);
-        };
-        IfftT2Job a{};
-        a.in = TR; a.out_t = TRT; a.out_rows = nullptr; a.tw = h->opy.tw; a.tw2 = h->opy.tw2;
-        a.in_is = a.out_t_is = (long long)npix; a.in_pitch = c.ny; a.out_t_pitch = c.nx; a.n_lines = c.nx; a.n_images = c.nz;
-        a.potential = 0; a.rows_parity = -1;
-        if (herm_t2) a.n_lines = (c.nx / 2 + 1 + 15) / 16 * 16;        // rows kx <= nx/2 in whole 16-line blocks (the surplus rows are never read)
-        if ((rc = pass(h->opy.R, a))) return rc;
-        IfftT2Job b{};
-        b.in = TRT; b.out_t = TR; b.out_rows = TRT; b.tw = h->opx.tw; b.tw2 = h->opx.tw2;
-        b.in_is = b.out_t_is = b.out_rows_is = (long long)npix; b.in_pitch = c.nx; b.out_t_pitch = c.ny; b.out_rows_pitch = c.nx;
-        b.n_lines = c.ny; b.n_images = c.nz; b.potential = 1; b.rows_parity = 1;      // scheme b: slice s is read along x iff s is odd
-        b.herm = herm_t2 ? 1 : 0;
-        b.scale = vscale; b.sigma_over_pi = (float)(c.sigma / M_PI);
-        if ((rc = pass(h->opx.R, b))) return rc;
-    } else if (h->Ry) {
-        RowJob r = row_job(h, TR, c.nz, c.ny);
-        r.do_ifft = 1;
-        if (herm_ifft) { const int G = 256 / h->Ry; r.nx = (c.nx / 2 + 1 + G - 1) / G * G; }     // whole row groups (the surplus rows are never read)
-        if ((rc = launch_row_fast(h, r, K_OTHER))) return rc;
-    } else {
-        LineArgs r = row_args(h, TR, TR, c.nz, c.ny);
-        r.fft1 = -1;
-        if ((rc = launch_lines(h, h->plan_y, r, K_OTHER))) return rc;
+                HIPCHK(h, hipGetLastError());
+                return mark_launch(h, K_OTHER);
+            };
+            IfftT2Job a{};
+            a.in = TR; a.out_t = TRT; a.out_rows = nullptr; a.tw = h->opy.tw; a.tw2 = h->opy.tw2;
+            a.in_is = a.out_t_is = (long long)npix; a.in_pitch = c.ny; a.out_t_pitch = c.nx; a.n_lines = c.nx; a.n_images = n_slices;
+            a.potential = 0; a.rows_parity = -1; a.slice_mod = c.nz;
+            if (herm_t2) a.n_lines = (c.nx / 2 + 1 + 15) / 16 * 16;        // rows kx <= nx/2 in whole 16-line blocks (the surplus rows are never read)
+            if ((rc = pass(a))) return rc;
+            IfftT2Job b{};
+            b.in = TRT; b.out_t = TR; b.out_rows = TRT; b.tw = h->opx.tw; b.tw2 = h->opx.tw2;
+            b.in_is = b.out_t_is = b.out_rows_is = (long long)npix; b.in_pitch = c.nx; b.out_t_pitch = c.ny; b.out_rows_pitch = c.nx;
+            b.n_lines = c.ny; b.n_images = n_slices; b.potential = 1; b.rows_parity = 1; b.slice_mod = c.nz;      // scheme b: slice s is read along x iff s is odd
+            b.herm = herm_t2 ? 1 : 0;
+            b.scale = vscale; b.sigma_over_pi = (float)(c.sigma / M_PI);
+            if ((rc = pass(b))) return rc;
+        } else if (h->Ry) {
+            RowJob r = row_job(h, TR, n_slices, c.ny);
+            r.do_ifft = 1;
+            if (herm_ifft) { const int Gr = 256 / h->Ry; r.nx = (c.nx / 2 + 1 + Gr - 1) / Gr * Gr; }     // whole row groups (the surplus rows are never read)
+            if ((rc = launch_row_fast(h, r, K_OTHER))) return rc;
+        } else {
+            LineArgs r = row_args(h, TR, TR, n_slices, c.ny);
+            r.fft1 = -1;
+            if ((rc = launch_lines(h, h->plan_y, r, K_OTHER))) return rc;
+        }
+        if (ifft_t2 || ifft_tb || ifft_tw) {
+            // (both passes done above)
+        } else if (h->Rx) {
+            ColJob k = col_job(h, TR, TR, n_slices, c.ny, c.ny);
+            k.flags = COL_INV | COL_POTENTIAL; k.scale = vscale; k.sigma = (float)c.sigma; k.out_real = h->V; k.slice_mod = c.nz;
+            // (a kept V is written by the untransposed store only: with keep_potential the x-pass slices are transposed afterwards)
+            if (h->onepass && !h->V) { k.flags |= COL_TPOT; k.tparity = h->scheme_b ? 0 : ((c.nz - 1) & 1); k.out_t = TRT; }
+            if ((rc = herm_ifft ? launch_col_herm(h, k, K_OTHER) : launch_col_fast(h, k, K_OTHER))) return rc;
+            if (h->onepass && h->V && (rc = transpose_odd_slices(h))) return rc;
+        } else {
+            LineArgs k = col_args(h, TR, TR, n_slices, c.ny, c.ny);
+            k.fft1 = -1;
+            k.scale = vscale;
+            k.store_mode = STORE_POTENTIAL; k.out_real = h->V; k.sigma = (float)c.sigma;
+            if ((rc = launch_lines(h, h->plan_x, k, K_OTHER))) return rc;
+            const int saved = h->cur_batch;                         // one-pass loop on such a grid: x-pass slices transposed, stack by stack
+            for (int f = 0; f < g && rc == MSL_OK; ++f) { h->cur_batch = slot + f; rc = transpose_odd_slices(h); }
+            h->cur_batch = saved;
+            if (rc) return rc;
+        }
     }
-    if (ifft_t2 || ifft_tb || ifft_tw) {
-        // (both passes done above)
-    } else if (h->Rx) {
-        ColJob k = col_job(h, TR, TR, c.nz, c.ny, c.ny);
-        k.flags = COL_INV | COL_POTENTIAL; k.scale = vscale; k.sigma = (float)c.sigma; k.out_real = h->V;
-        // (a kept V is written by the untransposed store only: with keep_potential the x-pass slices are transposed afterwards)
-        if (h->onepass && !h->V) { k.flags |= COL_TPOT; k.tparity = h->scheme_b ? 0 : ((c.nz - 1) & 1); k.out_t = TRT; }
-        if ((rc = herm_ifft ? launch_col_herm(h, k, K_OTHER) : launch_col_fast(h, k, K_OTHER))) return rc;
-        if (h->onepass && h->V && (rc = transpose_odd_slices(h))) return rc;
-    } else {
-        LineArgs k = col_args(h, TR, TR, c.nz, c.ny, c.ny);
-        k.fft1 = -1;
-        k.scale = vscale;
-        k.store_mode = STORE_POTENTIAL; k.out_real = h->V; k.sigma = (float)c.sigma;
-        if ((rc = launch_lines(h, h->plan_x, k, K_OTHER))) return rc;
-        if ((rc = transpose_odd_slices(h))) return rc;          // one-pass loop on a 2R^2 grid: x-pass slices transposed
-    }
+    h->n_species = nsp;
     if (timed) {
         HIPCHK(h, hipEventRecord(e1, h->stream));
         HIPCHK(h, hipEventSynchronize(e1));
@@ -1978,6 +1868,34 @@ int msl_build_potential(msl_handle* h, const double* pos, const int32_t* Z, int6
     }
     h->have_potential = true;
     return MSL_OK;
+}
+
+static int check_potential_args(msl_handle* h, const char* who, const double* pos, const int32_t* Z, int64_t n, int32_t ax1, int32_t ax2, int32_t axs) {
+    if (!h || (n > 0 && (!pos || !Z))) return fail(h, MSL_ERR_INVALID, "%s: null argument", who);
+    if (!h->have_kirkland) return fail(h, MSL_ERR_STATE, "%s: call msl_set_kirkland first", who);
+    if (!h->have_slices) return fail(h, MSL_ERR_STATE, "%s: call msl_set_slices first", who);
+    if (n < 0 || n > 0x7fffffff) return fail(h, MSL_ERR_INVALID, "%s: bad atom count", who);
+    if (ax1 < 0 || ax1 > 2 || ax2 < 0 || ax2 > 2 || axs < 0 || axs > 2 || ((1 << ax1) | (1 << ax2) | (1 << axs)) != 7)
+        return fail(h, MSL_ERR_INVALID, "%s: axes must be a permutation of 0,1,2", who);
+    return MSL_OK;
+}
+
+int msl_build_potential(msl_handle* h, const double* pos, const int32_t* Z, int64_t n, int32_t ax1, int32_t ax2, int32_t axs) {
+    int rc = check_potential_args(h, "msl_build_potential", pos, Z, n, ax1, ax2, axs);
+    if (rc) return rc;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    return build_potentials(h, pos, Z, n, 1, h->cur_batch, ax1, ax2, axs);
+}
+
+int msl_build_potentials(msl_handle* h, const double* pos, const int32_t* Z, int64_t n, int32_t count, int32_t ax1, int32_t ax2, int32_t axs) {
+    int rc = check_potential_args(h, "msl_build_potentials", pos, Z, n, ax1, ax2, axs);
+    if (rc) return rc;
+    if (count < 1 || count > h->FB) return fail(h, MSL_ERR_INVALID, "msl_build_potentials: count %d outside [1,%d] (msl_config.frame_batch)", count, h->FB);
+    if ((int64_t)n * count > 0x7fffffffLL) return fail(h, MSL_ERR_INVALID, "msl_build_potentials: more than 2^31 atoms in one batch");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    rc = build_potentials(h, pos, Z, n, count, 0, ax1, ax2, axs);
+    if (rc == MSL_OK) h->cur_batch = count - 1;         // the current stack (MSL_BUF_TRANSMISSION, msl_propagate) is the last frame's, as after `count` single builds
+    return rc;
 }
 
 int msl_upload_potential(msl_handle* h, const float* V) {
@@ -2076,9 +1994,9 @@ int msl_tacaw(msl_handle* h, const void* d_src, void* d_dst, int64_t batch, int3
     if (batch < 1 || npix < 1) return fail(h, MSL_ERR_INVALID, "msl_tacaw: bad batch/npix");
     if (npix > 0x7fffffffLL) return fail(h, MSL_ERR_UNSUPPORTED, "msl_tacaw: npix too large");
     const int Rt = (c.fft_path == 0) ? fast_radix(T) : 0;           // 256 or 1024 frames: four-step column kernel
-    const bool fast_t = Rt && (npix % 16 == 0) && npix >= 32 && !getenv("MSL_TACAW_GENERIC");
+    const bool fast_t = Rt && (npix % 16 == 0) && npix >= 32 && !dbg_env("MSL_TACAW_GENERIC");
     // any other frame count up to 512: chirp-z on the register FFTs (time_cz_kernel), 32-pixel tiles for T <= 128, else 16
-    const bool cz_t = !fast_t && c.fft_path == 0 && T <= 512 && (npix % 16 == 0) && !getenv("MSL_TACAW_GENERIC");
+    const bool cz_t = !fast_t && c.fft_path == 0 && T <= 512 && (npix % 16 == 0) && !dbg_env("MSL_TACAW_GENERIC");
     int rc = MSL_OK;
     float2* tw4_t = nullptr;
     if (fast_t) {
@@ -2119,7 +2037,7 @@ int msl_tacaw(msl_handle* h, const void* d_src, void* d_dst, int64_t batch, int3
         j.in_image_stride = j.out_image_stride = (long long)T * npix;
         j.in_pitch = j.out_pitch = (int)npix; j.ny = (int)npix; j.n_images = (int)batch;
         j.flags = COL_FWD | COL_INTENSITY; j.scale = 1.f;
-        if (Rt == 16 && npix % 32 == 0 && !getenv("MSL_TACAW_COLS16")) {
+        if (Rt == 16 && npix % 32 == 0 && !dbg_env("MSL_TACAW_COLS16")) {
             rc = launch_col_time<32>(h, j, K_OTHER);          // 64-pixel tiles (one workgroup per CU): 47.9 vs 41.7 ms
         } else {
             const int saved = h->Rx;

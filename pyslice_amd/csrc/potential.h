@@ -37,17 +37,20 @@ __global__ void formfactor_kernel(float* __restrict__ ff, const double* __restri
     ff[i] = (float)(s1 + s2);
 }
 
-// Per atom: species index, slice index -> sort key (or -1 when the atom belongs to no slice /
-// unknown species), and fractional in-plane coordinates.  Slice rule: potentials.py:302-307.
-__global__ void atom_prep_kernel(const double* __restrict__ pos, const int* __restrict__ Z, long long n,
+// Per atom of a group of G frames (a = frame * n + i; the species Z[i] are the same in every frame): species index and slice
+// index -> sort key (frame * nz + slice) * n_species + species (or -1 when the atom belongs to no slice / unknown species), and
+// fractional in-plane coordinates.  Slice rule: potentials.py:302-307.
+__global__ void atom_prep_kernel(const double* __restrict__ pos, const int* __restrict__ Z, long long n, int n_frames,
                                  const int* __restrict__ z_to_species, const double* __restrict__ lo,
                                  const double* __restrict__ hi, int nz, int n_species, int ax1, int ax2, int axs,
                                  double inv_l1, double inv_l2, int* __restrict__ key, double* __restrict__ u1,
                                  double* __restrict__ u2, int* __restrict__ counts) {
     long long a = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (a >= n) return;
+    if (a >= n * n_frames) return;
+    const int frame = (int)(a / n);
+    const long long i = a - (long long)frame * n;
     double zc = pos[a * 3 + axs];
-    int zz = Z[a];
+    int zz = Z[i];
     int sp = (zz >= 1 && zz <= 103) ? z_to_species[zz] : -1;
     // binary search for the last slice with lo[s] <= zc, then test the reference's [lo,hi) masks
     int s = -1;
@@ -61,34 +64,48 @@ __global__ void atom_prep_kernel(const double* __restrict__ pos, const int* __re
             if (zc >= lo[c] && zc < hi[c]) { s = c; break; }
         }
     }
-    int k = (s >= 0 && sp >= 0) ? s * n_species + sp : -1;
+    int k = (s >= 0 && sp >= 0) ? (frame * nz + s) * n_species + sp : -1;
     key[a] = k;
     u1[a] = pos[a * 3 + ax1] * inv_l1;
     u2[a] = pos[a * 3 + ax2] * inv_l2;
     if (k >= 0) atomicAdd(&counts[k], 1);
 }
 
-// Exclusive scan of the (nz*n_species) bin counts; one workgroup, serial over a small array.
-__global__ void bin_scan_kernel(const int* __restrict__ counts, int* __restrict__ start, int nkeys) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        int acc = 0;
-        for (int i = 0; i < nkeys; ++i) { start[i] = acc; acc += counts[i]; }
-        start[nkeys] = acc;
+// Exclusive scan of the bin counts (frames x slices x species of a group: up to a few thousand); one workgroup of 1024 threads,
+// every thread a contiguous share, the shares' totals scanned through the LDS.  start[nkeys] = number of atoms inside a slice.
+__global__ void __launch_bounds__(1024) bin_scan_kernel(const int* __restrict__ counts, int* __restrict__ start, int nkeys) {
+    __shared__ int part[1024];
+    const int t = threadIdx.x;
+    const int per = (nkeys + 1023) / 1024;
+    const int i0 = t * per, i1 = min(nkeys, i0 + per);
+    int acc = 0;
+    for (int i = i0; i < i1; ++i) acc += counts[i];
+    part[t] = acc;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {            // inclusive Hillis-Steele scan of the 1024 share totals
+        const int v = (t >= off) ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
     }
+    int run = part[t] - acc;                               // exclusive prefix of this share
+    for (int i = i0; i < i1; ++i) { start[i] = run; run += counts[i]; }
+    if (t == 1023) start[nkeys] = part[1023];
 }
 
 // Stable compaction: one 1024-thread workgroup per key collects its atoms in original order (deterministic sums).
-// Every wave scans a contiguous share of the atoms twice: once to count its matches, then -- after an exclusive prefix
-// over the 16 waves -- to write them.
-__global__ void __launch_bounds__(1024) bin_fill_kernel(const int* __restrict__ key, long long n, const int* __restrict__ start,
-                                                        int* __restrict__ order) {
+// Every wave scans a contiguous share of the key's FRAME (n atoms) twice: once to count its matches, then -- after an exclusive
+// prefix over the 16 waves -- to write them.
+__global__ void __launch_bounds__(1024) bin_fill_kernel(const int* __restrict__ key, long long n, int keys_per_frame,
+                                                        const int* __restrict__ start, int* __restrict__ order) {
     __shared__ int wave_count[16];
     const int mykey = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int base = start[mykey];
     if (start[mykey + 1] == base) return;                       // uniform for the workgroup
+    const long long a_first = (long long)(mykey / keys_per_frame) * n;
     const long long per = ((n + 16 * 64 - 1) / (16 * 64)) * 64;   // atoms per wave, a multiple of 64
-    const long long lo = per * wave, hi = (lo + per < n) ? lo + per : n;
+    const long long lo = a_first + per * wave, hi = (per * (wave + 1) < n) ? lo + per : a_first + n;
     int cnt = 0;
     for (long long a0 = lo; a0 < hi; a0 += 64) {
         const long long a = a0 + lane;
@@ -123,174 +140,55 @@ __global__ void phase_table_kernel(float2* __restrict__ table, const double* __r
     table[(long long)a * pitch + m] = make_float2(cs, sn);
 }
 
-// R[s][kx][ky] = sum_species ff[sp][kx][ky] * sum_{atoms of (s,sp)} ex[a][kx] * ey[a][ky]
-// 64x64 output tile per workgroup, 4x4 complex micro-tile per thread, atoms staged through LDS.
-#define SF_TILE 64
-#define SF_ATOMS 16
-__global__ void __launch_bounds__(256) structure_factor_kernel(float2* __restrict__ recip,
-                                                               const float2* __restrict__ ex,
-                                                               const float2* __restrict__ ey,
-                                                               const float* __restrict__ ff,
-                                                               const int* __restrict__ start, int n_species, int nx,
-                                                               int ny, int tiles_y) {
-    __shared__ float2 sx[SF_ATOMS][SF_TILE];
-    __shared__ float2 sy[SF_ATOMS][SF_TILE];
-    const int s = blockIdx.y;
-    const int tile = blockIdx.x;
-    const int kx0 = (tile / tiles_y) * SF_TILE, ky0 = (tile % tiles_y) * SF_TILE;
-    const int tid = threadIdx.x;
-    const int tx = tid & 15, ty = tid >> 4;
-    float2 total[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) total[i][j] = make_float2(0.f, 0.f);
-
-    for (int sp = 0; sp < n_species; ++sp) {
-        const int a_begin = start[s * n_species + sp], a_end = start[s * n_species + sp + 1];
-        if (a_begin == a_end) continue;
-        float2 acc[4][4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = make_float2(0.f, 0.f);
-        for (int a0 = a_begin; a0 < a_end; a0 += SF_ATOMS) {
-            __syncthreads();
-            // stage SF_ATOMS x 64 phases of each axis (zero-fill past the segment / the grid edge)
-            for (int e = tid; e < SF_ATOMS * SF_TILE; e += 256) {
-                int a = e / SF_TILE, m = e % SF_TILE;
-                bool ok = (a0 + a) < a_end;
-                sx[a][m] = (ok && kx0 + m < nx) ? ex[(size_t)(a0 + a) * nx + kx0 + m] : make_float2(0.f, 0.f);
-                sy[a][m] = (ok && ky0 + m < ny) ? ey[(size_t)(a0 + a) * ny + ky0 + m] : make_float2(0.f, 0.f);
-            }
-            __syncthreads();
-#pragma unroll 4
-            for (int a = 0; a < SF_ATOMS; ++a) {
-                float2 vx[4], vy[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { vx[i] = sx[a][tx * 4 + i]; vy[i] = sy[a][ty * 4 + i]; }
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        acc[i][j].x = fmaf(vx[i].x, vy[j].x, fmaf(-vx[i].y, vy[j].y, acc[i][j].x));
-                        acc[i][j].y = fmaf(vx[i].x, vy[j].y, fmaf(vx[i].y, vy[j].x, acc[i][j].y));
-                    }
-            }
-        }
-        const float* f = ff + (size_t)sp * nx * ny;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int kx = kx0 + tx * 4 + i;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                int ky = ky0 + ty * 4 + j;
-                if (kx < nx && ky < ny) {
-                    float w = f[(size_t)kx * ny + ky];
-                    total[i][j].x = fmaf(w, acc[i][j].x, total[i][j].x);
-                    total[i][j].y = fmaf(w, acc[i][j].y, total[i][j].y);
-                }
-            }
-        }
-    }
-    float2* out = recip + (size_t)s * nx * ny;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int kx = kx0 + tx * 4 + i;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int ky = ky0 + ty * 4 + j;
-            if (kx < nx && ky < ny) out[(size_t)kx * ny + ky] = total[i][j];
-        }
-    }
-}
-
-// The same accumulation on the matrix cores.  S = sum_a ex_a (x) ey_a is a complex GEMM with a short inner
-// dimension (atoms of one species in one slice); gfx950's exact-f32 MFMA (v_mfma_f32_32x32x2_f32) runs at twice the
-// rate a scalar-f32 VALU kernel reaches (77 TFLOP/s measured, tools/valubench.hip; the VALU kernel above sits at 72).
-// One wave owns a 32 x 32 output tile: A[i][k] = ex[atom k][kx0+i], B[k][j] = ey[atom k][ky0+j], two atoms per
-// instruction (lanes 0-31 / 32-63), four real MFMAs per complex product, Re/Im accumulators 2 x 16 VGPRs.
+// R[s][kx][ky] = sum_species ff[sp][kx][ky] * sum_{atoms of (s,sp)} ex[a][kx] * ey[a][ky]          (potentials.py:323-330)
+// S = sum_a ex_a (x) ey_a is a complex GEMM with a short inner dimension (atoms of one species in one slice) -- the one
+// GEMM-shaped step of the path: gfx950's exact-f32 MFMA (v_mfma_f32_32x32x2_f32), one wave per 32 x 32 tile, two atoms per
+// instruction (lanes 0-31 / 32-63).
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-__global__ void __launch_bounds__(256) structure_factor_mfma_kernel(float2* __restrict__ recip,
-                                                                    const float2* __restrict__ ex,
-                                                                    const float2* __restrict__ ey,
-                                                                    const float* __restrict__ ff,
-                                                                    const int* __restrict__ start, int n_species,
-                                                                    int nx, int ny, int tiles_y, int n_tiles) {
-    const int s = blockIdx.y;
-    const int lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tile >= n_tiles) return;
-    const int kx0 = (tile / tiles_y) * 32, ky0 = (tile % tiles_y) * 32;
-    const int i = lane & 31, kk = lane >> 5;
-    f32x16 tot_re = {0}, tot_im = {0};
-    for (int sp = 0; sp < n_species; ++sp) {
-        const int a0 = start[s * n_species + sp], a1 = start[s * n_species + sp + 1];
-        if (a0 == a1) continue;
-        f32x16 acc_re = {0}, acc_im = {0};
-        const float2* px = ex + (size_t)(a0 + kk) * nx + kx0 + i;
-        const float2* py = ey + (size_t)(a0 + kk) * ny + ky0 + i;
-        // 8 atoms (4 MFMA k-steps) per trip, software-pipelined: the loads of trip i+1 are in flight while the
-        // sixteen MFMAs of trip i run (matrix pipe 49 % -> 61 % busy; a 32 x 64 block per wave was slower: occupancy)
-        auto load8 = [&](int a, float2 (&x)[4], float2 (&y)[4]) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                x[u] = make_float2(0.f, 0.f); y[u] = make_float2(0.f, 0.f);
-                if (a + 2 * u < a1) { x[u] = px[(size_t)(2 * u) * nx]; y[u] = py[(size_t)(2 * u) * ny]; }
-            }
-            px += 8 * (size_t)nx; py += 8 * (size_t)ny;
-        };
-        float2 xn[4], yn[4];
-        load8(a0 + kk, xn, yn);
-        for (int a = a0 + kk; a < a1 + kk; a += 8) {           // same trip count for both lane halves
-            float2 x[4], y[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { x[u] = xn[u]; y[u] = yn[u]; }
-            load8(a + 8, xn, yn);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                acc_re = __builtin_amdgcn_mfma_f32_32x32x2f32(x[u].x, y[u].x, acc_re, 0, 0, 0);
-                acc_im = __builtin_amdgcn_mfma_f32_32x32x2f32(x[u].x, y[u].y, acc_im, 0, 0, 0);
-                acc_re = __builtin_amdgcn_mfma_f32_32x32x2f32(-x[u].y, y[u].y, acc_re, 0, 0, 0);
-                acc_im = __builtin_amdgcn_mfma_f32_32x32x2f32(x[u].y, y[u].x, acc_im, 0, 0, 0);
-            }
-        }
-        const float* f = ff + (size_t)sp * nx * ny;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;      // C/D layout of the 32x32 MFMA
-            const float w = f[(size_t)(kx0 + row) * ny + ky0 + i];
-            tot_re[r] = fmaf(w, acc_re[r], tot_re[r]);
-            tot_im[r] = fmaf(w, acc_im[r], tot_im[r]);
-        }
-    }
-    float2* out = recip + (size_t)s * nx * ny;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
-        out[(size_t)(kx0 + row) * ny + ky0 + i] = make_float2(tot_re[r], tot_im[r]);
-    }
-}
 
-// Quadrant form of the matrix-core kernel (default).  With x = ex[a][mx] = (c_x, -s_x), y = ey[a][my] = (c_y, -s_y) the four real
-// products an atom contributes,  A = x.x y.x,  B = x.y y.y,  C = x.x y.y,  D = x.y y.x,  give the bin and its three mirror images:
+// The four real products an atom contributes, with x = ex[a][mx] = (c_x, -s_x), y = ey[a][my] = (c_y, -s_y):
+//     A = x.x y.x,  B = x.y y.y,  C = x.x y.y,  D = x.y y.x
+// give the bin and its three mirror images:
 //     S[ mx,  my] = (A - B,  C + D)      S[-mx,  my] = (A + B,  C - D)
 //     S[ mx, -my] = (A + B, -C + D)      S[-mx, -my] = (A - B, -C - D)
-// (the phase table is exactly conjugate-symmetric, ex[a][n-m] = conj ex[a][m], and f_Z depends on mx^2, my^2 only).  A wave
-// therefore accumulates A, B, C, D separately -- the same four MFMAs per atom pair as the complex product -- over a 32 x 32
-// tile of the non-negative frequencies 0..n/2 only and writes up to four bins per accumulator element: a quarter of the
-// arithmetic of the full grid, half of the Hermitian form, any nx, ny (loads clamped, stores guarded), and neither the
-// Nyquist nor the mirror kernel.  Bins on the axes (m = 0) and on the Nyquist lines (2m = n) are their own mirror image.
+// (the phase table is exactly conjugate-symmetric, ex[a][n-m] = conj ex[a][m], and f_Z depends on mx^2, my^2 only).  Bins on the
+// axes (m = 0) and on the Nyquist lines (2m = n) are their own mirror image.
+// write_mx == 0: the inverse transform takes rows 0 .. nx/2 only and rebuilds row nx - mx as the conjugate of row mx, which is
+// exact for every bin but the Nyquist column, where the grid's one frequency -ny/2 serves both signs and R[-mx] is NOT conj
+// R[mx].  Re(ifft2) keeps the Hermitian part, (R[mx, ny/2] + conj R[-mx, ny/2]) / 2 = (A, D): stored there in that mode.
+__device__ __forceinline__ void store_quad_bin(float2* __restrict__ out, int nx, int ny, int mx, int my, float A, float B, float C,
+                                               float D, int write_mx) {
+    const bool mir_x = write_mx && mx > 0 && 2 * mx != nx;
+    const bool mir_y = my > 0 && 2 * my != ny;
+    const float dre = A - B, sre = A + B, sim = C + D, dim = C - D;
+    const bool herm_col = !write_mx && 2 * my == ny && 2 * mx != nx;
+    out[(size_t)mx * ny + my] = herm_col ? make_float2(A, D) : make_float2(dre, sim);
+    if (mir_x) out[(size_t)(nx - mx) * ny + my] = make_float2(sre, dim);
+    if (mir_y) out[(size_t)mx * ny + (ny - my)] = make_float2(sre, -dim);
+    if (mir_x && mir_y) out[(size_t)(nx - mx) * ny + (ny - my)] = make_float2(dre, -sim);
+}
+
+// Quadrant kernel: a wave accumulates A, B, C, D separately -- the same four MFMAs per atom pair as the complex product -- over a
+// 32 x 32 tile of the non-negative frequencies only and writes up to four bins per accumulator element: a quarter of the
+// arithmetic of the full grid, any nx, ny (loads clamped, stores guarded).
+// Grid: one dimension, n_slices (= frames of the group x nz) x wg_per_slice workgroups of four tiles, dealt so that all
+// workgroups of a slice run on ONE XCD (workgroups are dealt round-robin over the 8 XCDs: blockIdx % 8 share an L2): a slice's
+// phase-table rows are then fetched into one L2 instead of all eight (round 2: 5.3 x the algorithmic traffic at 1024^2, 11 x
+// at 2048^2).  tiles_x x tiles_y tiles cover the frequencies [0, 32 tiles); a Nyquist row / column left over by a power-of-two
+// grid (n/2 + 1 = 32 k + 1) goes to structure_factor_edge_kernel instead of a 33rd tile row of which 1/32 is used.
 __global__ void __launch_bounds__(256) structure_factor_quad_kernel(float2* __restrict__ recip,
                                                                     const float2* __restrict__ ex,
                                                                     const float2* __restrict__ ey,
                                                                     const float* __restrict__ ff,
                                                                     const int* __restrict__ start, int n_species,
                                                                     int nx, int ny, int tiles_y, int n_tiles, int n_rows,
-                                                                    int write_mx, int px_pitch, int py_pitch) {
-    const int s = blockIdx.y;
+                                                                    int write_mx, int px_pitch, int py_pitch, int n_slices,
+                                                                    int wg_per_slice) {
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    const int s = (jj / wg_per_slice) * 8 + xcd;
+    if (s >= n_slices) return;
     const int lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int tile = (jj % wg_per_slice) * 4 + (threadIdx.x >> 6);
     if (tile >= n_tiles) return;
     const int hx = nx / 2, hy = ny / 2;                     // largest non-negative frequency index of each axis
     const int kx0 = (tile / tiles_y) * 32, ky0 = (tile % tiles_y) * 32;
@@ -342,72 +240,50 @@ __global__ void __launch_bounds__(256) structure_factor_quad_kernel(float2* __re
     float2* out = recip + (size_t)s * nx * ny;
     const int my = ky0 + i;
     if (my > hy) return;
-    const bool mir_y = my > 0 && 2 * my != ny;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int mx = kx0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
         if (mx > hx) continue;
-        const bool mir_x = write_mx && mx > 0 && 2 * mx != nx;    // write_mx == 0: the inverse transform takes rows 0 .. nx/2 only
-        const float dre = tA[r] - tB[r], sre = tA[r] + tB[r], sim = tC[r] + tD[r], dim = tC[r] - tD[r];
-        // Rows 0 .. nx/2 only (write_mx == 0): the column pass rebuilds row nx - mx as the conjugate of row mx, which is exact
-        // for every bin but the Nyquist column, where the grid's one frequency -ny/2 serves both signs and R[-mx] is NOT conj
-        // R[mx].  Re(ifft2) keeps the Hermitian part, (R[mx, ny/2] + conj R[-mx, ny/2]) / 2 = (A, D): store that.
-        const bool herm_col = !write_mx && 2 * my == ny && 2 * mx != nx;
-        out[(size_t)mx * ny + my] = herm_col ? make_float2(tA[r], tD[r]) : make_float2(dre, sim);
-        if (mir_x) out[(size_t)(nx - mx) * ny + my] = make_float2(sre, dim);
-        if (mir_y) out[(size_t)mx * ny + (ny - my)] = make_float2(sre, -dim);
-        if (mir_x && mir_y) out[(size_t)(nx - mx) * ny + (ny - my)] = make_float2(dre, -sim);
+        store_quad_bin(out, nx, ny, mx, my, tA[r], tB[r], tC[r], tD[r], write_mx);
     }
 }
 
-// Hermitian shortcut for even nx, ny: R_s[-k] = conj(R_s[k]) for every bin that has a mirror partner.  The tile
-// kernel then only computes rows mx < nx/2; this kernel adds the bins without a partner -- the Nyquist row
-// mx = nx/2 (all my) and the Nyquist column my = ny/2 of the rows mx > nx/2 -- by direct summation.
-__global__ void structure_factor_nyquist_kernel(float2* __restrict__ recip, const float2* __restrict__ ex,
-                                                const float2* __restrict__ ey, const float* __restrict__ ff,
-                                                const int* __restrict__ start, int n_species, int nx, int ny) {
+// The Nyquist row mx = nx/2 (edge_x) and / or column my = ny/2 (edge_y) of a slice by direct summation -- (nx/2 + ny/2 + 1) bins
+// x the slice's atoms: along the row every thread shares the atom's x phase and reads consecutive y phases, along the column the
+// other way round, so the table reads are broadcast + coalesced.  grid (ceil(bins / 128), n_slices), 128 threads.
+__global__ void __launch_bounds__(128) structure_factor_edge_kernel(float2* __restrict__ recip, const float2* __restrict__ ex,
+                                                                    const float2* __restrict__ ey, const float* __restrict__ ff,
+                                                                    const int* __restrict__ start, int n_species, int nx, int ny,
+                                                                    int edge_x, int edge_y, int write_mx, int px_pitch, int py_pitch) {
     const int s = blockIdx.y;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;      // 0..ny-1: row bins, ny..ny+nx/2-2: column bins
-    int mx, my;
-    if (i < ny) { mx = nx / 2; my = i; }
-    else if (i < ny + nx / 2 - 1) { mx = nx / 2 + 1 + (i - ny); my = ny / 2; }
-    else return;
-    float2 total = make_float2(0.f, 0.f);
+    const int hx = nx / 2, hy = ny / 2;
+    const int n_row = edge_x ? hy + 1 : 0;                  // bins (hx, 0 .. hy)
+    const int n_col = edge_y ? (edge_x ? hx : hx + 1) : 0;  // bins (0 .. hx [- 1: the corner belongs to the row], hy)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_row + n_col) return;
+    const int mx = i < n_row ? hx : i - n_row, my = i < n_row ? i : hy;
+    float tA = 0.f, tB = 0.f, tC = 0.f, tD = 0.f;
     for (int sp = 0; sp < n_species; ++sp) {
         const int a0 = start[s * n_species + sp], a1 = start[s * n_species + sp + 1];
-        float2 acc = make_float2(0.f, 0.f);
+        float A = 0.f, B = 0.f, C = 0.f, D = 0.f;
         int a = a0;
         for (; a + 8 <= a1; a += 8) {                           // eight atoms' loads in flight; summation order unchanged
-            float2 vx[8], vy[8];
+            float2 x[8], y[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { vx[u] = ex[(size_t)(a + u) * nx + mx]; vy[u] = ey[(size_t)(a + u) * ny + my]; }
+            for (int u = 0; u < 8; ++u) { x[u] = ex[(size_t)(a + u) * px_pitch + mx]; y[u] = ey[(size_t)(a + u) * py_pitch + my]; }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                acc.x = fmaf(vx[u].x, vy[u].x, fmaf(-vx[u].y, vy[u].y, acc.x));
-                acc.y = fmaf(vx[u].x, vy[u].y, fmaf(vx[u].y, vy[u].x, acc.y));
+                A = fmaf(x[u].x, y[u].x, A); B = fmaf(x[u].y, y[u].y, B); C = fmaf(x[u].x, y[u].y, C); D = fmaf(x[u].y, y[u].x, D);
             }
         }
         for (; a < a1; ++a) {
-            const float2 vx = ex[(size_t)a * nx + mx], vy = ey[(size_t)a * ny + my];
-            acc.x = fmaf(vx.x, vy.x, fmaf(-vx.y, vy.y, acc.x));
-            acc.y = fmaf(vx.x, vy.y, fmaf(vx.y, vy.x, acc.y));
+            const float2 x = ex[(size_t)a * px_pitch + mx], y = ey[(size_t)a * py_pitch + my];
+            A = fmaf(x.x, y.x, A); B = fmaf(x.y, y.y, B); C = fmaf(x.x, y.y, C); D = fmaf(x.y, y.x, D);
         }
         const float w = ff[(size_t)sp * nx * ny + (size_t)mx * ny + my];
-        total.x = fmaf(w, acc.x, total.x);
-        total.y = fmaf(w, acc.y, total.y);
+        tA = fmaf(w, A, tA); tB = fmaf(w, B, tB); tC = fmaf(w, C, tC); tD = fmaf(w, D, tD);
     }
-    recip[(size_t)s * nx * ny + (size_t)mx * ny + my] = total;
-}
-
-// rows mx > nx/2 (except the Nyquist column): R[mx][my] = conj(R[nx-mx][(ny-my)%ny])
-__global__ void structure_factor_mirror_kernel(float2* __restrict__ recip, int nx, int ny) {
-    const int s = blockIdx.z;
-    const int mx = nx / 2 + 1 + blockIdx.y;
-    const int my = blockIdx.x * blockDim.x + threadIdx.x;
-    if (mx >= nx || my >= ny || my == ny / 2) return;
-    float2* img = recip + (size_t)s * nx * ny;
-    const float2 v = img[(size_t)(nx - mx) * ny + (my ? ny - my : 0)];
-    img[(size_t)mx * ny + my] = make_float2(v.x, -v.y);
+    store_quad_bin(recip + (size_t)s * nx * ny, nx, ny, mx, my, tA, tB, tC, tD, write_mx);
 }
 
 // Reciprocal-space probes: psik[p][mx][my] = mask * exp(2 pi i (fx (hx/nx + px/Lx) + fy (hy/ny + py/Ly)))

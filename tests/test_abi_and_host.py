@@ -145,14 +145,16 @@ def test_m0_is_only_touched_by_the_addtid_exchange(tmp_path):
         assert lines[i].startswith("s_mov_b32 m0,"), lines[i]
         assert lines[i + 1].startswith("s_nop"), (lines[i], lines[i + 1])
     assert sum(l.startswith("ds_write_addtid_b32") for l in lines) > 0
-    # the kernels the default paths launch neither spill nor fall below two waves per SIMD (the kernels kept for A/B runs --
-    # rowTC_pass_kernel, rowT2_pass_kernel<32>, ifftT2_kernel<32>, the generic line kernels -- are known to spill and are listed
-    # in DESIGN.md)
+    # no register kernel of the library spills or falls below two waves per SIMD (the generic LDS line kernels, the fallback for
+    # lengths no register kernel serves, are the only ones allowed private memory)
     text = "\n".join(lines)
-    shipped = ["rowT_pass_kernelILi32ELi16ELi4E", "rowT_pass_kernelILi16ELi16ELi4E", "rowT2_pass_kernelILi16E", "rowTW_pass_kernelILb1ELb1E",
-               "rowTB_pass_kernelILi32ELb1E", "rowTB_pass_kernelILi16ELb1E", "rowTB2_pass_kernelILb0ELb0ELb1E", "rowTC2_pass_kernel",
+    shipped = ["rowT_pass_kernelILi32ELi16E", "rowT_pass_kernelILi16ELi16E", "rowT2_pass_kernelILi16E", "rowTW_pass_kernelILb1ELb1E",
+               "rowTB_pass_kernelILi32E", "rowTB_pass_kernelILi16E", "rowTB2_pass_kernelILb0ELb0E", "rowTC2_pass_kernel",
                "ifftTB_kernelILi32E", "ifftTB_kernelILi16E", "ifftTB2_kernel", "ifftTW_kernel", "ifftT2_kernelILi16E",
-               "structure_factor_quad_kernel", "col_pass_kernelILi32ELi16ELb1E", "col_pass_kernelILi16ELi32ELb0E"]
+               "structure_factor_quad_kernel", "structure_factor_edge_kernel", "col_pass_kernelILi32ELi16ELb1E", "col_pass_kernelILi16ELi32ELb0E",
+               "time_cz_kernelILi16ELi32E", "time_cz_kernelILi32ELi16E", "tacaw_fold_kernel", "row_pass_pf_kernelILi32E", "row_pass2_kernelILi32E"]
+    names = re.findall(r"\.amdhsa_kernel (\S+)", text)
+    assert not [n for n in names if re.search(r"rowTP|rowT3|rowTC_pass|structure_factor_mfma|structure_factor_nyquist", n)], "superseded kernels are back"
     for name in shipped:
         m = re.search(r"\.amdhsa_kernel (_ZN3msl\d+" + re.escape(name) + r"\S*)(.*?)\.end_amdhsa_kernel", text, re.S)
         assert m, name

@@ -354,25 +354,6 @@ def test_calculator_oracle_parity_onepass(ps, orc, n, nz, P):
     assert rel_l2(t, np.exp(1j * orc.interaction_sigma(100e3) * np.moveaxis(V, 2, 0))) < 1e-4
 
 
-@pytest.mark.parametrize("mode", ["1", "3"])
-@pytest.mark.parametrize("nz", [2, 3, 6, 7])
-def test_paired_lines_kernel_matches_oracle(ps, orc, nz, mode, monkeypatch):
-    """MSL_ROWT_PAIRED=1: the 1024 x 1024 slice loop on 8-line tiles with the work buffers between two transposing passes
-    in the paired-lines layout (two workgroups per CU).  nz = 2: one transposing pass, natural in and out; nz = 3: natural ->
-    paired -> natural; deeper stacks run paired -> paired passes; even / odd depths start along different axes."""
-    from pyslice_amd.synthetic import synthetic_trajectory
-    monkeypatch.setenv("MSL_ROWT_PAIRED", mode)        # 1: two workgroups per CU; 3: three (two-phase store, t_k from L2)
-    tr = synthetic_trajectory(1024, nz, 1, density=0.02, seed=70 + nz)
-    lx, ly = tr.box_matrix[0, 0], tr.box_matrix[1, 1]
-    pp = [tuple(v) for v in np.random.default_rng(8).random((3, 2)) * [lx, ly]]
-    calc = ps.MultisliceCalculator(progress=False)
-    calc.setup(tr, aperture=30.0, voltage_eV=100e3, probe_positions=pp)
-    got = npy(calc.run().wavefunction_data)
-    want = orc.run_frames(tr.box_matrix, tr.positions, tr.atom_types, 30.0, 100e3, pp)["wavefunction_data"]
-    assert rel_l2(got, want) < WAVE_TOL
-    assert ref_residual(got, want) < RESID_TOL
-
-
 @pytest.mark.parametrize("nx,ny,nz,P,B", [(256, 256, 5, 1, 4), (256, 256, 4, 3, 2), (512, 512, 3, 1, 3), (512, 512, 4, 2, 4),
                                           (1024, 1024, 3, 1, 2), (1024, 256, 4, 1, 3), (96, 80, 3, 2, 4), (45, 63, 2, 1, 5),
                                           (501, 64, 2, 1, 2), (2048, 512, 2, 1, 2), (256, 256, 1, 1, 4), (700, 300, 3, 2, 3)])
@@ -749,19 +730,16 @@ def test_streaming_tacaw_c5_grid_window_and_bin(ps, orc):
     assert rel_l2(tac.total_diffraction, inten.sum(axis=1)) < TACAW_TOL
 
 
-@pytest.mark.parametrize("nx,ny,nz,P,chirpz", [(501, 491, 5, 3, 0), (500, 500, 4, 2, 0), (33, 128, 3, 2, 0), (129, 272, 4, 2, 0),
-                                               (100, 400, 3, 3, 0), (512, 300, 4, 2, 0), (349, 1024, 3, 1, 0), (271, 257, 2, 2, 0),
-                                               (491, 501, 1, 2, 0), (360, 448, 2, 70, 0), (192, 180, 3, 2, 0), (200, 191, 4, 2, 0),
-                                               (501, 491, 4, 2, 1), (100, 400, 3, 2, 1)])
-def test_any_length_register_kernel_matches_oracle(ps, orc, nx, ny, nz, P, chirpz, monkeypatch):
+@pytest.mark.parametrize("nx,ny,nz,P", [(501, 491, 5, 3), (500, 500, 4, 2), (33, 128, 3, 2), (129, 272, 4, 2),
+                                        (100, 400, 3, 3), (512, 300, 4, 2), (349, 1024, 3, 1), (271, 257, 2, 2),
+                                        (491, 501, 1, 2), (360, 448, 2, 70), (192, 180, 3, 2), (200, 191, 4, 2)])
+def test_any_length_register_kernel_matches_oracle(ps, orc, nx, ny, nz, P):
     """Lines of any length up to 512 run on the register FFTs (rowTB_pass_kernel: M = 256 for n <= 128, M = 1024 for
     192 <= n <= 512 and for every non-smooth n in between), the propagation A = ifft.P.fft as ONE zero-padded cyclic convolution
-    of length M (two FFTs) -- or, MSL_CHIRPZ=1, every N-point DFT as a chirp-z transform (four): the reference's own
-    501 x 491 grid (src/unittests/00_probe.py:7-8) in both orientations, the boundaries of the length ranges, line counts that
-    are not multiples of 16, mixes with the power-of-two and generic kernels, many probes, odd and even depths."""
+    of length M (two FFTs): the reference's own 501 x 491 grid (src/unittests/00_probe.py:7-8) in both orientations, the
+    boundaries of the length ranges, line counts that are not multiples of 16, mixes with the power-of-two and generic kernels,
+    many probes, odd and even depths."""
     from pyslice_amd.synthetic import synthetic_trajectory
-    if chirpz:
-        monkeypatch.setenv("MSL_CHIRPZ", "1")
     tr = synthetic_trajectory(nx, nz, 2, ny=ny, density=0.04, seed=nx + ny)
     lx, ly = tr.box_matrix[0, 0], tr.box_matrix[1, 1]
     pp = [tuple(v) for v in np.random.default_rng(9).random((P, 2)) * [lx, ly]]
@@ -774,15 +752,13 @@ def test_any_length_register_kernel_matches_oracle(ps, orc, nx, ny, nz, P, chirp
     assert ref_residual(got[chk], want) < RESID_TOL
 
 
-@pytest.mark.parametrize("nx,ny,nz,P,chirpz", [(997, 600, 3, 2, 0), (700, 700, 4, 1, 0), (513, 1000, 2, 2, 0), (1021, 576, 3, 1, 0),
-                                               (641, 333, 3, 2, 0), (768, 1024, 2, 1, 0), (997, 600, 3, 1, 1)])
-def test_lengths_513_to_1024_on_the_2048_point_wave_fft(ps, orc, nx, ny, nz, P, chirpz, monkeypatch):
-    """Lines of 513..1024 points run on the wave-per-line 2048-point register FFT (rowTB2_pass_kernel; convolution form, and
-    the chirp-z form behind MSL_CHIRPZ=1): primes, range ends, smooth lengths (600, 768), line counts that are not multiples of
-    8, mixes with the 1024-point kernel and a power-of-two direction."""
+@pytest.mark.parametrize("nx,ny,nz,P", [(997, 600, 3, 2), (700, 700, 4, 1), (513, 1000, 2, 2), (1021, 576, 3, 1),
+                                        (641, 333, 3, 2), (768, 1024, 2, 1)])
+def test_lengths_513_to_1024_on_the_2048_point_wave_fft(ps, orc, nx, ny, nz, P):
+    """Lines of 513..1024 points run on the wave-per-line 2048-point register FFT (rowTB2_pass_kernel, the zero-padded cyclic
+    convolution of length 2048): primes, range ends, smooth lengths (600, 768), line counts that are not multiples of 8, mixes
+    with the 1024-point kernel and a power-of-two direction."""
     from pyslice_amd.synthetic import synthetic_trajectory
-    if chirpz:
-        monkeypatch.setenv("MSL_CHIRPZ", "1")
     tr = synthetic_trajectory(nx, nz, 1, ny=ny, density=0.02, seed=nx + 3 * ny)
     lx, ly = tr.box_matrix[0, 0], tr.box_matrix[1, 1]
     pp = [tuple(v) for v in np.random.default_rng(10).random((P, 2)) * [lx, ly]]
@@ -817,15 +793,14 @@ def test_transmission_functions_2048_grid(ps, orc, nz):
 
 
 @pytest.mark.parametrize("nx,ny,nz,P,mode", [(1100, 1030, 3, 2, "two_waves"), (1025, 512, 2, 1, "two_waves"), (2047, 1200, 2, 1, "two_waves"),
-                                             (1500, 1029, 4, 3, "two_waves"), (1100, 1030, 3, 2, "one_wave"), (1100, 1030, 2, 1, "generic")])
+                                             (1500, 1029, 4, 3, "two_waves"), (1100, 1030, 2, 1, "generic")])
 def test_lengths_1025_to_2047(ps, orc, nx, ny, nz, P, mode, monkeypatch):
     """Lines of 1025..2047 points: cyclic convolution of length 4096 on pairs of 2048-point wave FFTs, the two branches of the
-    radix-2 step on two waves (rowTC2_pass_kernel, default) or in one (rowTC_pass_kernel, MSL_CONV4096=1), and the generic LDS
-    kernels in the two-pass loop (MSL_NO_CONV4096); next to a 513..1024-point and a 512-point axis, odd and even depths."""
+    radix-2 step on two waves (rowTC2_pass_kernel), and the generic LDS kernels in the two-pass loop as the cross-check
+    (MSL_DEBUG + MSL_NO_CONV4096); next to a 513..1024-point and a 512-point axis, odd and even depths."""
     from pyslice_amd.synthetic import synthetic_trajectory
-    if mode == "one_wave":
-        monkeypatch.setenv("MSL_CONV4096", "1")
-    elif mode == "generic":
+    if mode == "generic":
+        monkeypatch.setenv("MSL_DEBUG", "1")
         monkeypatch.setenv("MSL_NO_CONV4096", "1")
     tr = synthetic_trajectory(nx, nz, 1, ny=ny, density=0.01, seed=nx + ny)
     lx, ly = tr.box_matrix[0, 0], tr.box_matrix[1, 1]
@@ -841,11 +816,8 @@ def test_lengths_1025_to_2047(ps, orc, nx, ny, nz, P, mode, monkeypatch):
 @pytest.mark.parametrize("nx,ny,nz,P", [(2048, 2048, 3, 1), (2048, 2048, 4, 2), (2048, 512, 3, 2), (2048, 2048, 1, 1)])
 def test_2048_point_wave_per_line_kernel_matches_oracle(ps, orc, nx, ny, nz, P, monkeypatch):
     """2048-point lines on fft2048_wave (one wave per line, paired-lines layout between two such passes; a 2048 x 512 grid
-    alternates with the 512-point kernel through the natural layout); odd and even depths; and the 2 R^2 kernel it replaced
-    (MSL_WAVE2K=0) on the same input."""
+    alternates with the 512-point kernel through the natural layout); odd and even depths."""
     from pyslice_amd.synthetic import synthetic_trajectory
-    if nz == 3 and P == 1:
-        monkeypatch.setenv("MSL_WAVE2K", "0")
     tr = synthetic_trajectory(nx, nz, 1, ny=ny, density=0.004, seed=nz)
     lx, ly = tr.box_matrix[0, 0], tr.box_matrix[1, 1]
     pp = [tuple(v) for v in np.random.default_rng(12).random((P, 2)) * [lx, ly]]
@@ -866,6 +838,7 @@ def test_any_length_register_kernel_deep_stack_and_generic_cross_check(ps, orc, 
     outs = []
     for off in (False, True):
         if off:
+            monkeypatch.setenv("MSL_DEBUG", "1")
             monkeypatch.setenv("MSL_NO_BLUESTEIN_REG", "1")
         calc = ps.MultisliceCalculator(progress=False)
         calc.setup(tr, aperture=30.0, voltage_eV=100e3, probe_positions=pp)
@@ -1196,12 +1169,12 @@ def test_tacaw_any_frame_count_on_the_register_kernel(ps, T, shape):
     assert got[:, T // 2].max() == 0.0
     err = np.linalg.norm(got - want, axis=1) / np.linalg.norm(want, axis=1)
     assert err.max() < 5e-5, (T, err.max())
-    os.environ["MSL_TACAW_GENERIC"] = "1"
+    os.environ["MSL_DEBUG"] = os.environ["MSL_TACAW_GENERIC"] = "1"
     try:
         eng.tacaw()
         gen = eng.intensity().astype(np.float64)
     finally:
-        del os.environ["MSL_TACAW_GENERIC"]
+        del os.environ["MSL_TACAW_GENERIC"], os.environ["MSL_DEBUG"]
     eng.close()
     weak = big[:, 0] == 0                                     # the generic kernel transforms the raw lines: compare where no mean has to cancel
     assert rel_l2(got.transpose(0, 2, 3, 1)[weak], gen.transpose(0, 2, 3, 1)[weak]) < 1e-5
@@ -1224,10 +1197,10 @@ def test_tacaw_fourstep_time_axis_256_frames(ps, orc):
     assert np.allclose(tac.frequencies, f)
     assert rel_l2(got, inten) < TACAW_TOL
     assert got[:, 128].max() == 0.0
-    os.environ["MSL_TACAW_GENERIC"] = "1"
+    os.environ["MSL_DEBUG"] = os.environ["MSL_TACAW_GENERIC"] = "1"
     try:
         calc._engine.tacaw()
         gen = calc._engine.intensity()
     finally:
-        del os.environ["MSL_TACAW_GENERIC"]
+        del os.environ["MSL_TACAW_GENERIC"], os.environ["MSL_DEBUG"]
     assert rel_l2(got, gen) < 1e-5
