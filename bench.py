@@ -66,6 +66,14 @@ def parse():
     ap.add_argument("--tacaw-frames", type=int, default=TACAW_T,
                     help="frame slots of the TACAW leg (default 256 = BASELINE C3; 100 = the reference notebook's run)")
     ap.add_argument("--no-exchange", action="store_true", help="skip the end-of-run exchange timing (N>1)")
+    ap.add_argument("--stream", action="store_true",
+                    help="streaming TACAW (the only representable form of BASELINE C5): every frame goes through a ring of --stream-tile "
+                         "frame slots (k-window --k-window, detector bin --k-bin) and is folded into the time->frequency transform "
+                         "inside the timed region; N>1: each rank folds its own frames with global time indices, and after the timed "
+                         "region the partial sums are reduce-scattered over probes, finished and gathered (stream_ms)")
+    ap.add_argument("--stream-tile", type=int, default=8)
+    ap.add_argument("--k-window", type=int, default=512)
+    ap.add_argument("--k-bin", type=int, default=4)
     ap.add_argument("--no-launch-timing", action="store_true",
                     help="run the library as production does (no per-launch HIP events, frames queue asynchronously); "
                          "the roofline block is then null")
@@ -235,9 +243,18 @@ def run(a):
     from pyslice_amd.calculators import default_frame_batch
     fb = a.frame_batch if a.frame_batch > 0 else default_frame_batch(P, nz, n, n)      # the calculator's own default
     fb = max(1, min(fb, a.steps))
+    stream = a.stream
+    if stream:
+        if strong:
+            raise SystemExit("--stream runs with weak scaling (every rank folds its own block of frames)")
+        slots = max(1, min(a.stream_tile, n_local))
+        fb = max(1, min(fb, slots))
+        tacaw_T = None
+        kw = min(a.k_window, n)
     eng = _native.Engine(n, n, nz, xs[1] - xs[0], ys[1] - ys[0], zs[1] - zs[0] if nz > 1 else 0.5, wavelength(100e3),
                          interaction_sigma(100e3), n_probes=P, n_frames=slots, device=local_rank,
-                         launch_timing=not a.no_launch_timing, frame_batch=fb)
+                         launch_timing=not a.no_launch_timing, frame_batch=fb,
+                         window=(kw, kw) if stream else None, k_bin=(a.k_bin, a.k_bin) if stream and a.k_bin > 1 else None)
     eng.set_kirkland(loadKirkland())
     eng.set_slices(*slice_edges(zs))
     eng.set_probes(a.aperture, pp)
@@ -265,6 +282,48 @@ def run(a):
             eng.build_potentials(tr.positions[chunk[0]:chunk[-1] + 1] if consecutive else tr.positions[chunk], Z, 2)
             eng.propagate_frames(slot_of[chunk[0]], len(chunk))
 
+    # streaming TACAW: rank r's frame i carries the global time index r * n_local + i; all T = world * n_local frames (warm-up
+    # included: the fold is linear, and a transform needs every frame) go into one stream, all T frequency bins are kept
+    stream_state = {"ref": False}
+
+    def stream_steps(s0, s1):
+        todo = [f for s in range(s0, s1) for f in my_frames[s]]
+        for t0 in range(0, len(todo), slots):
+            tile = todo[t0:t0 + slots]
+            for i in range(0, len(tile), eng.frame_batch):
+                chunk = tile[i:i + eng.frame_batch]
+                if eng.frame_batch > 1:
+                    eng.build_potentials(tr.positions[chunk[0]:chunk[-1] + 1], Z, 2)
+                    eng.propagate_frames(i, len(chunk))
+                else:
+                    eng.build_potential(tr.positions[chunk[0]], Z, 2)
+                    eng.propagate_frame(i)
+            if not stream_state["ref"]:
+                # the run's first frame is every rank's reference pattern (rank 0's slot 0, broadcast once)
+                if world == 1:
+                    eng.tacaw_stream_set_reference(slot=0)
+                else:
+                    K = eng.wx * eng.wy
+                    if rank == 0:
+                        eng.tacaw_stream_set_reference(slot=0)
+                        eng.synchronize()
+                        ref = torch.as_tensor(_native.DeviceArray(eng.device_ptr(_native.BUF_STREAM_REF), (P, K), "<c8", owner=eng), device=dev)
+                        D.broadcast_from(ref, src=0)
+                    else:
+                        ref = torch.empty((P, K), dtype=torch.complex64, device=dev)
+                        D.broadcast_from(ref, src=0)
+                        torch.cuda.synchronize(dev)
+                        eng.tacaw_stream_set_reference(ref_ptr=ref.data_ptr())
+                        eng.synchronize()
+                stream_state["ref"] = True
+            eng.tacaw_stream_push(0, len(tile), rank * n_local + slot_of[tile[0]])
+
+    if stream:
+        dev = torch.device("cuda", local_rank)
+        eng.tacaw_stream_begin(world * n_local, None)
+        slot_of = {f: i for i, f in enumerate(f for fs in my_frames for f in fs)}
+        steps = stream_steps
+
     def fence():
         eng.synchronize()
         torch.cuda.synchronize()
@@ -288,7 +347,33 @@ def run(a):
     frames_timed = a.steps * a.frames_per_step if strong else world * a.steps
 
     dev = torch.device("cuda", local_rank)
-    wf_view = torch.as_tensor(_native.DeviceArray(eng.device_ptr(_native.BUF_WAVEFUNCTION), (P, slots, npix), "<c8", owner=eng),
+    stream_ms = None
+    if stream:
+        # end of the stream (after the timed region): sum of the ranks' partial sums (reduce-scatter over probes), |.|^2 of this
+        # rank's probes, gather of the intensities on rank 0
+        F, K = world * n_local, eng.wx * eng.wy
+
+        def view(what, shape, typestr):
+            return torch.as_tensor(_native.DeviceArray(eng.device_ptr(what), shape, typestr, owner=eng), device=dev)
+        fence()
+        t1 = time.perf_counter()
+        p0, p1 = D.reduce_probes(view(_native.BUF_STREAM_ACC, (P, F, K), "<c8"), P)
+        D.reduce_probes(view(_native.BUF_STREAM_S1, (P, K, 2), "<f8"), P)
+        D.reduce_probes(view(_native.BUF_STREAM_S2, (P, K), "<f8"), P)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        mine = torch.empty((p1 - p0, F, K), dtype=torch.float32, device=dev)
+        eng.tacaw_stream_finish_range(p0, p1 - p0, mine.data_ptr(), True)
+        t3 = time.perf_counter()
+        full = D.gather_probes(mine, P, dst=0)
+        fence()
+        t4 = time.perf_counter()
+        stream_ms = {"frames": F, "bins": F, "stored_pixels": K, "ring": slots, "reduce_scatter": round((t2 - t1) * 1e3, 3),
+                     "finish": round((t3 - t2) * 1e3, 3), "gather_probes": round((t4 - t3) * 1e3, 3),
+                     "accumulator_bytes_per_rank": 8.0 * P * F * K,
+                     "intensity_sum": float(full.double().sum()) if full is not None else None}
+        del mine, full
+    wf_view = torch.as_tensor(_native.DeviceArray(eng.device_ptr(_native.BUF_WAVEFUNCTION), (P, slots, eng.wx * eng.wy), "<c8", owner=eng),
                               device=dev)
 
     # ---- TACAW leg (N=1): time FFT over the resident frame slots; slots beyond the computed frames are filled with copies
@@ -404,6 +489,9 @@ def run(a):
         }
         if tacaw is not None:
             out["tacaw"] = tacaw
+        if stream_ms is not None:
+            out["stream_ms"] = stream_ms
+            out["config"]["streaming_tacaw"] = {"ring": slots, "k_window": kw, "k_bin": a.k_bin, "frames_folded": world * n_local}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"], V = cpu_baseline(n, nz, P, a.aperture, a.cpu_slices)
             try:
@@ -412,7 +500,7 @@ def run(a):
                 out["cpu_baseline_allcores"] = {"error": repr(exc)}
     else:
         out = None
-    if world > 1 and not a.no_exchange:
+    if world > 1 and not a.no_exchange and not stream:
         # The timed region is over and its line is complete.  The exchanges move tens of GB between the ranks over a backend
         # this build could not exercise on real multi-GPU hardware: if they stall, every rank's watchdog ends its process after
         # `--exchange-timeout` seconds and rank 0 still prints the line, with the failure recorded instead of the timings.

@@ -178,7 +178,8 @@ class MultisliceCalculator:
         n_slices = len(slice_coords)
         dz = zs[1] - zs[0] if nz > 1 else 0.5
         # A previous run's WFData (and zero-copy device views of its buffers) may still hold the old engine: drop our
-        # reference and let the last owner free it, instead of closing it under them.
+        # reference and let the last owner free it, instead of closing it under them.  (A caller that keeps an earlier result
+        # and only needs its host arrays frees the device side with result.release().)
         self._engine = None
         batch = self._frame_batch
         if batch is None:
@@ -192,10 +193,23 @@ class MultisliceCalculator:
             wx, wy = self._k_window if self._k_window is not None else (nx, ny)
             if wx % self._k_bin[0] or wy % self._k_bin[1]:
                 raise ValueError(f"the stored spectrum {wx} x {wy} is not a multiple of k_bin {self._k_bin}")
-        self._engine = _native.Engine(nx, ny, n_slices, self.dx, self.dy, dz, wavelength(voltage_eV),
-                                      interaction_sigma(voltage_eV), n_probes=self.n_probes,
-                                      n_frames=slots, device=_device_index(dev),
-                                      window=self._k_window, frame_batch=batch, k_bin=self._k_bin)
+        # The frame batch costs batch x (two orientations of the transmission stack + three work buffers): when the device cannot
+        # hold it next to the (P, T_local, wx, wy) result -- a result near capacity, a shared or smaller GPU -- halve it down to one
+        # frame per launch sequence instead of failing a run that fits without batching (an explicit frame_batch is honoured as is)
+        while True:
+            try:
+                self._engine = _native.Engine(nx, ny, n_slices, self.dx, self.dy, dz, wavelength(voltage_eV),
+                                              interaction_sigma(voltage_eV), n_probes=self.n_probes,
+                                              n_frames=slots, device=_device_index(dev),
+                                              window=self._k_window, frame_batch=batch, k_bin=self._k_bin)
+                break
+            except MemoryError:
+                if self._frame_batch is not None or batch <= 1:
+                    raise
+                batch = max(1, batch // 2)
+                if self._stream_tile is not None:
+                    batch = min(batch, slots)
+                logger.info(f"device memory: frame batch reduced to {batch}")
         self._engine.set_kirkland(loadKirkland())
         lo, hi = slice_edges(slice_coords)
         self._engine.set_slices(lo, hi)

@@ -593,6 +593,7 @@ struct RowTJob {
     const float2* bf;       // (M/2 + 1) filter FFT_M(conj chirp, wrapped) / M -- an even sequence, first half stored
     const float2* bw;       // (M/2) chirp w[n] = exp(-i pi n^2 / N), zero for n >= N
     int n_line;             // N
+    int perm_shift;         // rowT_pass_kernel<.., OUT_P>: log2(R' / 8), R' = radix of the kernel that reads the output lines
 #ifdef MSL_STAMPS
     unsigned* stamps;       // tools/rowt_timeline.hip: per wave, cycles spent in each of MSL_NSTAMP phases of the iteration
 #endif
@@ -608,7 +609,16 @@ struct RowTJob {
 #define MSL_STAMP(id)
 #endif
 
-template <int R, int LINES>
+// IN_P / OUT_P: between two transposing passes the work buffer holds every line in the INTERLEAVED order
+//     position 2 R' (j >> 1) + 2 l + (j & 1)   <->   element R' j + l          (R' = radix of the kernel that reads the line)
+// i.e. the two elements a lane of the reading kernel keeps in registers 2 jp and 2 jp + 1 sit next to each other: the reader
+// fetches a line with R'/2 loads of 16 bytes per lane instead of R' loads of 8 (a wave's load covers 2 x 512 contiguous bytes) --
+// 8-byte accesses run at 0.54-0.70 of the 16-byte rate through the L1 / address path (MI355X_MICROARCH.md), and in the phase
+// timeline a wave spent 22 % of its time issuing the prefetch loads.  The writer keeps its 128-byte transposed segments: a tile
+// is then not 16 consecutive lines but 8 lines l0 .. l0 + 7 of block j = 2 jp and the same 8 of block 2 jp + 1 (tile row r =
+// line R' (2 jp + (r & 1)) + l0 + (r >> 1)), whose 16 output elements are exactly positions 2 R' jp + 2 l0 .. + 15: the store
+// addresses do not change at all, only which input lines (and t_k lines) form a tile.  job.perm_shift = log2(R' / 8).
+template <int R, int LINES, bool IN_P = false, bool OUT_P = false>
 __global__ void __launch_bounds__(LINES * R, (R == 16) ? 3 : 2) rowT_pass_kernel(RowTJob job) {
     constexpr int N = R * R;
 #ifdef MSL_STAMPS
@@ -644,17 +654,37 @@ __global__ void __launch_bounds__(LINES * R, (R == 16) ? 3 : 2) rowT_pass_kernel
     // work item = (line block lb, probe chunk pc), item = lb * pchunks + pc; the cursor (item, lb, pc, k) advances
     // incrementally -- a division per iteration costs ~0.3 us of scalar work on the critical path
     const int step_lb = (int)gridDim.x / pchunks, step_pc = (int)gridDim.x % pchunks;
+    // input line of this thread's tile row in line block lbb
+    auto line_of = [&](int lbb) {
+        if constexpr (OUT_P) {
+            const int sh = job.perm_shift;                              // blocks of 16 output elements per 2 R' chunk: R' / 8
+            return (((lbb >> sh) * 2 + (grp & 1)) << (sh + 3)) + 8 * (lbb & ((1 << sh) - 1)) + (grp >> 1);
+        } else {
+            return lbb * LINES + grp;
+        }
+    };
     auto line_ptr = [&](int lbb, int pcc, int kk) {
-        return job.in + (long long)(pcc * PC + kk) * job.in_image_stride + (long long)(lbb * LINES + grp) * job.in_pitch;
+        return job.in + (long long)(pcc * PC + kk) * job.in_image_stride + (long long)line_of(lbb) * job.in_pitch;
+    };
+    // registers [LO, HI) of the next line: 8-byte loads of elements j R + ln, or (interleaved input) 16-byte loads of the pairs
+    auto load_regs = [&](float2 (&dst)[R], const float2* r, auto lo_c, auto hi_c) {
+        constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
+        if constexpr (IN_P) {
+            static_assert(LO % 2 == 0 && HI % 2 == 0, "register pairs");
+#pragma unroll
+            for (int jp = LO / 2; jp < HI / 2; ++jp) {
+                const msl_f4v t = __builtin_nontemporal_load(reinterpret_cast<const msl_f4v*>(r + (2 * R * jp + 2 * ln)));
+                dst[2 * jp] = make_float2(t.x, t.y); dst[2 * jp + 1] = make_float2(t.z, t.w);
+            }
+        } else {
+#pragma unroll
+            for (int j = LO; j < HI; ++j) dst[j] = ld_stream(r + (j * R + ln));
+        }
     };
     int item = blockIdx.x;
     int lb = item / pchunks, pc = item - lb * pchunks, k = 0;
     float2 vn[R];
-    if (item < n_items) {
-        const float2* r = line_ptr(lb, pc, 0);
-#pragma unroll
-        for (int j = 0; j < R; ++j) vn[j] = ld_stream(r + (j * R + ln));
-    }
+    if (item < n_items) load_regs(vn, line_ptr(lb, pc, 0), std::integral_constant<int, 0>{}, std::integral_constant<int, R>{});
     float2 tv[R];
 #ifdef MSL_STAMPS
     unsigned acc_[MSL_NSTAMP] = {0};
@@ -672,7 +702,7 @@ __global__ void __launch_bounds__(LINES * R, (R == 16) ? 3 : 2) rowT_pass_kernel
         const int p = pc * PC + k;
         const int cur_lb = lb;
         if (k == 0) {
-            const float2* trow = job.trans + frame_off(job, pc * PC) + (long long)(lb * LINES + grp) * N;
+            const float2* trow = job.trans + frame_off(job, pc * PC) + (long long)line_of(lb) * N;
 #pragma unroll
             for (int j = 0; j < R; ++j) tv[j] = ld_stream(trow + j * R + ln);       // read once per launch too (+0.4 %)
         }
@@ -692,11 +722,7 @@ __global__ void __launch_bounds__(LINES * R, (R == 16) ? 3 : 2) rowT_pass_kernel
             constexpr int HI = (R == 32) ? decltype(hi_c)::value : R;
             if constexpr (HI > LO) {
                 __builtin_amdgcn_sched_barrier(0);
-                if (nitem < n_items) {
-                    const float2* r = line_ptr(nlb, npc, nk);
-#pragma unroll
-                    for (int j = LO; j < HI; ++j) vn[j] = ld_stream(r + (j * R + ln));
-                }
+                if (nitem < n_items) load_regs(vn, line_ptr(nlb, npc, nk), std::integral_constant<int, LO>{}, std::integral_constant<int, HI>{});
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
@@ -1622,28 +1648,41 @@ __global__ void __launch_bounds__(16 * R, 2) ifftT2_kernel(IfftT2Job job) {
     float* scratch = reinterpret_cast<float*>(tile + grp * CS);
     const int lblocks = job.n_lines / 16;
     const int n_items = lblocks * job.n_images;
-    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-        const int img = item / lblocks, lb = item - img * lblocks;
+    // the next item's line is loaded into registers while the current one is transformed (two 256-thread workgroups per CU = two
+    // waves per SIMD: without it the loads of an item were exposed -- 193 us of a 0.33 ms potential per frame at 512^2 x 100)
+    float2 vn[2 * R];
+    auto load_line = [&](int it) {
+        const int img = it / lblocks, lb = it - img * lblocks;
         const float2* src = job.in + (long long)img * job.in_is + (long long)(lb * 16 + grp) * job.in_pitch;
-        int lnv = ln;                                       // laundered: keeps dozens of per-lane LDS / global addresses from being
-        asm volatile("" : "+v"(lnv));                       // hoisted out of the loop into registers the transform needs
-        float2 v[2 * R];
+        int lnl = ln;
+        asm volatile("" : "+v"(lnl));
         if (job.herm) {                                     // workgroup-uniform: mirrored elements as two 8-byte loads
 #pragma unroll
             for (int j = 0; j < R; ++j) {
-                const int e0 = 2 * (j * R + lnv), e1 = e0 + 1;
+                const int e0 = 2 * (j * R + lnl), e1 = e0 + 1;
                 float2 a = src[e0 <= N / 2 ? e0 : N - e0], b = src[e1 <= N / 2 ? e1 : N - e1];
                 if (e0 > N / 2) a.y = -a.y;
                 if (e1 > N / 2) b.y = -b.y;
-                v[j] = a; v[R + j] = b;
+                vn[j] = a; vn[R + j] = b;
             }
         } else {
 #pragma unroll
             for (int j = 0; j < R; ++j) {
-                const float4 x = *reinterpret_cast<const float4*>(src + 2 * (j * R + lnv));
-                v[j] = make_float2(x.x, x.y); v[R + j] = make_float2(x.z, x.w);
+                const float4 x = *reinterpret_cast<const float4*>(src + 2 * (j * R + lnl));
+                vn[j] = make_float2(x.x, x.y); vn[R + j] = make_float2(x.z, x.w);
             }
         }
+    };
+    if ((int)blockIdx.x < n_items) load_line(blockIdx.x);
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int img = item / lblocks, lb = item - img * lblocks;
+        int lnv = ln;                                       // laundered: keeps dozens of per-lane LDS / global addresses from being
+        asm volatile("" : "+v"(lnv));                       // hoisted out of the loop into registers the transform needs
+        float2 v[2 * R];
+#pragma unroll
+        for (int j = 0; j < 2 * R; ++j) v[j] = vn[j];
+        __builtin_amdgcn_sched_barrier(0);
+        if (item + (int)gridDim.x < n_items) load_line(item + (int)gridDim.x);
         __builtin_amdgcn_sched_barrier(0);
         float* scr = scratch;
         asm volatile("" : "+v"(scr));

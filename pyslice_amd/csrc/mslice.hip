@@ -469,7 +469,7 @@ int make_cz_tables(msl_handle* h, msl_handle::OpDir& o, int n) {
         if ((r = dalloc(h, &o.cz_tw2, (size_t)64))) return r;
         if (hipMemcpy(o.cz_tw, T.data(), M * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess ||
             hipMemcpy(o.cz_tw2, W.data(), 64 * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess)
-            return MSL_ERR_HIP;
+            return fail(h, MSL_ERR_HIP, "chirp-z twiddle upload failed (%d points)", n);
     } else if ((r = make_tw4(h, &o.cz_tw, R))) {
         return r;
     }
@@ -488,7 +488,7 @@ int make_cz_tables(msl_handle* h, msl_handle::OpDir& o, int n) {
     if ((r = dalloc(h, &o.cz_bf, (size_t)NH + 2))) return r;
     if (hipMemcpy(o.cz_bw, bw.data(), NH * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(o.cz_bf, bf.data(), (NH + 2) * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess)
-        return MSL_ERR_HIP;
+        return fail(h, MSL_ERR_HIP, "chirp-z table upload failed (%d points)", n);
     o.cz_R = wave ? 64 : R;
     return MSL_OK;
 }
@@ -697,9 +697,10 @@ int transpose_odd_slices(msl_handle* h) {
     return MSL_OK;
 }
 
-// transposing pass on R^2-point lines (1024 / 256): add-tid exchange, 16-line tiles
-template <int R>
-int launch_rowT_r(msl_handle* h, RowTJob job, int kind) {
+// transposing pass on R^2-point lines (1024 / 256): add-tid exchange, 16-line tiles; IN_P / OUT_P: interleaved line order of the
+// work buffer on the input / output side (16-byte loads in the reading kernel, see rowT_pass_kernel)
+template <int R, bool IN_P, bool OUT_P>
+int launch_rowT_io(msl_handle* h, RowTJob job, int kind) {
     constexpr int N = R * R, LINES = 16;
     constexpr int CS = (R * R + 33) / 32 * 32 + 2;
     const size_t lds = ((size_t)2 * N + (size_t)LINES * CS) * 8;
@@ -713,10 +714,16 @@ int launch_rowT_r(msl_handle* h, RowTJob job, int kind) {
     job.pchunk = pc;
     const long long items = lb * ((job.n_images + pc - 1) / pc);
     const int grid = (int)std::min<long long>(items, slots);
-    (void)hipFuncSetAttribute((const void*)rowT_pass_kernel<R, LINES>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
-    hipLaunchKernelGGL((rowT_pass_kernel<R, LINES>), dim3(grid), dim3(LINES * R), lds, h->stream, job);
+    (void)hipFuncSetAttribute((const void*)rowT_pass_kernel<R, LINES, IN_P, OUT_P>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
+    hipLaunchKernelGGL((rowT_pass_kernel<R, LINES, IN_P, OUT_P>), dim3(grid), dim3(LINES * R), lds, h->stream, job);
     HIPCHK(h, hipGetLastError());
     return mark_launch(h, kind);
+}
+template <int R>
+int launch_rowT_r(msl_handle* h, const RowTJob& job, int kind) {
+    const bool in_p = job.flags & P2_IN_PAIRED, out_p = job.flags & P2_OUT_PAIRED;
+    if (in_p) return out_p ? launch_rowT_io<R, true, true>(h, job, kind) : launch_rowT_io<R, true, false>(h, job, kind);
+    return out_p ? launch_rowT_io<R, false, true>(h, job, kind) : launch_rowT_io<R, false, false>(h, job, kind);
 }
 
 // lines of 2 R^2 = 512 points
@@ -957,7 +964,11 @@ int slice_loop_onepass(msl_handle* h, int fused_slot, int groups, int first_grou
         }
         const bool along_y = !slice_is_transposed(h, k);
         RowTJob j{};
+        // between two transposing passes the work buffer is in the interleaved line order (16-byte loads in the reader): the first
+        // pass reads the probes, the last transposing pass (k = nz - 2) writes for the in-place pass, both in natural order
+        if (!dbg_env("MSL_NO_INTERLEAVE")) flags |= (k > 0 ? P2_IN_PAIRED : 0) | (k < nz - 2 ? P2_OUT_PAIRED : 0);
         j.flags = flags; j.n_images = P;
+        j.perm_shift = ((along_y ? h->Rx : h->Ry) == 32) ? 2 : 1;             // radix of the kernel that reads this pass's output: log2(R' / 8)
         if (groups > 1) { j.t_group = c.n_probes; j.t_magic = (unsigned)((1ull << 32) / (unsigned)c.n_probes + 1); j.t_stride = (long long)c.nz * npix; }
         if (along_y) {
             j.in = (k == 0) ? h->psi0 : h->psi; j.out = h->psiT;

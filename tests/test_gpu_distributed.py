@@ -217,6 +217,31 @@ def test_bench_two_ranks_gloo_rehearsal(tmp_path):
         assert j["value"] > 0 and j["roofline"]["launches"] > 0
 
 
+def test_bench_streaming_tacaw_one_and_two_ranks():
+    """`bench.py --stream`: every frame is folded into the streaming TACAW inside the timed region; with two ranks (gloo rehearsal
+    on the one GPU) each folds its own frames with global time indices and the partial sums are reduce-scattered, finished and
+    gathered after the timed region.  Frequency-integrated intensity: positive, and equal for the same frames split differently
+    is not testable here (every rank synthesises its own frames) -- the physics is covered by test_ranks_frame_sharded_streaming_tacaw."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["MSL_BENCH_BACKEND"] = "gloo"
+    for gpus in (1, 2):
+        r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", str(gpus), "--grid", "256", "--slices", "6", "--probes", "3",
+                            "--steps", "5", "--warmup", "2", "--stream", "--stream-tile", "3", "--k-window", "64", "--k-bin", "2",
+                            "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(line) == 1, r.stdout
+        j = json.loads(line[0])
+        sm = j["stream_ms"]
+        assert j["n_gpus"] == gpus and sm["frames"] == 7 * gpus and sm["stored_pixels"] == 32 * 32 and sm["ring"] == 3
+        assert sm["intensity_sum"] > 0 and j["value"] > 0 and j["roofline"]["launches"] > 0
+        assert j["config"]["streaming_tacaw"]["frames_folded"] == 7 * gpus
+
+
 def test_bench_line_survives_a_stalled_exchange():
     """the end-of-run exchanges run after the bench line is assembled, under a watchdog: a rank that never arrives costs the
     exchange timings, not the measurement -- the line is printed once, with the failure in it -- and every rank exits, with

@@ -1180,6 +1180,36 @@ def test_tacaw_any_frame_count_on_the_register_kernel(ps, T, shape):
     assert rel_l2(got.transpose(0, 2, 3, 1)[weak], gen.transpose(0, 2, 3, 1)[weak]) < 1e-5
 
 
+def test_result_release_returns_the_device_memory(ps, orc):
+    """A WFData from run() keeps the engine (and every device buffer of the run) alive so that TACAWData can work on the resident
+    spectra; release() drops that hold: the device memory comes back while the host arrays stay usable -- TACAWData then stages
+    the host copy -- and a second setup() on the same calculator does not pile a second set of buffers on top."""
+    import gc
+    import torch
+    from pyslice_amd.synthetic import synthetic_trajectory
+    tr = synthetic_trajectory(256, 4, 6, density=0.03, seed=2)
+    pp = [(5.0, 5.0), (12.0, 20.0), (3.0, 17.0), (21.0, 9.0)]
+    gc.collect()
+    free0, _ = torch.cuda.mem_get_info(0)
+    calc = ps.MultisliceCalculator(progress=False)
+    calc.setup(tr, aperture=30.0, voltage_eV=100e3, probe_positions=pp)
+    wf = calc.run()
+    want = orc.run_frames(tr.box_matrix, tr.positions, tr.atom_types, 30.0, 100e3, pp)["wavefunction_data"]
+    calc.setup(tr, aperture=30.0, voltage_eV=100e3, probe_positions=pp)          # the first run's engine now lives in `wf` only
+    free_two, _ = torch.cuda.mem_get_info(0)
+    wf.release()
+    gc.collect()
+    free_one, _ = torch.cuda.mem_get_info(0)
+    assert free_one - free_two > 4 * 6 * 256 * 256 * 8                            # at least the (P,T,nx,ny) spectra came back
+    assert rel_l2(npy(wf.wavefunction_data), want) < WAVE_TOL
+    f, inten = orc.tacaw(want, wf.time)
+    assert rel_l2(npy(ps.TACAWData(wf).intensity), inten) < TACAW_TOL             # staged from the host arrays
+    del calc
+    gc.collect()
+    torch.cuda.empty_cache()
+    assert free0 - torch.cuda.mem_get_info(0)[0] < 512 << 20        # (code objects, the staged copy `wf` still holds, allocator slack)
+
+
 def test_tacaw_fourstep_time_axis_256_frames(ps, orc):
     """T = 256 frames (BASELINE C3's frame count) takes the four-step time-FFT kernel (pixels as columns of a
     (T, npix) image, DC zeroed, fftshifted |.|^2 epilogue); compare with the oracle and with the generic kernel."""
