@@ -1,4 +1,4 @@
-// Where does an iteration of the transposing pass spend its time?  Diagnostic build of rowT_pass_kernel<32,16,0>
+// Where does an iteration of the transposing pass spend its time?  Diagnostic build of rowT_pass_kernel<32,16>
 // (-DMSL_STAMPS: s_memtime at the phase boundaries of every iteration, accumulated per wave) on BASELINE C3's shape:
 // 64 probes x 1024 lines x 1024 points, chunks of 16 probes, 256 workgroups.  Prints cycles per phase and wave-iteration.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -DMSL_STAMPS -o tools/bin/rowt_timeline tools/rowt_timeline.hip
@@ -29,15 +29,15 @@ int main() {
     job.in = in; job.out = out; job.trans = trans; job.pl = pl; job.tw = tw; job.tw2 = nullptr;
     job.in_image_stride = job.out_image_stride = (long long)img; job.in_pitch = job.out_pitch = PITCH;
     job.n_lines = N; job.n_images = P; job.flags = P2_PRE_A | P2_POST_A; job.pchunk = 16; job.stamps = stamps;
-    constexpr int CS = R * (R + 1) + 1;
+    constexpr int CS = (R * R + 33) / 32 * 32 + 2;
     const size_t lds = ((size_t)2 * N + (size_t)16 * CS) * 8;
-    CK(hipFuncSetAttribute((const void*)rowT_pass_kernel<32, 16, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CK(hipFuncSetAttribute((const void*)rowT_pass_kernel<32, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     float best = 1e9;
     for (int r = 0; r < 6; ++r) {
         CK(hipMemset(stamps, 0, (size_t)GRID * 8 * MSL_NSTAMP * 4));
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL((rowT_pass_kernel<32, 16, 0>), dim3(GRID), dim3(512), lds, 0, job);
+        hipLaunchKernelGGL((rowT_pass_kernel<32, 16>), dim3(GRID), dim3(512), lds, 0, job);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best = ms < best ? ms : best;
     }
