@@ -408,6 +408,13 @@ __global__ void __launch_bounds__(COLS * R) col_pass_kernel(ColJob job) {
             float2 v[R];
 #pragma unroll
             for (int j = 0; j < R; ++j) v[j] = mycol[j * R + ln];
+            if (job.flags & COL_INTENSITY) {
+                // TACAW: the line's first sample instead of its time mean -- any constant only changes the DC bin, which is zeroed
+                // below -- so that a pixel whose mean dwarfs its thermal part is transformed at the size of the result
+                const float2 ref = mycol[0];
+#pragma unroll
+                for (int j = 0; j < R; ++j) v[j] = make_float2(v[j].x - ref.x, v[j].y - ref.y);
+            }
             wave_lds_fence();
             if (job.flags & COL_FWD) fourstep_c64<R, false>(v, mycol, tw, ln);
             if (job.flags & COL_MULPX) {

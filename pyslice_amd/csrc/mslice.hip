@@ -2006,8 +2006,9 @@ int msl_tacaw(msl_handle* h, const void* d_src, void* d_dst, int64_t batch, int3
     if (npix > 0x7fffffffLL) return fail(h, MSL_ERR_UNSUPPORTED, "msl_tacaw: npix too large");
     const int Rt = (c.fft_path == 0) ? fast_radix(T) : 0;           // 256 or 1024 frames: four-step column kernel
     const bool fast_t = Rt && (npix % 16 == 0) && npix >= 32 && !dbg_env("MSL_TACAW_GENERIC");
-    // any other frame count up to 512: chirp-z on the register FFTs (time_cz_kernel), 32-pixel tiles for T <= 128, else 16
-    const bool cz_t = !fast_t && c.fft_path == 0 && T <= 512 && (npix % 16 == 0) && !dbg_env("MSL_TACAW_GENERIC");
+    // any other frame count up to 512, and 256 frames of a grid whose pixel count the four-step kernel cannot tile: chirp-z on the
+    // register FFTs (time_cz_kernel), 32-pixel tiles for T <= 128, else 16; any pixel count (ragged last tile, odd counts unvectorised)
+    const bool cz_t = !fast_t && c.fft_path == 0 && T <= 512 && !dbg_env("MSL_TACAW_GENERIC");
     int rc = MSL_OK;
     float2* tw4_t = nullptr;
     if (fast_t) {
@@ -2061,21 +2062,23 @@ int msl_tacaw(msl_handle* h, const void* d_src, void* d_dst, int64_t batch, int3
         TimeJob j{};
         j.in = src; j.out = dst; j.tw = h->opt.cz_tw; j.bf = h->opt.cz_bf; j.bw = h->opt.cz_bw;
         j.image_stride = (long long)T * npix; j.npix = (int)npix; j.n_images = (int)batch; j.T = T;
-        auto launch = [&](auto r_c, auto cols_c) -> int {
+        auto launch = [&](auto r_c, auto cols_c, auto vec_c) -> int {
             constexpr int R = decltype(r_c)::value, COLS = decltype(cols_c)::value;
+            constexpr bool VEC = decltype(vec_c)::value;
             constexpr int M = R * R, NH = M / 2;
             const size_t lds = ((size_t)M + NH + 2 + NH + (size_t)2 * COLS * tcz_stride(R, T)) * 8;          // two tile buffers
-            const long long tiles = (npix / COLS) * batch;
+            const long long tiles = ((npix + COLS - 1) / COLS) * batch;
             const int per_cu = std::max(1, std::min(2, (int)((size_t)h->lds_limit / lds)));
             const int grid = (int)std::min<long long>(tiles, (long long)h->n_cus * per_cu);
-            (void)hipFuncSetAttribute((const void*)time_cz_kernel<R, COLS>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
-            hipLaunchKernelGGL((time_cz_kernel<R, COLS>), dim3(grid), dim3(COLS * R), lds, h->stream, j);
+            (void)hipFuncSetAttribute((const void*)time_cz_kernel<R, COLS, VEC>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
+            hipLaunchKernelGGL((time_cz_kernel<R, COLS, VEC>), dim3(grid), dim3(COLS * R), lds, h->stream, j);
             HIPCHK(h, hipGetLastError());
             return mark_launch(h, K_OTHER);
         };
-        if (h->opt.cz_R == 16) rc = (npix % 32 == 0) ? launch(std::integral_constant<int, 16>{}, std::integral_constant<int, 32>{})
-                                                     : launch(std::integral_constant<int, 16>{}, std::integral_constant<int, 16>{});
-        else rc = launch(std::integral_constant<int, 32>{}, std::integral_constant<int, 16>{});
+        using I16 = std::integral_constant<int, 16>; using I32 = std::integral_constant<int, 32>;
+        const bool even = (npix % 2 == 0);
+        if (h->opt.cz_R == 16) rc = even ? launch(I16{}, I32{}, std::true_type{}) : launch(I16{}, I32{}, std::false_type{});
+        else rc = even ? launch(I32{}, I16{}, std::true_type{}) : launch(I32{}, I16{}, std::false_type{});
         if (rc) return rc;
     } else {
         LineArgs a;

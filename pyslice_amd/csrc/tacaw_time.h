@@ -36,7 +36,10 @@ struct TimeJob {
 __host__ __device__ constexpr int tcz_min_stride(int R) { return 17 * R * R / 32; }
 __host__ __device__ inline int tcz_stride(int R, int T) { const int s = T > tcz_min_stride(R) ? T : tcz_min_stride(R); return s | 1; }
 
-template <int R, int COLS>
+// VEC: npix is even -- a thread's two pixels are one 16-byte load and one 8-byte store; otherwise (odd grids: the reference's own
+// 501 x 491 test grid has 245 991 pixels) they are separate 8- / 4-byte accesses.  Either way npix need not be a multiple of COLS:
+// the last tile of an image is ragged and its surplus pixels are neither loaded nor stored (their columns transform garbage).
+template <int R, int COLS, bool VEC>
 __global__ void __launch_bounds__(COLS * R) time_cz_kernel(TimeJob job) {
     constexpr int M = R * R, H = R / 2, NH = M / 2, NT = COLS * R, TCH = 8;
     // LDS column stride in float2: odd, so that the column-major staging (lanes = pixel pairs: stride 2 CS) and the row reads of
@@ -62,17 +65,26 @@ __global__ void __launch_bounds__(COLS * R) time_cz_kernel(TimeJob job) {
     const int q = tid % QN, r0 = tid / QN;            // staging role: pixel pair q, frames r0 + ROWS_PER_IT * i
     const float2* fa = bf + ln;                       // Bf[j R + ln],                             j <  R/2
     const float2* fb = bf - ln;                       // Bf[M - (j R + ln)] = bf[(R - j) R - ln],  j >= R/2
-    const int tiles_per_image = job.npix / COLS;
+    const int tiles_per_image = (job.npix + COLS - 1) / COLS;
     const long long n_tiles = (long long)tiles_per_image * job.n_images;
     const int half = T / 2;                           // np.fft.fftshift: bin u lands at (u + T/2) mod T
     float4 stage[NIT];
     auto load_tile = [&](long long t) {
         const long long p = t / tiles_per_image, c0 = (t % tiles_per_image) * COLS;
         const float2* src = job.in + p * job.image_stride + c0 + 2 * q;
+        const int left = job.npix - (int)c0 - 2 * q;        // pixels of the image from this thread's first one on
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
             const int f = r0 + ROWS_PER_IT * i;
-            if (f < T) stage[i] = *reinterpret_cast<const float4*>(src + (long long)f * job.npix);
+            if (f < T) {
+                const float2* s = src + (long long)f * job.npix;
+                if constexpr (VEC) {
+                    if (left > 0) stage[i] = *reinterpret_cast<const float4*>(s);       // npix even: pixels come in pairs
+                } else {
+                    const float2 a = left > 0 ? s[0] : make_float2(0.f, 0.f), b = left > 1 ? s[1] : make_float2(0.f, 0.f);
+                    stage[i] = make_float4(a.x, a.y, b.x, b.y);
+                }
+            }
         }
     };
     // registers -> LDS, column-major: thread (q, r0) owns the slots (2q, f), (2q + 1, f) of its frames f in BOTH directions -- it
@@ -91,10 +103,20 @@ __global__ void __launch_bounds__(COLS * R) time_cz_kernel(TimeJob job) {
     auto store_tile = [&](const float2* cols, long long t) {
         const long long p = t / tiles_per_image, c0 = (t % tiles_per_image) * COLS;
         float* dst = job.out + p * job.image_stride + c0 + 2 * q;
+        const int left = job.npix - (int)c0 - 2 * q;
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
             const int f = r0 + ROWS_PER_IT * i;
-            if (f < T) *reinterpret_cast<float2*>(dst + (long long)f * job.npix) = make_float2(cols[(2 * q) * CS + f].x, cols[(2 * q + 1) * CS + f].x);
+            if (f < T) {
+                float* d = dst + (long long)f * job.npix;
+                const float a = cols[(2 * q) * CS + f].x, b = cols[(2 * q + 1) * CS + f].x;
+                if constexpr (VEC) {
+                    if (left > 0) *reinterpret_cast<float2*>(d) = make_float2(a, b);
+                } else {
+                    if (left > 0) d[0] = a;
+                    if (left > 1) d[1] = b;
+                }
+            }
         }
     };
     // my pixel's time line: subtract the first sample, chirp, FFT_M, filter, IFFT_M; |.|^2 (fftshifted) back into the column

@@ -152,7 +152,7 @@ def test_m0_is_only_touched_by_the_addtid_exchange(tmp_path):
                "rowTB_pass_kernelILi32E", "rowTB_pass_kernelILi16E", "rowTB2_pass_kernelILb0ELb0E", "rowTC2_pass_kernel",
                "ifftTB_kernelILi32E", "ifftTB_kernelILi16E", "ifftTB2_kernel", "ifftTW_kernel", "ifftT2_kernelILi16E",
                "structure_factor_quad_kernel", "structure_factor_edge_kernel", "col_pass_kernelILi32ELi16ELb1E", "col_pass_kernelILi16ELi32ELb0E",
-               "time_cz_kernelILi16ELi32E", "time_cz_kernelILi32ELi16E", "tacaw_fold_kernel", "row_pass_pf_kernelILi32E", "row_pass2_kernelILi32E"]
+               "time_cz_kernelILi16ELi32ELb1E", "time_cz_kernelILi32ELi16ELb1E", "time_cz_kernelILi16ELi32ELb0E", "time_cz_kernelILi32ELi16ELb0E", "tacaw_fold_kernel", "row_pass_pf_kernelILi32E", "row_pass2_kernelILi32E"]
     names = re.findall(r"\.amdhsa_kernel (\S+)", text)
     assert not [n for n in names if re.search(r"rowTP|rowT3|rowTC_pass|structure_factor_mfma|structure_factor_nyquist", n)], "superseded kernels are back"
     for name in shipped:

@@ -1143,14 +1143,15 @@ def test_g10_probe_defocus(ps, golden):
     assert np.array_equal(npy(pr.array), before)
 
 
-@pytest.mark.parametrize("T", [2, 3, 33, 40, 100, 128, 129, 255, 257, 500, 512])
-@pytest.mark.parametrize("shape", [(8, 8), (6, 8)])
+@pytest.mark.parametrize("T", [2, 3, 33, 40, 100, 128, 129, 255, 256, 257, 500, 512])
+@pytest.mark.parametrize("shape", [(8, 8), (6, 8), (7, 9), (5, 14)])
 def test_tacaw_any_frame_count_on_the_register_kernel(ps, T, shape):
     """The reference transforms whatever frame count the trajectory has (tacaw_data.py:94-96; 100 frames in its notebook,
     example.ipynb:578).  Every T <= 512 that is not 256 runs the chirp-z register kernel (time_cz_kernel: M = 256 for T <= 128
     on 32- or 16-pixel tiles, M = 1024 above): against the float64 transform of the same float32 frames, per pixel -- some
     pixels with a time mean 1e4 times their thermal part (the kernel subtracts the line's first sample instead of the mean) --
-    and against the generic LDS kernel."""
+    and against the generic LDS kernel.  Pixel counts that are multiples of the tile, ragged (48, 70) and odd (63: the reference's
+    own 501 x 491 test grid has an odd pixel count)."""
     from pyslice_amd import _native
     rng = np.random.default_rng(T)
     nx, ny = shape
