@@ -991,9 +991,11 @@ int slice_loop_onepass(msl_handle* h, int fused_slot, int groups, int first_grou
     return MSL_OK;
 }
 
-int ensure_atoms(msl_handle* h, size_t n) {
-    if (n <= h->atom_cap) return MSL_OK;
-    size_t cap = std::max<size_t>(n, h->atom_cap * 3 / 2 + 1024);
+// n atoms of a frame group; `rows` rows of the sorted phase tables (the atoms plus the padding of every bin to SF_ALIGN rows)
+int ensure_atoms(msl_handle* h, size_t n, size_t rows) {
+    if (rows <= h->atom_cap) return MSL_OK;
+    (void)n;
+    size_t cap = std::max<size_t>(rows, h->atom_cap * 3 / 2 + 1024);
     int rc;
     if ((rc = dalloc(h, &h->d_pos, cap * 3))) return rc;
     if ((rc = dalloc(h, &h->d_Z, cap))) return rc;
@@ -1635,7 +1637,7 @@ static int build_potentials(msl_handle* h, const double* pos, const int32_t* Z, 
         if ((rc = dalloc(h, &h->d_start, (size_t)nkeys_cap + 1))) return rc;
         h->keys_cap = nkeys_cap;
     }
-    if ((rc = ensure_atoms(h, (size_t)n * G))) return rc;
+    if ((rc = ensure_atoms(h, (size_t)n * G, (size_t)n * G + (size_t)(SF_ALIGN - 1) * nkeys_cap))) return rc;
     // R_s is Hermitian (real V): only the rows kx <= nx/2 are written and row-transformed when the inverse transform mirrors them
     // itself (every register-kernel path: col_pass_kernel<.., HERM>, ifftT2 / ifftTB / ifftTW with job.herm)
     const bool tw_axes = h->onepass && h->opx.wave2k && h->opy.wave2k && !h->V && h->transT;
@@ -1707,13 +1709,16 @@ static int build_potentials(msl_handle* h, const double* pos, const int32_t* Z, 
             hipLaunchKernelGGL(atom_prep_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, h->stream, h->d_pos, h->d_Z,
                                (long long)n, g, h->d_z2s, h->d_lo, h->d_hi, c.nz, nsp, ax1, ax2, axs, 1.0 / lx, 1.0 / ly, h->d_key,
                                h->d_u1, h->d_u2, h->d_counts);
-            hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, h->stream, h->d_counts, h->d_start, nkeys);
+            // many atoms per (slice, species): the streaming structure-factor kernel, whose bins are padded to whole half-trips
+            const bool sf_stream = (double)n / std::max(1, keys_per_frame) >= 128.0 && !dbg_env("MSL_SF_TILED");
+            hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, h->stream, h->d_counts, h->d_start, nkeys, sf_stream ? SF_ALIGN : 1);
             hipLaunchKernelGGL(bin_fill_kernel, dim3(nkeys), dim3(1024), 0, h->stream, h->d_key, (long long)n, keys_per_frame, h->d_start, h->d_order);
             HIPCHK(h, hipGetLastError());
             // atoms that fell into a slice: d_start[nkeys], read by the kernels themselves (grids sized for all atoms of the group)
             const int* n_sorted = h->d_start + nkeys;
             recip_written = true;
-            const long long tx = rows * cx, ty = rows * cy;
+            const long long rows_pad = rows + (long long)(SF_ALIGN - 1) * nkeys;          // sorted rows at most: every bin padded to SF_ALIGN
+            const long long tx = rows_pad * cx, ty = rows_pad * cy;
             hipLaunchKernelGGL(phase_table_kernel, dim3((unsigned)((tx + 255) / 256)), dim3(256), 0, h->stream, h->d_ex, h->d_u1,
                                h->d_order, n_sorted, c.nx, cx, cx);
             hipLaunchKernelGGL(phase_table_kernel, dim3((unsigned)((ty + 255) / 256)), dim3(256), 0, h->stream, h->d_ey, h->d_u2,
@@ -1725,8 +1730,14 @@ static int build_potentials(msl_handle* h, const double* pos, const int32_t* Z, 
             const int n_tiles = tiles_x * tiles_y, wg_per_slice = (n_tiles + 3) / 4;
             const long long n_wg = (long long)wg_per_slice * ((n_slices + 7) / 8 * 8);
             if (n_wg > 0x7fffffffLL) return fail(h, MSL_ERR_UNSUPPORTED, "structure factor: too many workgroups");
+            if (sf_stream) {
+                // persistent form, one wave per SIMD: one workgroup per CU, a multiple of 8 (XCD-local slices)
+                const int n_pers = std::max(8, h->n_cus / 8 * 8);
+                hipLaunchKernelGGL(structure_factor_stream_kernel, dim3((unsigned)n_pers), dim3(256), 0, h->stream, TR, h->d_ex, h->d_ey, h->d_ff,
+                                   h->d_start, nsp, c.nx, c.ny, tiles_y, n_tiles, (int)rows_pad, half_rows ? 0 : 1, cx, cy, n_slices);
+            } else
             hipLaunchKernelGGL(structure_factor_quad_kernel, dim3((unsigned)n_wg), dim3(256), 0, h->stream, TR, h->d_ex, h->d_ey, h->d_ff,
-                               h->d_start, nsp, c.nx, c.ny, tiles_y, n_tiles, (int)rows, half_rows ? 0 : 1, cx, cy, n_slices, wg_per_slice);
+                               h->d_start, nsp, c.nx, c.ny, tiles_y, n_tiles, (int)rows_pad, half_rows ? 0 : 1, cx, cy, n_slices, wg_per_slice);
             if (edge_x || edge_y) {
                 const int bins = (edge_x ? cy : 0) + (edge_y ? (edge_x ? cx - 1 : cx) : 0);
                 for (int s0 = 0; s0 < n_slices; s0 += 65535) {

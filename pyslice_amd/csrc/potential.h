@@ -72,14 +72,17 @@ __global__ void atom_prep_kernel(const double* __restrict__ pos, const int* __re
 }
 
 // Exclusive scan of the bin counts (frames x slices x species of a group: up to a few thousand); one workgroup of 1024 threads,
-// every thread a contiguous share, the shares' totals scanned through the LDS.  start[nkeys] = number of atoms inside a slice.
-__global__ void __launch_bounds__(1024) bin_scan_kernel(const int* __restrict__ counts, int* __restrict__ start, int nkeys) {
+// every thread a contiguous share, the shares' totals scanned through the LDS.  `align` (1 or SF_ALIGN = 8): every bin is rounded up
+// to a multiple of that many rows -- the phase tables get zero rows there (order = -1) -- for structure_factor_stream_kernel, which
+// walks whole half-trips of 8 atoms without masks.  start[nkeys] = rows of the sorted tables, padding included.
+#define SF_ALIGN 8
+__global__ void __launch_bounds__(1024) bin_scan_kernel(const int* __restrict__ counts, int* __restrict__ start, int nkeys, int align) {
     __shared__ int part[1024];
     const int t = threadIdx.x;
     const int per = (nkeys + 1023) / 1024;
     const int i0 = t * per, i1 = min(nkeys, i0 + per);
     int acc = 0;
-    for (int i = i0; i < i1; ++i) acc += counts[i];
+    for (int i = i0; i < i1; ++i) acc += (counts[i] + align - 1) / align * align;
     part[t] = acc;
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {            // inclusive Hillis-Steele scan of the 1024 share totals
@@ -89,7 +92,7 @@ __global__ void __launch_bounds__(1024) bin_scan_kernel(const int* __restrict__ 
         __syncthreads();
     }
     int run = part[t] - acc;                               // exclusive prefix of this share
-    for (int i = i0; i < i1; ++i) { start[i] = run; run += counts[i]; }
+    for (int i = i0; i < i1; ++i) { start[i] = run; run += (counts[i] + align - 1) / align * align; }
     if (t == 1023) start[nkeys] = part[1023];
 }
 
@@ -115,6 +118,11 @@ __global__ void __launch_bounds__(1024) bin_fill_kernel(const int* __restrict__ 
     __syncthreads();
     int pos = base;
     for (int w = 0; w < wave; ++w) pos += wave_count[w];
+    if (wave == 0) {                                            // padding rows of the bin (at most SF_ALIGN - 1)
+        int total = 0;
+        for (int w = 0; w < 16; ++w) total += wave_count[w];
+        if (base + total + lane < start[mykey + 1]) order[base + total + lane] = -1;
+    }
     for (long long a0 = lo; a0 < hi; a0 += 64) {
         const long long a = a0 + lane;
         const bool f = (a < hi) && (key[a] == mykey);
@@ -133,7 +141,9 @@ __global__ void phase_table_kernel(float2* __restrict__ table, const double* __r
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)(*n_sorted_ptr) * n_cols) return;
     int a = (int)(i / n_cols), m = (int)(i - (long long)a * n_cols);
-    double t = (double)signed_freq(m, n) * u[order[a]];
+    const int src = order[a];
+    if (src < 0) { table[(long long)a * pitch + m] = make_float2(0.f, 0.f); return; }       // padding row of a bin
+    double t = (double)signed_freq(m, n) * u[src];
     t -= rint(t);
     float sn, cs;
     sincospif((float)(-2.0 * t), &sn, &cs);
@@ -245,6 +255,108 @@ __global__ void __launch_bounds__(256) structure_factor_quad_kernel(float2* __re
         const int mx = kx0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
         if (mx > hx) continue;
         store_quad_bin(out, nx, ny, mx, my, tA[r], tB[r], tC[r], tD[r], write_mx);
+    }
+}
+
+// The same arithmetic as a persistent kernel with ONE wave per SIMD and a continuous matrix-instruction stream, for slices with
+// many atoms.  Counters of the kernel above (tools/sf_mfma_counters.sh): the matrix pipes are busy 56 % of its time at 512^2, 69 %
+// at 1024^2 -- every (slice, species) is a handful of 16-atom trips between a latency-exposed first operand load and a
+// latency-exposed weight load.  Here a wave walks ALL rows of a slice in half-trips of 8 (the sorted tables keep a slice's species
+// contiguous; with `align` = 8 every bin is padded with zero rows to a multiple of 8: no masks, and a species boundary is a
+// half-trip boundary) with its operand loads three half-trips ahead in four register sets; at a boundary the sums are flushed into
+// the totals with the species' weights f_Z, which were fetched while it accumulated.  Work item q = (slice, group of 4 tiles),
+// dealt so that the workgroups of an XCD (blockIdx % 8) walk the slices s = xcd + 8 m in order: a few slices in flight per L2.
+// Measured against the tiled kernel (same box, potential per frame): 1024^2 x 200 slices (267 rows per bin) 4.42 -> 4.33 ms,
+// 2048^2 x 50 (1 058 per bin) 11.85 -> 10.88 ms, 512^2 x 100 (66 per bin, +9 % padding) 0.312 -> 0.316 ms: used from 128 rows per
+// bin on.  (A variant without running totals -- species flushed straight into the bins, read-modify-write, 2 waves per SIMD --
+// spills: five inlined copies of the flush.)
+__global__ void __launch_bounds__(256, 1) structure_factor_stream_kernel(float2* __restrict__ recip, const float2* __restrict__ ex,
+                                                                      const float2* __restrict__ ey, const float* __restrict__ ff,
+                                                                      const int* __restrict__ start, int n_species, int nx, int ny,
+                                                                      int tiles_y, int n_tiles, int n_rows, int write_mx, int px_pitch,
+                                                                      int py_pitch, int n_slices) {
+    const int xcd = blockIdx.x & 7, jw = blockIdx.x >> 3, wg_x = gridDim.x >> 3;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hx = nx / 2, hy = ny / 2;
+    const int i = lane & 31, kk = lane >> 5;
+    const int G = (n_tiles + 3) / 4, Mx = (n_slices + 7) / 8;
+    for (int q = jw; q < Mx * G; q += wg_x) {
+        const int m = q / G, g = q - m * G;
+        const int s = xcd + 8 * m, tile = 4 * g + wave;
+        if (s >= n_slices || tile >= n_tiles) continue;
+        const int kx0 = (tile / tiles_y) * 32, ky0 = (tile % tiles_y) * 32;
+        const int lx = min(kx0 + i, hx), ly = min(ky0 + i, hy);
+        const float2* exl = ex + lx;
+        const float2* eyl = ey + ly;
+        const int* st = start + s * n_species;
+        const int S0 = st[0], S1 = st[n_species];
+        const int H = (S1 - S0) >> 3;                   // whole half-trips: every bin is padded to a multiple of 8 rows
+        f32x16 tA = {0}, tB = {0}, tC = {0}, tD = {0};
+        f32x16 A = {0}, B = {0}, C = {0}, D = {0};
+        // species in turn (empty ones skipped): sp accumulates until row seg1; spn is the next one with rows
+        int sp = -1, seg1 = S0, spn = -1, segn1 = S0;
+        auto next_of = [&](int& k, int& e) { const int from = e; do { ++k; if (k >= n_species) return; e = st[k + 1]; } while (e <= from); };
+        float wc[16], wn[16];               // weights f_Z of the current species, and of the one after it (in flight)
+        auto load_w = [&](int spc, float (&w)[16]) {
+            const float* f = ff + (size_t)spc * nx * ny;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) w[r] = f[(size_t)min(kx0 + (r & 3) + 8 * (r >> 2) + 4 * kk, hx) * ny + ly];
+        };
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { wc[r] = 0.f; wn[r] = 0.f; }
+        next_of(sp, seg1);
+        spn = sp; segn1 = seg1;
+        if (sp < n_species) { load_w(sp, wc); next_of(spn, segn1); if (spn < n_species) load_w(spn, wn); }
+        auto flush = [&]() {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                tA[r] = fmaf(wc[r], A[r], tA[r]); tB[r] = fmaf(wc[r], B[r], tB[r]);
+                tC[r] = fmaf(wc[r], C[r], tC[r]); tD[r] = fmaf(wc[r], D[r], tD[r]);
+                A[r] = 0.f; B[r] = 0.f; C[r] = 0.f; D[r] = 0.f;
+                wc[r] = wn[r];
+            }
+            sp = spn; seg1 = segn1;
+            if (sp < n_species) { next_of(spn, segn1); if (spn < n_species) load_w(spn, wn); }
+        };
+        auto load8 = [&](int h, float2 (&x)[4], float2 (&y)[4]) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = min(S0 + 8 * h + kk + 2 * u, n_rows - 1);
+                x[u] = exl[(size_t)r * px_pitch];
+                y[u] = eyl[(size_t)r * py_pitch];
+            }
+        };
+        // (the accumulators are pinned to the accumulation registers by the asm constraints: with the builtin the register
+        // allocator moved all 64 of them between the two files at every branch of this loop)
+        auto mma = [&](f32x16& acc, float a, float b) { asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b)); };
+        auto step = [&](int h, const float2 (&x)[4], const float2 (&y)[4]) {
+            if (S0 + 8 * h == seg1) flush();                // the species ended with the previous half-trip
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                mma(A, x[u].x, y[u].x);
+                mma(B, x[u].y, y[u].y);
+                mma(C, x[u].x, y[u].y);
+                mma(D, x[u].y, y[u].x);
+            }
+        };
+        float2 x0[4], y0[4], x1[4], y1[4], x2[4], y2[4], x3[4], y3[4];
+        if (H > 0) { load8(0, x0, y0); load8(1, x1, y1); load8(2, x2, y2); }
+        for (int h = 0; h < H; h += 4) {
+            load8(h + 3, x3, y3); step(h, x0, y0);
+            if (h + 1 < H) { load8(h + 4, x0, y0); step(h + 1, x1, y1); }
+            if (h + 2 < H) { load8(h + 5, x1, y1); step(h + 2, x2, y2); }
+            if (h + 3 < H) { load8(h + 6, x2, y2); step(h + 3, x3, y3); }
+        }
+        if (H > 0) flush();                                 // the slice's last species
+        float2* out = recip + (size_t)s * nx * ny;
+        const int my = ky0 + i;
+        if (my > hy) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int mx = kx0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+            if (mx > hx) continue;
+            store_quad_bin(out, nx, ny, mx, my, tA[r], tB[r], tC[r], tD[r], write_mx);
+        }
     }
 }
 

@@ -588,6 +588,44 @@ def test_randomised_potential_sweep(ps, orc):
         assert err < POT_TOL, (cfg, err)
 
 
+@pytest.mark.parametrize("nx,ny,nz,n_atoms,batch", [(96, 80, 3, 1500, 1), (128, 128, 2, 2100, 3), (64, 250, 1, 400, 1), (256, 256, 4, 1100, 2)])
+def test_structure_factor_stream_kernel_dense_slices(ps, orc, nx, ny, nz, n_atoms, batch):
+    """From 128 atoms per (slice, species) on the potential takes structure_factor_stream_kernel (persistent, the rows of every bin
+    padded to whole half-trips of 8, species flushed at half-trip boundaries): three species of which one is missing from a
+    slice and one slice holds a single species, bin sizes that are and are not multiples of 8, several frames per build, odd grid
+    lengths; and just below the threshold the tiled kernel on the same kind of input.  Transmission functions against the
+    oracle's potential."""
+    from pyslice_amd import _native
+    from pyslice_amd.potentials import loadKirkland
+    rng = np.random.default_rng(nx + n_atoms)
+    dx, dy, dz = 0.1, 0.09, 0.5
+    xs, ys, zs = np.arange(nx) * dx, np.arange(ny) * dy, np.arange(nz) * dz
+    Z = rng.choice([5, 7, 14], size=n_atoms, p=[0.5, 0.4, 0.1]).astype(np.int32)
+    eV = 100e3
+    sig = orc.interaction_sigma(eV)
+    frames = []
+    for b in range(batch):
+        pos = rng.random((n_atoms, 3)) * [nx * dx, ny * dy, nz * dz]
+        if nz > 1:
+            pos[(Z == 14) & (pos[:, 2] < 0.75), 2] += 0.6                # no Si in the first slice
+            pos[(Z != 5) & (pos[:, 2] >= (nz - 1) * dz + 0.25 - dz / 2), 2] -= dz      # the last slice holds boron only
+        frames.append(pos)
+    eng = _native.Engine(nx, ny, nz, dx, dy, dz, orc.wavelength(eV), sig, n_probes=1, n_frames=batch, frame_batch=batch)
+    eng.set_kirkland(loadKirkland())
+    eng.set_slices(*orc.slice_edges(zs))
+    if batch > 1:
+        eng.build_potentials(np.stack(frames), Z, 2)
+    else:
+        eng.build_potential(frames[0], Z, 2)
+    for b in range(batch):
+        eng.select_batch_slot(b)
+        V = orc.potential(xs, ys, zs, frames[b], Z)
+        t = eng.transmission()
+        err = np.abs(t - np.exp(1j * sig * np.moveaxis(V, 2, 0))).max() / (sig * np.abs(V).max())
+        assert err < POT_TOL, (b, err)
+    eng.close()
+
+
 @pytest.mark.parametrize("nx,ny,nz,P", [(256, 256, 3, 700), (512, 512, 4, 70), (2048, 512, 4, 20), (1024, 512, 4, 33),
                                          (500, 360, 3, 40)])
 def test_many_probes_per_launch(ps, orc, nx, ny, nz, P):
