@@ -1509,7 +1509,8 @@ __device__ __forceinline__ void line2_transform(float2 (&v)[2 * R], float* scrat
 // Transposing pass A . t_k . A for N = 2 R^2 with R = 16 (N = 512): next line prefetched and t_k kept in registers like
 // rowT_pass_kernel, full-line tile.  (2048 = 2 * 32^2 holds 64 complex per lane in this layout, with room for neither: 2048-point
 // lines run on the wave-per-line transform, rowTW_pass_kernel.)
-template <int R>
+// IN_P / OUT_P: interleaved line order of the work buffer on the input / output side (see rowT_pass_kernel): 16-byte loads.
+template <int R, bool IN_P = false, bool OUT_P = false>
 __global__ void __launch_bounds__(16 * R, 2) rowT2_pass_kernel(RowTJob job) {      // two waves per SIMD: at most 256 VGPRs + AGPRs
     static_assert(R == 16, "the 2 R^2 layout is used for 512-point lines only");
     constexpr int N2 = R * R, N = 2 * N2, NT = 16 * R;
@@ -1538,17 +1539,36 @@ __global__ void __launch_bounds__(16 * R, 2) rowT2_pass_kernel(RowTJob job) {   
     const int step_lb = (int)gridDim.x / pchunks, step_pc = (int)gridDim.x % pchunks;
     int item = blockIdx.x;
     int lb = item / pchunks, pc = item % pchunks, k = 0;
-    const int in_off = grp * job.in_pitch + ln;
-    auto block_base = [&](int lbb, int pcc, int kk) {
-        return job.in + ((long long)(pcc * PC + kk) * job.in_image_stride + (long long)lbb * 16 * job.in_pitch);
+    // input line of tile row g in line block lbb (OUT_P: 8 lines of block 2 jp and the same 8 of block 2 jp + 1 of the reader's
+    // 2 R' chunks; the thread index is re-derived at every use: the kernel sits at its register limit)
+    auto line_of = [&](int lbb, int g) {
+        if constexpr (OUT_P) {
+            const int sh = job.perm_shift;
+            return (((lbb >> sh) * 2 + (g & 1)) << (sh + 3)) + 8 * (lbb & ((1 << sh) - 1)) + (g >> 1);
+        } else {
+            return lbb * 16 + g;
+        }
+    };
+    auto image_base = [&](int pcc, int kk) { return job.in + (long long)(pcc * PC + kk) * job.in_image_stride; };
+    auto load_line = [&](float2 (&dst)[2 * R], const float2* img, int lbb) {
+        int t = tid;
+        asm volatile("" : "+v"(t));
+        const float2* r = img + (long long)line_of(lbb, t / R) * job.in_pitch;
+        const int l = t % R;
+        if constexpr (IN_P) {
+#pragma unroll
+            for (int jp = 0; jp < R; ++jp) {
+                const msl_f4v q4 = __builtin_nontemporal_load(reinterpret_cast<const msl_f4v*>(r + (2 * R * jp + 2 * l)));
+                dst[2 * jp] = make_float2(q4.x, q4.y); dst[2 * jp + 1] = make_float2(q4.z, q4.w);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2 * R; ++j) dst[j] = ld_stream(r + (l + j * R));
+        }
     };
     float2 vn[2 * R];
     float2 tv[2 * R];
-    if (item < n_items) {
-        const float2* r = block_base(lb, pc, 0);
-#pragma unroll
-        for (int j = 0; j < 2 * R; ++j) vn[j] = ld_stream(r + (in_off + j * R));
-    }
+    if (item < n_items) load_line(vn, image_base(pc, 0), lb);
     while (item < n_items) {
         float2 v[2 * R];
 #pragma unroll
@@ -1556,26 +1576,18 @@ __global__ void __launch_bounds__(16 * R, 2) rowT2_pass_kernel(RowTJob job) {   
         const int p = pc * PC + k;
         const int cur_lb = lb;
         if (k == 0) {
-            const float2* trow = job.trans + frame_off(job, pc * PC) + (long long)lb * 16 * N;
             int toff = tid;                               // re-derived here (one chunk of probes in PC): not worth a register across the loop
             asm volatile("" : "+v"(toff));
-            toff = (toff / R) * N + (toff % R);
+            const float2* trow = job.trans + frame_off(job, pc * PC) + (long long)line_of(lb, toff / R) * N + (toff % R);
 #pragma unroll
-            for (int j = 0; j < 2 * R; ++j) tv[j] = trow[toff + j * R];
+            for (int j = 0; j < 2 * R; ++j) tv[j] = trow[j * R];
         }
         int nitem = item, nlb = lb, npc = pc, nk = k + 1;
         if (nk >= min(PC, job.n_images - pc * PC)) {
             nk = 0; nitem = item + (int)gridDim.x; nlb = lb + step_lb; npc = pc + step_pc;
             if (npc >= pchunks) { npc -= pchunks; ++nlb; }
         }
-        if (nitem < n_items) {                          // (a mid-iteration prefetch as in rowT_pass_kernel measured 3% slower here)
-            const float2* r = block_base(nlb, npc, nk);
-            int ioff = tid;                             // re-derived from the thread index every iteration: the kernel sits at
-            asm volatile("" : "+v"(ioff));              // its register limit and would otherwise spill this offset
-            ioff = (ioff / R) * job.in_pitch + (ioff % R);
-#pragma unroll
-            for (int j = 0; j < 2 * R; ++j) vn[j] = ld_stream(r + (ioff + j * R));
-        }
+        if (nitem < n_items) load_line(vn, image_base(npc, nk), nlb);      // (a mid-iteration prefetch as in rowT_pass_kernel measured 3% slower here)
         if (job.flags & P2_PRE_A) {
             line2_transform<R, false, XM>(v, scratch, tw, tw2, ln, wscr, wscr_lds, tid & 63);
             mul_table<2 * R, 0, false, R>(v, pl, ln);

@@ -727,7 +727,8 @@ int launch_rowT_r(msl_handle* h, const RowTJob& job, int kind) {
 }
 
 // lines of 2 R^2 = 512 points
-int launch_rowT2(msl_handle* h, RowTJob job, int kind) {
+template <bool IN_P, bool OUT_P>
+int launch_rowT2_io(msl_handle* h, RowTJob job, int kind) {
     constexpr int R = 16, N2 = R * R, N = 2 * N2;
     const size_t lds = ((size_t)2 * N2 + N + (size_t)16 * (N + 2)) * 8;
     const int per_cu = std::max(1, std::min(2, (int)((size_t)h->lds_limit / lds)));
@@ -738,10 +739,15 @@ int launch_rowT2(msl_handle* h, RowTJob job, int kind) {
     job.pchunk = pc;
     const long long items = lb * ((job.n_images + pc - 1) / pc);
     const int grid = (int)std::min<long long>(items, slots);
-    (void)hipFuncSetAttribute((const void*)rowT2_pass_kernel<R>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
-    hipLaunchKernelGGL(rowT2_pass_kernel<R>, dim3(grid), dim3(16 * R), lds, h->stream, job);
+    (void)hipFuncSetAttribute((const void*)rowT2_pass_kernel<R, IN_P, OUT_P>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
+    hipLaunchKernelGGL((rowT2_pass_kernel<R, IN_P, OUT_P>), dim3(grid), dim3(16 * R), lds, h->stream, job);
     HIPCHK(h, hipGetLastError());
     return mark_launch(h, kind);
+}
+int launch_rowT2(msl_handle* h, const RowTJob& job, int kind) {
+    const bool in_p = job.flags & P2_IN_PAIRED, out_p = job.flags & P2_OUT_PAIRED;
+    if (in_p) return out_p ? launch_rowT2_io<true, true>(h, job, kind) : launch_rowT2_io<true, false>(h, job, kind);
+    return out_p ? launch_rowT2_io<false, true>(h, job, kind) : launch_rowT2_io<false, false>(h, job, kind);
 }
 
 // lines of any length <= R^2/2: zero-padded cyclic convolution on the register FFTs
@@ -833,7 +839,7 @@ int launch_rowT_dir(msl_handle* h, const msl_handle::OpDir& o, RowTJob job, int 
     }
     job.tw = o.tw;
     if (o.wave2k) { job.tw2 = o.tw2; return launch_rowTW(h, job, kind); }
-    job.flags &= ~(P2_IN_PAIRED | P2_OUT_PAIRED);
+    if (!(o.two || (o.R && !o.breg && !o.breg2 && !o.breg4))) job.flags &= ~(P2_IN_PAIRED | P2_OUT_PAIRED);    // (only the 256 / 512 / 1024-point kernels read and write the interleaved order)
     if (o.breg4) {                          // 1025 .. 2047 points: cyclic convolution of length 4096, two waves per line
         job.n_line = (&o == &h->opx) ? h->cfg.nx : h->cfg.ny;
         job.tw2 = o.tw2; job.bf = o.qf; job.bw = o.bw; job.pl = nullptr;
@@ -880,6 +886,12 @@ int slice_loop_onepass_b(msl_handle* h, int fused_slot, int groups, int first_gr
         if (groups > 1) { j.t_group = c.n_probes; j.t_magic = (unsigned)((1ull << 32) / (unsigned)c.n_probes + 1); j.t_stride = (long long)c.nz * npix; }
         if (h->opx.wave2k && h->opy.wave2k)               // work buffers between two of these passes: paired-lines layout
             j.flags |= (k > 0 ? P2_IN_PAIRED : 0) | (k < nz - 1 ? P2_OUT_PAIRED : 0);
+        // 512-point lines next to 512 / 256 / 1024-point ones: interleaved line order between two passes (16-byte loads)
+        auto il_kernel = [](const msl_handle::OpDir& o) { return o.R && !o.generic && !o.breg && !o.breg2 && !o.breg4 && !o.wave2k; };
+        if (il_kernel(h->opx) && il_kernel(h->opy) && !dbg_env("MSL_NO_INTERLEAVE")) {
+            j.flags |= (k > 0 ? P2_IN_PAIRED : 0) | (k < nz - 1 ? P2_OUT_PAIRED : 0);
+            j.perm_shift = (((k & 1) ? h->opy : h->opx).R == 32) ? 2 : 1;       // radix of the kernel that reads this pass's output
+        }
         if (!(k & 1)) {
             j.in = (k == 0) ? h->psi0 : h->psi; j.out = h->psiT;
             j.trans = h->trans + toff + (size_t)k * npix; j.pl = h->pyt;

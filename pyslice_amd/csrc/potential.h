@@ -138,9 +138,16 @@ __global__ void __launch_bounds__(1024) bin_fill_kernel(const int* __restrict__ 
 // is odd in t, so the full table is exactly conjugate-symmetric: table[a][n-m] == conj(table[a][m]).
 __global__ void phase_table_kernel(float2* __restrict__ table, const double* __restrict__ u,
                                    const int* __restrict__ order, const int* __restrict__ n_sorted_ptr, int n, int n_cols, int pitch) {
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long long)(*n_sorted_ptr) * n_cols) return;
-    int a = (int)(i / n_cols), m = (int)(i - (long long)a * n_cols);
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)(*n_sorted_ptr) * n_cols;
+    if (i >= total) return;
+    int a, m;
+    if (total < 0xffffffffLL) {                         // (uniform) 32-bit division: the 64-bit one was most of this kernel's instructions
+        const unsigned iu = (unsigned)i;
+        a = (int)(iu / (unsigned)n_cols); m = (int)(iu - (unsigned)a * (unsigned)n_cols);
+    } else {
+        a = (int)(i / n_cols); m = (int)(i - (long long)a * n_cols);
+    }
     const int src = order[a];
     if (src < 0) { table[(long long)a * pitch + m] = make_float2(0.f, 0.f); return; }       // padding row of a bin
     double t = (double)signed_freq(m, n) * u[src];
