@@ -1361,20 +1361,39 @@ __global__ void __launch_bounds__(512, 2) rowTW_pass_kernel(RowTJob job) {
     const int pchunks = (job.n_images + PC - 1) / PC;
     const int n_items = lblocks * pchunks;
     const int step_lb = (int)gridDim.x / pchunks, step_pc = (int)gridDim.x % pchunks;
-    constexpr int ES = IN_P ? 2 : 1;
+    // The work buffer between two of these passes (IN_P / OUT_P): lines in pairs -- the pair L/2 shares a row of 2 x pitch entries --
+    // and inside a pair the elements in chunks of 128: entry 256 (e >> 7) + ((2 (e & 63) + (L & 1)) * 2 + ((e >> 6) & 1)) holds element
+    // e of line L.  A lane's registers 2 jp and 2 jp + 1 (elements 128 jp + la and 128 jp + 64 + la) are adjacent: 16-byte loads, a
+    // wave's load covers 1 KB of which it uses half and its pair's wave the other half (round 2's layout 2 e + (L & 1) made every
+    // load an 8-byte access at a 16-byte stride).  The writer's tile is 4 lines l0 .. l0 + 3 of block 2 jp and the same 4 of block
+    // 2 jp + 1 (tile row r = line 128 jp + 64 (r & 1) + l0 + (r >> 1)): with the two positions of a position pair they fill 16
+    // consecutive entries -- the 128-byte segments of before.
+    auto line_of = [&](int lbb) {
+        if constexpr (OUT_P) return 128 * (lbb >> 4) + 64 * (wv & 1) + 4 * (lbb & 15) + (wv >> 1);
+        else return lbb * LINES + wv;
+    };
     auto line_ptr = [&](int lbb, int pcc, int kk) {
-        const int Ln = lbb * LINES + wv;
-        const long long off = IN_P ? (long long)(Ln >> 1) * (2 * job.in_pitch) + (Ln & 1) : (long long)Ln * job.in_pitch;
-        return job.in + (long long)(pcc * PC + kk) * job.in_image_stride + off + la * ES;
+        const int Ln = line_of(lbb);
+        const long long off = IN_P ? (long long)(Ln >> 1) * (2 * job.in_pitch) + (2 * la + (Ln & 1)) * 2 : (long long)Ln * job.in_pitch + la;
+        return job.in + (long long)(pcc * PC + kk) * job.in_image_stride + off;
+    };
+    auto load_regs = [&](float2 (&dst)[R], const float2* r, auto lo_c, auto hi_c) {
+        constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
+        if constexpr (IN_P) {
+#pragma unroll
+            for (int jp = LO / 2; jp < HI / 2; ++jp) {
+                const msl_f4v t = __builtin_nontemporal_load(reinterpret_cast<const msl_f4v*>(r + 256 * jp));
+                dst[2 * jp] = make_float2(t.x, t.y); dst[2 * jp + 1] = make_float2(t.z, t.w);
+            }
+        } else {
+#pragma unroll
+            for (int j = LO; j < HI; ++j) dst[j] = ld_stream(r + j * 64);
+        }
     };
     int item = blockIdx.x;
     int lb = item / pchunks, pc = item - lb * pchunks, k = 0;
     float2 vn[R];
-    if (item < n_items) {
-        const float2* r = line_ptr(lb, pc, 0);
-#pragma unroll
-        for (int j = 0; j < R; ++j) vn[j] = ld_stream(r + (j * 64 * ES));
-    }
+    if (item < n_items) load_regs(vn, line_ptr(lb, pc, 0), MSL_IC(0), MSL_IC(R));
     float2 tv[R];
     while (item < n_items) {
         float2 v[R];
@@ -1383,7 +1402,7 @@ __global__ void __launch_bounds__(512, 2) rowTW_pass_kernel(RowTJob job) {
         const int p = pc * PC + k;
         const int cur_lb = lb;
         if (k == 0) {
-            const float2* trow = job.trans + frame_off(job, pc * PC) + (long long)(lb * LINES + wv) * N + la;
+            const float2* trow = job.trans + frame_off(job, pc * PC) + (long long)line_of(lb) * N + la;
 #pragma unroll
             for (int j = 0; j < R; ++j) tv[j] = trow[j * 64];
         }
@@ -1395,11 +1414,7 @@ __global__ void __launch_bounds__(512, 2) rowTW_pass_kernel(RowTJob job) {
         auto prefetch_part = [&](auto lo_c, auto hi_c) {
             constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
             __builtin_amdgcn_sched_barrier(0);
-            if (nitem < n_items) {
-                const float2* r = line_ptr(nlb, npc, nk);
-#pragma unroll
-                for (int j = LO; j < HI; ++j) vn[j] = ld_stream(r + (j * 64 * ES));
-            }
+            if (nitem < n_items) load_regs(vn, line_ptr(nlb, npc, nk), MSL_IC(LO), MSL_IC(HI));
             __builtin_amdgcn_sched_barrier(0);
         };
         if (job.flags & P2_PRE_A) fft2048_wave<false, TCH>(v, scr, tw, w64, L, la, sgn);
@@ -1423,17 +1438,18 @@ __global__ void __launch_bounds__(512, 2) rowTW_pass_kernel(RowTJob job) {
         for (int j = 0; j < R; ++j) myrow[j * 64 + L] = v[j];          // element 64 j + lam(L) at lds_pos64
         lds_barrier();
         if constexpr (OUT_P) {
-            const int i = tid & 7, oct = tid >> 3, q = oct & 3, hh = oct >> 2;
-            // pair index 0 .. 63: the four octets of a half-wave take pairs whose tile positions are 8 apart (different banks)
+            // one 16-byte store = position 2 mm + c of the tile rows 2 i and 2 i + 1 (blocks 2 jp / 2 jp + 1 of the output line pair
+            // mm); eight lanes (i, c) make a 128-byte run; the four octets of a half-wave take pairs 8 positions apart (LDS banks)
+            const int i8 = tid & 7, i = i8 >> 1, c = i8 & 1, oct = tid >> 3, q = oct & 3, hh = oct >> 2;
             const int mm0 = 2 * q + (hh & 1) + 8 * ((hh >> 1) & 1) + 16 * ((hh >> 2) & 1) + 32 * (hh >> 3);
-            const float2* src = tile + i * RS + lds_pos64(2 * mm0);
-            float2* dst = job.out + (long long)p * job.out_image_stride + 2 * (cur_lb * LINES + i);
+            const float2* src = tile + (2 * i) * RS + lds_pos64(2 * mm0 + c);
+            float2* dst = job.out + (long long)p * job.out_image_stride + 256 * (cur_lb >> 4) + (2 * (4 * (cur_lb & 15) + i) + c) * 2;
             int off0 = mm0 * 2 * job.out_pitch;
             asm volatile("" : "+v"(off0));
             const int ostep = 64 * 2 * job.out_pitch;
 #pragma unroll
             for (int it = 0; it < N / 2 / 64; ++it) {
-                const float2 a = src[it * 128], b = src[it * 128 + 2];       // elements 2 mm, 2 mm + 1: two lanes apart
+                const float2 a = src[it * 128], b = src[RS + it * 128];
                 st_stream(dst + (off0 + it * ostep), a.x, a.y, b.x, b.y);
             }
         } else {
