@@ -58,6 +58,16 @@ constexpr int bitrev(int i, int n) {
     return r;
 }
 
+// FENCE: a scheduling barrier after every butterfly.  A long transform held by ONE lane (tacaw_time.h: 100 complex registers) leaves
+// the scheduler free to interleave dozens of independent butterflies, whose temporaries then no longer fit beside the data; in
+// program order a butterfly needs its own operands and nothing else.  (The 16- / 32-point transforms of the slice loop stay unfenced.)
+template <bool FENCE>
+MSL_HD void fft_fence() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (FENCE) __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
 // t * W_N^k with W = exp(-+ 2 pi i / N); INV selects the conjugate (inverse transform)
 template <int N, int K, bool INV>
 MSL_HD cf twiddle_mul(cf t) {
@@ -86,7 +96,16 @@ MSL_HD cf twiddle_mul(cf t) {
 // Radix plan of the decimation-in-frequency network: radix 4 while the length allows it, then one radix-2 stage
 // (32 = 4.4.2, 16 = 4.4).  Half as many twiddle multiplications on every input-to-output path as a pure radix-2
 // network: the rounding error of a transform, which accumulates linearly over the slices of a multislice run, halves.
-constexpr int fft_radix(int n) { return (n % 4 == 0) ? 4 : 2; }
+// Other lengths (the per-lane time transform of tacaw_time.h: 100 = 4.5.5 frames, 96 = 4.4.2.3 ...) continue with radix 5 and 3;
+// a length with another prime factor has no plan (fft_smooth).
+constexpr int fft_radix(int n) { return (n % 4 == 0) ? 4 : (n % 2 == 0) ? 2 : (n % 5 == 0) ? 5 : 3; }
+constexpr bool fft_smooth(int n) {
+    if (n < 1) return false;
+    while (n % 2 == 0) n /= 2;
+    while (n % 3 == 0) n /= 3;
+    while (n % 5 == 0) n /= 5;
+    return n == 1;
+}
 
 // frequency index held at position i after dif<N>: block q = i / (N/r) holds the sub-transform of the outputs r m + q
 constexpr int dif_out_index(int i, int n) {
@@ -95,17 +114,18 @@ constexpr int dif_out_index(int i, int n) {
     return r * dif_out_index(i % m, m) + i / m;
 }
 
-template <int N, int S, bool INV, int K>
+template <int N, int S, bool INV, int K, bool FENCE = false>
 MSL_HD void dif2_level(cf* v) {
     if constexpr (K < N / 2) {
         cf a = v[K * S], b = v[(K + N / 2) * S];
         v[K * S] = mk(a.x + b.x, a.y + b.y);
         v[(K + N / 2) * S] = twiddle_mul<N, K, INV>(mk(a.x - b.x, a.y - b.y));
-        dif2_level<N, S, INV, K + 1>(v);
+        fft_fence<FENCE>();
+        dif2_level<N, S, INV, K + 1, FENCE>(v);
     }
 }
 
-template <int N, int S, bool INV, int K>
+template <int N, int S, bool INV, int K, bool FENCE = false>
 MSL_HD void dif4_level(cf* v) {
     if constexpr (K < N / 4) {
         constexpr int Q = N / 4;
@@ -117,28 +137,77 @@ MSL_HD void dif4_level(cf* v) {
         v[(K + Q) * S] = twiddle_mul<N, K, INV>(mk(t1.x + t3.x, t1.y + t3.y));
         v[(K + 2 * Q) * S] = twiddle_mul<N, 2 * K, INV>(mk(t0.x - t2.x, t0.y - t2.y));
         v[(K + 3 * Q) * S] = twiddle_mul<N, 3 * K, INV>(mk(t1.x - t3.x, t1.y - t3.y));
-        dif4_level<N, S, INV, K + 1>(v);
+        fft_fence<FENCE>();
+        dif4_level<N, S, INV, K + 1, FENCE>(v);
     }
 }
 
-template <int N, int S, bool INV, int Q>
+// radix 3: y0 = a0 + s, y1,2 = a0 - s/2 -+ i sin(2 pi/3) d   (s = a1 + a2, d = a1 - a2; signs for the forward transform)
+template <int N, int S, bool INV, int K, bool FENCE = false>
+MSL_HD void dif3_level(cf* v) {
+    if constexpr (K < N / 3) {
+        constexpr int Q = N / 3;
+        constexpr float sn = 0.86602540378443864676f;
+        const cf a0 = v[K * S], a1 = v[(K + Q) * S], a2 = v[(K + 2 * Q) * S];
+        const cf s = mk(a1.x + a2.x, a1.y + a2.y), d = mk(a1.x - a2.x, a1.y - a2.y);
+        const cf m = mk(a0.x - 0.5f * s.x, a0.y - 0.5f * s.y);
+        const cf n = INV ? mk(-sn * d.y, sn * d.x) : mk(sn * d.y, -sn * d.x);      // -+ i sn d
+        v[K * S] = mk(a0.x + s.x, a0.y + s.y);
+        v[(K + Q) * S] = twiddle_mul<N, K, INV>(mk(m.x + n.x, m.y + n.y));
+        v[(K + 2 * Q) * S] = twiddle_mul<N, 2 * K, INV>(mk(m.x - n.x, m.y - n.y));
+        fft_fence<FENCE>();
+        dif3_level<N, S, INV, K + 1, FENCE>(v);
+    }
+}
+
+// radix 5 on the sums and differences of the pairs (1,4), (2,3): 36 instructions per butterfly
+template <int N, int S, bool INV, int K, bool FENCE = false>
+MSL_HD void dif5_level(cf* v) {
+    if constexpr (K < N / 5) {
+        constexpr int Q = N / 5;
+        constexpr float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;     // cos(2 pi/5), cos(4 pi/5)
+        constexpr float s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;      // sin(2 pi/5), sin(4 pi/5)
+        const cf a0 = v[K * S], a1 = v[(K + Q) * S], a2 = v[(K + 2 * Q) * S], a3 = v[(K + 3 * Q) * S], a4 = v[(K + 4 * Q) * S];
+        const cf p1 = mk(a1.x + a4.x, a1.y + a4.y), d1 = mk(a1.x - a4.x, a1.y - a4.y);
+        const cf p2 = mk(a2.x + a3.x, a2.y + a3.y), d2 = mk(a2.x - a3.x, a2.y - a3.y);
+        const cf m1 = mk(a0.x + c1 * p1.x + c2 * p2.x, a0.y + c1 * p1.y + c2 * p2.y);
+        const cf m2 = mk(a0.x + c2 * p1.x + c1 * p2.x, a0.y + c2 * p1.y + c1 * p2.y);
+        const cf n1 = mk(s1 * d1.x + s2 * d2.x, s1 * d1.y + s2 * d2.y);
+        const cf n2 = mk(s2 * d1.x - s1 * d2.x, s2 * d1.y - s1 * d2.y);
+        // forward: y1 = m1 - i n1, y4 = m1 + i n1, y2 = m2 - i n2, y3 = m2 + i n2; the inverse swaps the signs
+        const cf r1 = INV ? mk(-n1.y, n1.x) : mk(n1.y, -n1.x);
+        const cf r2 = INV ? mk(-n2.y, n2.x) : mk(n2.y, -n2.x);
+        v[K * S] = mk(a0.x + p1.x + p2.x, a0.y + p1.y + p2.y);
+        v[(K + Q) * S] = twiddle_mul<N, K, INV>(mk(m1.x + r1.x, m1.y + r1.y));
+        v[(K + 2 * Q) * S] = twiddle_mul<N, 2 * K, INV>(mk(m2.x + r2.x, m2.y + r2.y));
+        v[(K + 3 * Q) * S] = twiddle_mul<N, 3 * K, INV>(mk(m2.x - r2.x, m2.y - r2.y));
+        v[(K + 4 * Q) * S] = twiddle_mul<N, 4 * K, INV>(mk(m1.x - r1.x, m1.y - r1.y));
+        fft_fence<FENCE>();
+        dif5_level<N, S, INV, K + 1, FENCE>(v);
+    }
+}
+
+template <int N, int S, bool INV, int Q, bool FENCE = false>
 MSL_HD void dif_blocks(cf* v);
 
 // decimation in frequency on v[0], v[S], ..., v[(N-1)S]; position i ends up holding frequency dif_out_index(i, N)
-template <int N, int S, bool INV>
+template <int N, int S, bool INV, bool FENCE = false>
 MSL_HD void dif(cf* v) {
     if constexpr (N > 1) {
-        if constexpr (fft_radix(N) == 4) dif4_level<N, S, INV, 0>(v); else dif2_level<N, S, INV, 0>(v);
-        dif_blocks<N, S, INV, 0>(v);
+        if constexpr (fft_radix(N) == 4) dif4_level<N, S, INV, 0, FENCE>(v);
+        else if constexpr (fft_radix(N) == 2) dif2_level<N, S, INV, 0, FENCE>(v);
+        else if constexpr (fft_radix(N) == 5) dif5_level<N, S, INV, 0, FENCE>(v);
+        else dif3_level<N, S, INV, 0, FENCE>(v);
+        dif_blocks<N, S, INV, 0, FENCE>(v);
     }
 }
 
-template <int N, int S, bool INV, int Q>
+template <int N, int S, bool INV, int Q, bool FENCE>
 MSL_HD void dif_blocks(cf* v) {
     constexpr int R = fft_radix(N);
     if constexpr (Q < R) {
-        dif<N / R, S, INV>(v + Q * (N / R) * S);
-        dif_blocks<N, S, INV, Q + 1>(v);
+        dif<N / R, S, INV, FENCE>(v + Q * (N / R) * S);
+        dif_blocks<N, S, INV, Q + 1, FENCE>(v);
     }
 }
 

@@ -1186,6 +1186,30 @@ int fill_propagator(msl_handle* h) {
 
 }  // namespace
 
+// frame counts with a per-lane kernel: the 2-3-5-smooth numbers in [TDIR_MIN, TDIR_MAX]
+#define MSL_TDIR_LENGTHS(X) X(16) X(18) X(20) X(24) X(25) X(27) X(30) X(32) X(36) X(40) X(45) X(48) X(50) X(54) X(60) X(64) X(72) X(75) \
+    X(80) X(81) X(90) X(96) X(100) X(108) X(120) X(125) X(128)
+static bool time_direct_has(int T) { return T >= TDIR_MIN && T <= TDIR_MAX && fft_smooth(T); }
+template <int T>
+static int launch_time_direct_t(msl_handle* h, const TimeJob& j) {
+    static_assert(fft_smooth(T) && T >= TDIR_MIN && T <= TDIR_MAX, "no per-lane time kernel for this frame count");
+    const long long tiles = ((long long)(j.npix + 255) / 256) * j.n_images;
+    int per_cu = 1;                                  // 1 for the long lines (512 registers per lane), more for the short ones
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)time_direct_kernel<T>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    const int grid = (int)std::min<long long>(tiles, (long long)h->n_cus * per_cu);
+    hipLaunchKernelGGL((time_direct_kernel<T>), dim3(grid), dim3(256), 0, h->stream, j);
+    HIPCHK(h, hipGetLastError());
+    return mark_launch(h, K_OTHER);
+}
+static int launch_time_direct(msl_handle* h, const TimeJob& j) {
+    switch (j.T) {
+#define X(n) case n: return launch_time_direct_t<n>(h, j);
+        MSL_TDIR_LENGTHS(X)
+#undef X
+    }
+    return fail(h, MSL_ERR_UNSUPPORTED, "no per-lane time kernel for %d frames", j.T);
+}
+
 extern "C" {
 
 int msl_abi_version(void) { return MSL_ABI_VERSION; }
@@ -2031,11 +2055,15 @@ int msl_tacaw(msl_handle* h, const void* d_src, void* d_dst, int64_t batch, int3
     const bool fast_t = Rt && (npix % 16 == 0) && npix >= 32 && !dbg_env("MSL_TACAW_GENERIC");
     // any other frame count up to 512, and 256 frames of a grid whose pixel count the four-step kernel cannot tile: chirp-z on the
     // register FFTs (time_cz_kernel), 32-pixel tiles for T <= 128, else 16; any pixel count (ragged last tile, odd counts unvectorised)
-    const bool cz_t = !fast_t && c.fft_path == 0 && T <= 512 && !dbg_env("MSL_TACAW_GENERIC");
+    // smooth frame counts from 16 to 128 (100 = 4.5.5 ...): a lane per pixel, the whole time line in its registers (time_direct_kernel)
+    const bool direct_t = !fast_t && c.fft_path == 0 && time_direct_has(T) && (unsigned long long)((T + 1) / 2) * (unsigned long long)npix * 8ull < (1ull << 32)
+                          && !dbg_env("MSL_TACAW_GENERIC") && !dbg_env("MSL_TACAW_CHIRPZ");
+    const bool cz_t = !fast_t && !direct_t && c.fft_path == 0 && T <= 512 && !dbg_env("MSL_TACAW_GENERIC");
     int rc = MSL_OK;
     float2* tw4_t = nullptr;
     if (fast_t) {
         if ((rc = make_tw4(h, &tw4_t, Rt))) return rc;
+    } else if (direct_t) {
     } else if (cz_t) {
         if (h->opt_T != T) {
             h->opt_T = 0;
@@ -2081,6 +2109,11 @@ int msl_tacaw(msl_handle* h, const void* d_src, void* d_dst, int64_t batch, int3
             h->Rx = saved;
         }
         if (rc) { (void)hipFree(tw4_t); return rc; }
+    } else if (direct_t) {
+        TimeJob j{};
+        j.in = src; j.out = dst;
+        j.image_stride = (long long)T * npix; j.npix = (int)npix; j.n_images = (int)batch; j.T = T;
+        if ((rc = launch_time_direct(h, j))) return rc;
     } else if (cz_t) {
         TimeJob j{};
         j.in = src; j.out = dst; j.tw = h->opt.cz_tw; j.bf = h->opt.cz_bf; j.bw = h->opt.cz_bw;

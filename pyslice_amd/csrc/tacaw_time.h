@@ -17,6 +17,8 @@
 // the thermal part, the float32 transform then works on numbers of the size of the result instead of cancelling T large terms.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
+#include <utility>
 #include "fft_pow2.h"
 
 namespace msl {
@@ -197,6 +199,101 @@ __global__ void __launch_bounds__(COLS * R) time_cz_kernel(TimeJob job) {
         lds_barrier();
     }
     if (it > 0) store_tile(bufs + ((it - 1) & 1) * (COLS * CS), tile - step);
+}
+
+// ---- smooth frame counts up to 128 (2^a 3^b 5^c: 100 = 4.5.5, the reference notebook's run; 64, 96, 120, 128 ...): no convolution ----
+// One LANE holds a pixel's whole time line in registers and transforms it with the compile-time mixed-radix network of
+// fft_regs.h: ~24 VALU instructions per sample at T = 100 where chirp-z on a 16-lane group needs ~160, no LDS, no cross-lane
+// traffic.  A wave's load covers 64 neighbouring pixels of one frame (512-byte runs, its stores 256-byte runs), so nothing is
+// staged either; the transform leaves the spectrum in the network's digit-reversed order, which the store addresses absorb.
+// The next tile's samples fly in a second register set (the AGPR half of the unified file: one wave per SIMD, 512 registers per
+// lane) while the current tile is transformed, PF of them -- as many as fit beside 2 T data registers.
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+
+// Row loads of the per-lane kernel: raw buffer loads -- a descriptor in 4 SGPRs for the image, the row's byte offset in one more
+// (SALU arithmetic) and ONE 32-bit lane offset register for all rows.  Written as plain pointer arithmetic the same loads come
+// out with a 64-bit address pair per row, advanced by VALU adds: two registers per load in flight, which this kernel cannot
+// spare.  (LLVM intrinsic declared here; aux 2 = "nt", the non-temporal hint of ld_stream.)
+typedef int msl_i4v __attribute__((ext_vector_type(4)));
+__device__ msl_f2v msl_raw_buffer_load_f2(msl_i4v rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v2f32");
+__device__ __forceinline__ msl_i4v make_raw_rsrc(const void* base) {          // stride 0, no bound (offsets are 32-bit)
+    const unsigned long long a = (unsigned long long)base;
+    msl_i4v r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r.y = __builtin_amdgcn_readfirstlane((int)((a >> 32) & 0xffffu));
+    r.z = -1;
+    r.w = 0x00020000;
+    return r;
+}
+
+__host__ __device__ constexpr int tdir_prefetch(int T) { return T < 216 - T ? T : 216 - T; }
+constexpr int TDIR_MIN = 16, TDIR_MAX = 128;
+
+template <int T>
+__global__ void __launch_bounds__(256) time_direct_kernel(TimeJob job) {
+    constexpr int PF = tdir_prefetch(T), half = T / 2, KH = (T + 1) / 2;
+    const int tid = threadIdx.x;
+    const int tiles_per_image = (job.npix + 255) / 256;
+    const long long n_tiles = (long long)tiles_per_image * job.n_images;
+    const long long step = gridDim.x;
+    // lanes beyond the image's last pixel (ragged last tile) work on its last pixel too: same samples, same instructions, the
+    // same values stored to the same addresses -- no branch around the stores, which would also let the compiler sink the whole
+    // transform into it, past its scheduling fences.  Addresses: a uniform row
+    // pointer (SGPR pair, advanced by the SALU) plus the lane's 32-bit byte offset -- no 64-bit VALU address arithmetic.
+    auto column = [&](long long t, msl_i4v& rows, msl_i4v& rows_hi, float*& orow, unsigned& c, bool& live) {
+        const int p = __builtin_amdgcn_readfirstlane((int)(t / tiles_per_image));
+        const int c0 = __builtin_amdgcn_readfirstlane((int)(t % tiles_per_image) * 256);
+        live = c0 + tid < job.npix;
+        c = live ? (unsigned)(c0 + tid) : (unsigned)(job.npix - 1);
+        rows = make_raw_rsrc(job.in + (long long)p * job.image_stride);
+        rows_hi = make_raw_rsrc(job.in + (long long)p * job.image_stride + (long long)KH * job.npix);
+        orow = job.out + (long long)p * job.image_stride;
+    };
+    // rows below KH through the first descriptor, the others through the second: the 32-bit row offsets stay below 2^32 for
+    // every image the host sends here (KH npix 8 bytes < 4 GB)
+    auto load_row = [&](const msl_i4v& rows, const msl_i4v& rows_hi, int k, unsigned c) {
+        const msl_f2v t = k < KH ? msl_raw_buffer_load_f2(rows, (int)(8u * c), (int)(8u * (unsigned)k * (unsigned)job.npix), 2)
+                                 : msl_raw_buffer_load_f2(rows_hi, (int)(8u * c), (int)(8u * (unsigned)(k - KH) * (unsigned)job.npix), 2);
+        return make_float2(t.x, t.y);
+    };
+    long long tile = blockIdx.x;
+    float2 nx[PF];
+    msl_i4v rows, rows_hi; float* orow; unsigned c; bool live;
+    if (tile < n_tiles) {
+        column(tile, rows, rows_hi, orow, c, live);
+#pragma unroll
+        for (int k = 0; k < PF; ++k) nx[k] = load_row(rows, rows_hi, k, c);
+    }
+    for (; tile < n_tiles; tile += step) {
+        float2 v[T];
+#pragma unroll
+        for (int k = 0; k < PF; ++k) v[k] = nx[k];
+#pragma unroll
+        for (int k = PF; k < T; ++k) v[k] = load_row(rows, rows_hi, k, c);
+        float* const out_rows = orow;
+        const unsigned my_c = c;
+        if (tile + step < n_tiles) {
+            column(tile + step, rows, rows_hi, orow, c, live);
+#pragma unroll
+            for (int k = 0; k < PF; ++k) nx[k] = load_row(rows, rows_hi, k, c);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // any constant may be subtracted (only bin 0 sees it, and bin 0 is zeroed): the first sample keeps the numbers small
+        const float2 ref = v[0];
+#pragma unroll
+        for (int k = 0; k < T; ++k) v[k] = make_float2(v[k].x - ref.x, v[k].y - ref.y);
+        dif<T, 1, false, true>(v);
+        static_for<0, T>([&](auto ic) {
+            constexpr int I = decltype(ic)::value;
+            constexpr int F = dif_out_index(I, T);                 // frequency held by register I
+            constexpr int KS = (F + half) % T;                     // np.fft.fftshift
+            const float val = (F == 0) ? 0.f : fmaf(v[I].x, v[I].x, v[I].y * v[I].y);
+            __builtin_nontemporal_store(val, reinterpret_cast<float*>(reinterpret_cast<char*>(out_rows + (long long)KS * job.npix) + 4u * my_c));
+        });
+    }
 }
 
 }  // namespace msl

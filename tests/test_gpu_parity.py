@@ -1181,11 +1181,12 @@ def test_g10_probe_defocus(ps, golden):
     assert np.array_equal(npy(pr.array), before)
 
 
-@pytest.mark.parametrize("T", [2, 3, 33, 40, 100, 128, 129, 255, 256, 257, 500, 512])
+@pytest.mark.parametrize("T", [2, 3, 33, 40, 100, 101, 128, 129, 255, 256, 257, 500, 512])
 @pytest.mark.parametrize("shape", [(8, 8), (6, 8), (7, 9), (5, 14)])
 def test_tacaw_any_frame_count_on_the_register_kernel(ps, T, shape):
     """The reference transforms whatever frame count the trajectory has (tacaw_data.py:94-96; 100 frames in its notebook,
-    example.ipynb:578).  Every T <= 512 that is not 256 runs the chirp-z register kernel (time_cz_kernel: M = 256 for T <= 128
+    example.ipynb:578).  Every T <= 512 that is not 256 runs a register kernel -- the per-lane mixed-radix one for the smooth
+    counts from 16 to 128 (40, 100, 128 here; all of them in the next test), else chirp-z (time_cz_kernel: M = 256 for T <= 128
     on 32- or 16-pixel tiles, M = 1024 above): against the float64 transform of the same float32 frames, per pixel -- some
     pixels with a time mean 1e4 times their thermal part (the kernel subtracts the line's first sample instead of the mean) --
     and against the generic LDS kernel.  Pixel counts that are multiples of the tile, ragged (48, 70) and odd (63: the reference's
@@ -1217,6 +1218,44 @@ def test_tacaw_any_frame_count_on_the_register_kernel(ps, T, shape):
     eng.close()
     weak = big[:, 0] == 0                                     # the generic kernel transforms the raw lines: compare where no mean has to cancel
     assert rel_l2(got.transpose(0, 2, 3, 1)[weak], gen.transpose(0, 2, 3, 1)[weak]) < 1e-5
+
+
+TDIR_LENGTHS = [16, 18, 20, 24, 25, 27, 30, 32, 36, 40, 45, 48, 50, 54, 60, 64, 72, 75, 80, 81, 90, 96, 100, 108, 120, 125, 128]
+
+
+@pytest.mark.parametrize("shape", [(7, 9), (20, 30)])
+def test_tacaw_smooth_frame_counts_on_the_per_lane_kernel(ps, shape):
+    """time_direct_kernel: every 2-3-5-smooth frame count from 16 to 128 (radix-4 / 2 / 5 / 3 register network, one lane per pixel;
+    100 = 4.5.5 is the reference notebook's run, example.ipynb:578).  63 pixels (one ragged tile) and 600 (three tiles, the
+    last ragged; 3 probes = 9 tiles, more than one per workgroup is not reachable at this size, the bench covers it).  Against
+    the float64 transform per pixel -- strong-mean pixels included -- and, bin for bin, against the chirp-z kernel."""
+    from pyslice_amd import _native
+    nx, ny = shape
+    for T in TDIR_LENGTHS:
+        rng = np.random.default_rng(1000 + T)
+        eng = _native.Engine(nx, ny, 1, 0.1, 0.1, 0.5, 0.037, 1e-3, n_probes=3, n_frames=T)
+        big = (rng.standard_normal((3, 1, nx, ny)) + 1j * rng.standard_normal((3, 1, nx, ny))) * 1e2
+        big[:, :, ::2, ::3] = 0.0
+        small = (rng.standard_normal((3, T, nx, ny)) + 1j * rng.standard_normal((3, T, nx, ny))) * 1e-2
+        frames = (big + small).astype(np.complex64)
+        f64 = frames.astype(np.complex128)
+        want = np.abs(np.fft.fftshift(np.fft.fft(f64 - f64.mean(axis=1, keepdims=True), axis=1), axes=1)) ** 2
+        for t in range(T):
+            eng.upload_frame(t, frames[:, t])
+        eng.tacaw()
+        got = eng.intensity().astype(np.float64)
+        assert got[:, T // 2].max() == 0.0
+        err = np.linalg.norm(got - want, axis=1) / np.linalg.norm(want, axis=1)
+        assert err.max() < 2e-5, (T, err.max())
+        os.environ["MSL_DEBUG"] = os.environ["MSL_TACAW_CHIRPZ"] = "1"
+        try:
+            eng.tacaw()
+            cz = eng.intensity().astype(np.float64)
+        finally:
+            del os.environ["MSL_TACAW_CHIRPZ"], os.environ["MSL_DEBUG"]
+        eng.close()
+        assert not np.array_equal(cz, got), T                     # (two different kernels did run)
+        assert rel_l2(got, cz) < 2e-5, T
 
 
 def test_result_release_returns_the_device_memory(ps, orc):

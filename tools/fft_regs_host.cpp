@@ -82,6 +82,22 @@ int main() {
     rep("fft_regs<16> inv", check_regs<16, true>(), 1e-6);
     rep("fft_regs<32> inv", check_regs<32, true>(), 1e-6);
     rep("fft_regs<64> inv", check_regs<64, true>(), 1e-6);
+    // mixed radix (2, 3, 4, 5): the per-lane time transform of tacaw_time.h
+    rep("fft_regs<3> fwd", check_regs<3, false>(), 1e-6);
+    rep("fft_regs<5> fwd", check_regs<5, false>(), 1e-6);
+    rep("fft_regs<5> inv", check_regs<5, true>(), 1e-6);
+    rep("fft_regs<9> inv", check_regs<9, true>(), 1e-6);
+    rep("fft_regs<12> fwd", check_regs<12, false>(), 1e-6);
+    rep("fft_regs<15> fwd", check_regs<15, false>(), 1e-6);
+    rep("fft_regs<25> fwd", check_regs<25, false>(), 1e-6);
+    rep("fft_regs<40> fwd", check_regs<40, false>(), 1e-6);
+    rep("fft_regs<45> inv", check_regs<45, true>(), 1e-6);
+    rep("fft_regs<96> fwd", check_regs<96, false>(), 1e-6);
+    rep("fft_regs<100> fwd", check_regs<100, false>(), 1e-6);
+    rep("fft_regs<100> inv", check_regs<100, true>(), 1e-6);
+    rep("fft_regs<120> fwd", check_regs<120, false>(), 1e-6);
+    rep("fft_regs<125> fwd", check_regs<125, false>(), 1e-6);
+    rep("fft_regs<128> fwd", check_regs<128, false>(), 1e-6);
     rep("fourstep 32x32 fwd", check_fourstep<32, 32, false>(), 1e-6);
     rep("fourstep 32x32 inv", check_fourstep<32, 32, true>(), 1e-6);
     rep("fourstep 16x16 fwd", check_fourstep<16, 16, false>(), 1e-6);
