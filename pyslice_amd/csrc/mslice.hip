@@ -83,6 +83,8 @@ struct msl_handle {
                    float2* ptab = nullptr; float2* bf = nullptr; float2* bw = nullptr; } opx, opy;
     OpDir opt;                     // chirp-z tables of the TACAW time axis (cz_* only), made for opt_T frames (time_cz_kernel)
     int opt_T = 0;
+    float2* tsplit_tw = nullptr;   // W_T^n, n < T: cross-wave butterflies of time_split_kernel, made for tsplit_T frames
+    int tsplit_T = 0;
     float2* psiT = nullptr;
     float2* psi0T = nullptr;
     bool need_psi0T = false;
@@ -1201,6 +1203,46 @@ static int launch_time_direct_t(msl_handle* h, const TimeJob& j) {
     HIPCHK(h, hipGetLastError());
     return mark_launch(h, K_OTHER);
 }
+// smooth frame counts 129 .. 512 as L x TP with TP <= 128: L = 2 (two workgroups per CU), else 4, else 6 -- a multiple of the four
+// SIMDs' worth of waves or close -- else 3 or 5 (odd counts); two waves per SIMD from L = 5 on: TP <= 100
+#define MSL_TSPLIT_SHAPES(X) X(45, 3) X(72, 2) X(75, 2) X(80, 2) X(81, 2) X(90, 2) X(96, 2) X(100, 2) X(108, 2) X(75, 3) X(120, 2) X(81, 3) \
+    X(125, 2) X(128, 2) X(45, 6) X(72, 4) X(75, 4) X(80, 4) X(81, 4) X(90, 4) X(125, 3) X(96, 4) X(100, 4) X(81, 5) X(108, 4) X(75, 6) \
+    X(120, 4) X(81, 6) X(125, 4) X(128, 4)
+static int time_split_waves(int T) {           // L, or 0: no such kernel
+    if (T <= TDIR_MAX || T > 512 || !fft_smooth(T)) return 0;
+    for (int L : {2, 4, 6, 3, 5})
+        if (T % L == 0 && T / L <= TDIR_MAX && (L <= 4 || T / L <= 100)) return L;
+    return 0;
+}
+template <int TP, int L>
+static int launch_time_split_t(msl_handle* h, const TimeJob& j) {
+    const size_t lds = tsplit_lds_bytes(TP, L);
+    const long long tiles = ((long long)(j.npix + 63) / 64) * j.n_images;
+    (void)hipFuncSetAttribute((const void*)time_split_kernel<TP, L>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
+    int per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)time_split_kernel<TP, L>, 64 * L, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    const int grid = (int)std::min<long long>(tiles, (long long)h->n_cus * per_cu);
+    hipLaunchKernelGGL((time_split_kernel<TP, L>), dim3(grid), dim3(64 * L), lds, h->stream, j);
+    HIPCHK(h, hipGetLastError());
+    return mark_launch(h, K_OTHER);
+}
+static int launch_time_split(msl_handle* h, TimeJob j) {
+    const int T = j.T, L = time_split_waves(T);
+    if (h->tsplit_T != T) {
+        h->tsplit_T = 0;
+        std::vector<float2> w(T);
+        for (int n = 0; n < T; ++n) { const double a = -2.0 * M_PI * (double)n / (double)T; w[n] = make_float2((float)cos(a), (float)sin(a)); }
+        int rc = dalloc(h, &h->tsplit_tw, (size_t)T);
+        if (rc) return rc;
+        HIPCHK(h, hipMemcpy(h->tsplit_tw, w.data(), (size_t)T * sizeof(float2), hipMemcpyHostToDevice));
+        h->tsplit_T = T;
+    }
+    j.tw = h->tsplit_tw;
+#define X(tp, l) if (T == (tp) * (l) && L == (l)) return launch_time_split_t<tp, l>(h, j);
+    MSL_TSPLIT_SHAPES(X)
+#undef X
+    return fail(h, MSL_ERR_UNSUPPORTED, "no wave-split time kernel for %d frames", T);
+}
 static int launch_time_direct(msl_handle* h, const TimeJob& j) {
     switch (j.T) {
 #define X(n) case n: return launch_time_direct_t<n>(h, j);
@@ -1497,7 +1539,7 @@ int msl_destroy(msl_handle* h) {
                     h->scratch, h->psiT, h->psi0T, h->transT, h->bin_stage, h->st_acc, h->st_s1, h->st_s2, h->st_tw, h->st_bins, h->st_ref, h->opx.tw2, h->opx.ptab, h->opy.tw2, h->opy.ptab,
                     ((h->opx.two || h->opx.breg || h->opx.breg2 || h->opx.breg4 || h->opx.wave2k) ? h->opx.tw : nullptr), ((h->opy.two || h->opy.breg || h->opy.breg2 || h->opy.breg4 || h->opy.wave2k) ? h->opy.tw : nullptr),
                     h->opx.bf, h->opx.bw, h->opy.bf, h->opy.bw, h->opx.qf, h->opy.qf, h->opx.cz_tw, h->opx.cz_tw2, h->opx.cz_bf, h->opx.cz_bw,
-                    h->opy.cz_tw, h->opy.cz_tw2, h->opy.cz_bf, h->opy.cz_bw, h->opt.cz_tw, h->opt.cz_tw2, h->opt.cz_bf, h->opt.cz_bw, h->plan_x.chirp, h->plan_x.bfilt, h->plan_y.chirp, h->plan_y.bfilt, h->plan_t.chirp, h->plan_t.bfilt};
+                    h->opy.cz_tw, h->opy.cz_tw2, h->opy.cz_bf, h->opy.cz_bw, h->opt.cz_tw, h->opt.cz_tw2, h->opt.cz_bf, h->opt.cz_bw, h->tsplit_tw, h->plan_x.chirp, h->plan_x.bfilt, h->plan_y.chirp, h->plan_y.bfilt, h->plan_t.chirp, h->plan_t.bfilt};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -2052,18 +2094,21 @@ int msl_tacaw(msl_handle* h, const void* d_src, void* d_dst, int64_t batch, int3
     if (batch < 1 || npix < 1) return fail(h, MSL_ERR_INVALID, "msl_tacaw: bad batch/npix");
     if (npix > 0x7fffffffLL) return fail(h, MSL_ERR_UNSUPPORTED, "msl_tacaw: npix too large");
     const int Rt = (c.fft_path == 0) ? fast_radix(T) : 0;           // 256 or 1024 frames: four-step column kernel
-    const bool fast_t = Rt && (npix % 16 == 0) && npix >= 32 && !dbg_env("MSL_TACAW_GENERIC");
+    const bool fast_t = Rt && (npix % 16 == 0) && npix >= 32 && !dbg_env("MSL_TACAW_GENERIC") && !(dbg_env("MSL_TACAW_SPLIT") && time_split_waves(T));
     // any other frame count up to 512, and 256 frames of a grid whose pixel count the four-step kernel cannot tile: chirp-z on the
     // register FFTs (time_cz_kernel), 32-pixel tiles for T <= 128, else 16; any pixel count (ragged last tile, odd counts unvectorised)
     // smooth frame counts from 16 to 128 (100 = 4.5.5 ...): a lane per pixel, the whole time line in its registers (time_direct_kernel)
     const bool direct_t = !fast_t && c.fft_path == 0 && time_direct_has(T) && (unsigned long long)((T + 1) / 2) * (unsigned long long)npix * 8ull < (1ull << 32)
                           && !dbg_env("MSL_TACAW_GENERIC") && !dbg_env("MSL_TACAW_CHIRPZ");
-    const bool cz_t = !fast_t && !direct_t && c.fft_path == 0 && T <= 512 && !dbg_env("MSL_TACAW_GENERIC");
+    // smooth counts up to 512: the same network split over the 2 .. 6 waves of a workgroup (time_split_kernel)
+    const bool split_t = !fast_t && c.fft_path == 0 && time_split_waves(T) > 0 && (unsigned long long)65 * (unsigned long long)npix * 8ull < (1ull << 32)
+                         && !dbg_env("MSL_TACAW_GENERIC") && !dbg_env("MSL_TACAW_CHIRPZ");
+    const bool cz_t = !fast_t && !direct_t && !split_t && c.fft_path == 0 && T <= 512 && !dbg_env("MSL_TACAW_GENERIC");
     int rc = MSL_OK;
     float2* tw4_t = nullptr;
     if (fast_t) {
         if ((rc = make_tw4(h, &tw4_t, Rt))) return rc;
-    } else if (direct_t) {
+    } else if (direct_t || split_t) {
     } else if (cz_t) {
         if (h->opt_T != T) {
             h->opt_T = 0;
@@ -2114,6 +2159,11 @@ int msl_tacaw(msl_handle* h, const void* d_src, void* d_dst, int64_t batch, int3
         j.in = src; j.out = dst;
         j.image_stride = (long long)T * npix; j.npix = (int)npix; j.n_images = (int)batch; j.T = T;
         if ((rc = launch_time_direct(h, j))) return rc;
+    } else if (split_t) {
+        TimeJob j{};
+        j.in = src; j.out = dst;
+        j.image_stride = (long long)T * npix; j.npix = (int)npix; j.n_images = (int)batch; j.T = T;
+        if ((rc = launch_time_split(h, j))) return rc;
     } else if (cz_t) {
         TimeJob j{};
         j.in = src; j.out = dst; j.tw = h->opt.cz_tw; j.bf = h->opt.cz_bf; j.bw = h->opt.cz_bw;

@@ -296,4 +296,185 @@ __global__ void __launch_bounds__(256) time_direct_kernel(TimeJob job) {
     }
 }
 
+// ---- smooth frame counts above 128: the same transform split over the L waves of a workgroup, T = L x TP ----
+// Wave q holds the samples q TP + K of 64 pixels (lane = pixel: loads and stores keep their 512- / 256-byte runs) and the first
+// decimation-in-frequency level is a radix-L butterfly ACROSS the waves through the LDS:
+//     y_q[K] = ( sum_j x[j TP + K] W_L^{j q} ) W_T^{K q},      X[L f + q] = FFT_TP(y_q)[f]
+// -- coefficients and twiddles are wave-uniform (q is), read from a T-entry table of W_T^n -- after which every lane runs the
+// TP-point register network on its own.  The exchange goes in chunks of CH samples through two alternating buffers (L x CH x 64
+// complex each), one barrier per chunk: a wave passes barrier n + 1 only after it has read chunk n, so chunk n + 2 may overwrite
+// it.  L = 2, 3, 4 run one wave per SIMD with 512 registers per lane; L = 5, 6 two, with 256 (and TP <= 100).
+__host__ __device__ constexpr int tsplit_chunk(int L) { return L <= 4 ? 32 : 16; }
+__host__ __device__ constexpr int tsplit_prefetch(int TP, int L) {
+    const int room = ((L <= 4 ? 512 : 256) - 224 - 2 * TP) / 2;
+    return room < 0 ? 0 : (room > TP ? TP : room);
+}
+__host__ __device__ constexpr size_t tsplit_lds_bytes(int TP, int L) { return ((size_t)TP * L + (size_t)2 * L * tsplit_chunk(L) * 64) * 8; }
+
+template <int TP, int L>
+__global__ void __launch_bounds__(64 * L) time_split_kernel(TimeJob job) {
+    constexpr int T = TP * L, half = T / 2, KH = (TP + 1) / 2, CH = tsplit_chunk(L);
+    // Prefetch of the next tile: PF rows before the transform starts -- what fits beside the 2 TP data registers -- and the others
+    // block by block: the register network's first level leaves R1 independent blocks of M1 samples; as soon as a block is
+    // transformed and stored its registers take the next LATE rows.  All TP rows of the next tile are in flight or landed when the
+    // tile ends, and the loads are spread over the whole of it.
+    // (Rows that still do not fit -- two waves per SIMD leave few spare registers -- are fetched at the top of the tile.)
+    constexpr int R1 = fft_radix(TP), M1 = TP / R1;
+    constexpr int PF = tsplit_prefetch(TP, L);
+    constexpr int LATE_ALL = (R1 - 1) * M1 < TP - PF ? (R1 - 1) * M1 : TP - PF;      // rows fetched behind finished blocks
+    constexpr int NPRE = PF + LATE_ALL;                                                // rows of the next tile in flight at its start
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float2* twl = reinterpret_cast<float2*>(smem_raw);             // W_T^n, n < T
+    float2* xbuf = twl + T;                                        // two exchange buffers [j][k][lane]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < T; i += 64 * L) twl[i] = job.tw[i];
+    __syncthreads();
+    float cr[L], ci[L];                                            // W_L^{j q} = W_T^{(j q mod L) TP}
+#pragma unroll
+    for (int j = 1; j < L; ++j) {
+        const float2 w = twl[((j * q) % L) * TP];
+        cr[j] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(w.x)));
+        ci[j] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(w.y)));
+    }
+    const int tiles_per_image = (job.npix + 63) / 64;
+    const long long n_tiles = (long long)tiles_per_image * job.n_images;
+    const long long step = gridDim.x;
+    // (ragged last tile: the surplus lanes repeat the image's last pixel, as in time_direct_kernel)
+    auto column = [&](long long t, msl_i4v& rows0, msl_i4v& rows, msl_i4v& rows_hi, float*& orow, unsigned& c) {
+        const int p = __builtin_amdgcn_readfirstlane((int)(t / tiles_per_image));
+        const int c0 = __builtin_amdgcn_readfirstlane((int)(t % tiles_per_image) * 64);
+        c = c0 + lane < job.npix ? (unsigned)(c0 + lane) : (unsigned)(job.npix - 1);
+        const float2* img = job.in + (long long)p * job.image_stride;
+        rows0 = make_raw_rsrc(img);
+        rows = make_raw_rsrc(img + (long long)(q * TP) * job.npix);
+        rows_hi = make_raw_rsrc(img + (long long)(q * TP + KH) * job.npix);
+        orow = job.out + (long long)p * job.image_stride;
+    };
+    // (row offsets, LDS addresses beyond the 64 KB an instruction's offset field reaches: all the same for every tile, and the
+    // compiler would keep hundreds of them in registers across the loop -- and spill them; `hide` makes a value look new)
+    auto hide_s = [](int x) { asm volatile("" : "+s"(x)); return x; };
+    auto hide_v = [](int x) { asm volatile("" : "+v"(x)); return x; };
+    auto load_row = [&](const msl_i4v& rows, const msl_i4v& rows_hi, int k, unsigned c, int npix_now) {
+        const msl_f2v t = k < KH ? msl_raw_buffer_load_f2(rows, (int)(8u * c), (int)(8u * (unsigned)k * (unsigned)npix_now), 2)
+                                 : msl_raw_buffer_load_f2(rows_hi, (int)(8u * c), (int)(8u * (unsigned)(k - KH) * (unsigned)npix_now), 2);
+        return make_float2(t.x, t.y);
+    };
+    long long tile = blockIdx.x;
+    float2 nx[NPRE > 0 ? NPRE : 1];
+    float2 nref = make_float2(0.f, 0.f);
+    msl_i4v rows0, rows, rows_hi; float* orow; unsigned c;
+    if (tile < n_tiles) {
+        column(tile, rows0, rows, rows_hi, orow, c);
+        { const msl_f2v t = msl_raw_buffer_load_f2(rows0, (int)(8u * c), 0, 0); nref = make_float2(t.x, t.y); }
+#pragma unroll
+        for (int k = 0; k < NPRE; ++k) nx[k] = load_row(rows, rows_hi, k, c, job.npix);
+    }
+    int par = 0;
+    for (; tile < n_tiles; tile += step) {
+        float2 v[TP];
+        // the line's first sample, subtracted from all of it (time_cz_kernel's note): every wave fetches it, wave 0's fetch pays
+        const float2 ref = nref;
+#pragma unroll
+        for (int k = 0; k < NPRE; ++k) v[k] = nx[k];
+        int npix_now = hide_s(job.npix);
+#pragma unroll
+        for (int k = NPRE; k < TP; ++k) v[k] = load_row(rows, rows_hi, k, c, npix_now);
+        float* const out_rows = orow;
+        const unsigned my_c = c;
+        // (a workgroup's last tile prefetches itself again: unconditional loads -- a branch would keep the old values alive as
+        // the other arm of the merge, a second copy of the line)
+        column(tile + step < n_tiles ? tile + step : tile, rows0, rows, rows_hi, orow, c);
+        { const msl_f2v t = msl_raw_buffer_load_f2(rows0, (int)(8u * c), 0, 0); nref = make_float2(t.x, t.y); }
+#pragma unroll
+        for (int k = 0; k < PF; ++k) nx[k] = load_row(rows, rows_hi, k, c, npix_now);
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, (TP + CH - 1) / CH>([&](auto cc) {
+            constexpr int cb = decltype(cc)::value * CH;
+            float2* buf = xbuf + par * (L * CH * 64) + hide_v(lane);
+            par ^= 1;
+#pragma unroll
+            for (int k = cb; k < cb + CH; ++k)
+                if (k < TP) buf[(q * CH + (k - cb)) * 64] = make_float2(v[k].x - ref.x, v[k].y - ref.y);
+            lds_barrier();
+            // the butterfly of my wave, four samples at a time, the next four already on their way from the LDS (one wave per
+            // SIMD: nobody else would cover the round trip).  L = 2 and 4 use the trivial coefficients' structure:
+            // a0 + s a1, resp. (a0 + s a2) + W_4^q (a1 + s a3) with s = W_L^{(L/2) q} = +-1.
+            constexpr int G = L <= 4 ? 4 : 2, KEND = cb + CH < TP ? cb + CH : TP;
+            float2 A[G][L], W[G];
+            auto fetch = [&](int k0, float2 (&a)[G][L], float2 (&w)[G]) {
+#pragma unroll
+                for (int g = 0; g < G; ++g)
+                    if (k0 + g < KEND) {
+#pragma unroll
+                        for (int j = 0; j < L; ++j) a[g][j] = buf[(j * CH + (k0 + g - cb)) * 64];
+                        w[g] = twl[(k0 + g) * q];
+                    }
+            };
+            fetch(cb, A, W);
+#pragma unroll
+            for (int k0 = cb; k0 < KEND; k0 += G) {
+                float2 B[G][L], Wn[G];
+                if (k0 + G < KEND) fetch(k0 + G, B, Wn);
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    if (k0 + g < KEND) {
+                        float2 acc;
+                        if constexpr (L == 2) {
+                            acc = make_float2(fmaf(A[g][1].x, cr[1], A[g][0].x), fmaf(A[g][1].y, cr[1], A[g][0].y));
+                        } else if constexpr (L == 4) {
+                            const float2 t = make_float2(fmaf(A[g][2].x, cr[2], A[g][0].x), fmaf(A[g][2].y, cr[2], A[g][0].y));
+                            const float2 u = make_float2(fmaf(A[g][3].x, cr[2], A[g][1].x), fmaf(A[g][3].y, cr[2], A[g][1].y));
+                            acc.x = fmaf(u.x, cr[1], fmaf(-u.y, ci[1], t.x));
+                            acc.y = fmaf(u.x, ci[1], fmaf(u.y, cr[1], t.y));
+                        } else {
+                            acc = A[g][0];
+#pragma unroll
+                            for (int j = 1; j < L; ++j) {
+                                acc.x = fmaf(A[g][j].x, cr[j], fmaf(-A[g][j].y, ci[j], acc.x));
+                                acc.y = fmaf(A[g][j].x, ci[j], fmaf(A[g][j].y, cr[j], acc.y));
+                            }
+                        }
+                        v[k0 + g] = cmulf(acc, W[g]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    W[g] = Wn[g];
+#pragma unroll
+                    for (int j = 0; j < L; ++j) A[g][j] = B[g][j];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        if constexpr (R1 == 4) dif4_level<TP, 1, false, 0, true>(v);
+        else if constexpr (R1 == 2) dif2_level<TP, 1, false, 0, true>(v);
+        else if constexpr (R1 == 5) dif5_level<TP, 1, false, 0, true>(v);
+        else dif3_level<TP, 1, false, 0, true>(v);
+        // (the row offsets below are the same for every tile: hidden from the compiler, which would otherwise keep all TP of them,
+        // 64 bits each, in scalar registers across the loop and spill those through the vector file)
+        static_for<0, R1>([&](auto bc) {
+            constexpr int B = decltype(bc)::value;
+            dif<M1, 1, false, true>(v + B * M1);
+            npix_now = hide_s(npix_now);
+            static_for<B * M1, (B + 1) * M1>([&](auto ic) {
+                constexpr int I = decltype(ic)::value;
+                constexpr int F = dif_out_index(I, TP);            // sub-frequency held by register I: bin L F + q
+                int row = L * F + q + half;                        // np.fft.fftshift (uniform)
+                if (row >= T) row -= T;
+                float val = fmaf(v[I].x, v[I].x, v[I].y * v[I].y);
+                if (F == 0 && q == 0) val = 0.f;
+                __builtin_nontemporal_store(val, reinterpret_cast<float*>(reinterpret_cast<char*>(out_rows + (long long)row * npix_now) + 4u * my_c));
+            });
+            if constexpr (B < R1 - 1 && PF + B * M1 < NPRE) {
+                constexpr int K0 = PF + B * M1, K1 = K0 + M1 < NPRE ? K0 + M1 : NPRE;
+#pragma unroll
+                for (int k = K0; k < K1; ++k) nx[k] = load_row(rows, rows_hi, k, c, npix_now);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    }
+}
+
 }  // namespace msl

@@ -1221,17 +1221,21 @@ def test_tacaw_any_frame_count_on_the_register_kernel(ps, T, shape):
 
 
 TDIR_LENGTHS = [16, 18, 20, 24, 25, 27, 30, 32, 36, 40, 45, 48, 50, 54, 60, 64, 72, 75, 80, 81, 90, 96, 100, 108, 120, 125, 128]
+TSPLIT_LENGTHS = [135, 144, 150, 160, 162, 180, 192, 200, 216, 225, 240, 243, 250, 256, 270, 288, 300, 320, 324, 360, 375, 384, 400, 405,
+                  432, 450, 480, 486, 500, 512]
 
 
 @pytest.mark.parametrize("shape", [(7, 9), (20, 30)])
 def test_tacaw_smooth_frame_counts_on_the_per_lane_kernel(ps, shape):
     """time_direct_kernel: every 2-3-5-smooth frame count from 16 to 128 (radix-4 / 2 / 5 / 3 register network, one lane per pixel;
-    100 = 4.5.5 is the reference notebook's run, example.ipynb:578).  63 pixels (one ragged tile) and 600 (three tiles, the
-    last ragged; 3 probes = 9 tiles, more than one per workgroup is not reachable at this size, the bench covers it).  Against
-    the float64 transform per pixel -- strong-mean pixels included -- and, bin for bin, against the chirp-z kernel."""
+    100 = 4.5.5 is the reference notebook's run, example.ipynb:578), and time_split_kernel: every smooth count from 129 to 512 as
+    L x TP over the L = 2 .. 6 waves of a workgroup (500 = 4 x 125, 486 = 6 x 81 ...; 256 through the debug switch, its default
+    being the four-step kernel).  63 pixels (one ragged tile) and 600 (ragged last tile; with 3 probes more tiles than one per
+    workgroup only in the split kernel: 30, the bench covers the rest).  Against the float64 transform per pixel -- strong-mean
+    pixels included -- and, bin for bin, against the chirp-z kernel."""
     from pyslice_amd import _native
     nx, ny = shape
-    for T in TDIR_LENGTHS:
+    for T in TDIR_LENGTHS + TSPLIT_LENGTHS:
         rng = np.random.default_rng(1000 + T)
         eng = _native.Engine(nx, ny, 1, 0.1, 0.1, 0.5, 0.037, 1e-3, n_probes=3, n_frames=T)
         big = (rng.standard_normal((3, 1, nx, ny)) + 1j * rng.standard_normal((3, 1, nx, ny))) * 1e2
@@ -1242,7 +1246,13 @@ def test_tacaw_smooth_frame_counts_on_the_per_lane_kernel(ps, shape):
         want = np.abs(np.fft.fftshift(np.fft.fft(f64 - f64.mean(axis=1, keepdims=True), axis=1), axes=1)) ** 2
         for t in range(T):
             eng.upload_frame(t, frames[:, t])
-        eng.tacaw()
+        if T == 256:
+            os.environ["MSL_DEBUG"] = os.environ["MSL_TACAW_SPLIT"] = "1"
+        try:
+            eng.tacaw()
+        finally:
+            if T == 256:
+                del os.environ["MSL_TACAW_SPLIT"], os.environ["MSL_DEBUG"]
         got = eng.intensity().astype(np.float64)
         assert got[:, T // 2].max() == 0.0
         err = np.linalg.norm(got - want, axis=1) / np.linalg.norm(want, axis=1)

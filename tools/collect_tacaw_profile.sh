@@ -34,7 +34,7 @@ for part in (med("sq1"), med("sq2"), med("fetch"), med("write")):
     for k, v in part.items(): sq.setdefault(k, {}).update(v)
 out = {"command": open(os.path.join(O, "command.txt")).read().strip(), "line": [l.strip() for l in open(os.path.join(O, "stats.txt")) if l.startswith("T=")], "kernels": {}}
 for k, s in sq.items():
-    if k in stats and ("time_cz" in k or "col_pass" in k or "line_fft" in k):
+    if k in stats and ("time_" in k or "col_pass" in k or "line_fft" in k):
         e = dict(stats[k]); e["counters"] = s
         w = s.get("SQ_WAVE_CYCLES", 0)
         if w:
