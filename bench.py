@@ -386,7 +386,7 @@ def run(a):
         eng.tacaw()
         ms = eng.counters()["ms_tacaw"] - before
         tacaw = {"ms": round(ms, 3), "GBps": round(12.0 * P * tacaw_T * npix / (ms * 1e-3) / 1e9, 1), "frames": tacaw_T,
-                 "probes": P, "kernel": "four-step time FFT" if tacaw_T in (256, 1024) else ("chirp-z on the register FFTs" if tacaw_T <= 512 else "generic LDS kernel"),
+                 "probes": P, "kernel": _tacaw_kernel_name(tacaw_T, npix),
                  "algorithmic_bytes": 12.0 * P * tacaw_T * npix, "frac_of_hbm_peak": round(12.0 * P * tacaw_T * npix / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                  "note": f"{n_local} computed frames, remaining slots filled with copies (timing is data-independent)"}
 
@@ -544,6 +544,22 @@ def run(a):
         except Exception:
             pass
         t.cancel()
+
+
+def _tacaw_kernel_name(T, npix):
+    """the kernel msl_tacaw picks for T frames (mslice.hip: msl_tacaw)"""
+    n = T
+    for p in (2, 3, 5):
+        while n % p == 0:
+            n //= p
+    smooth = n == 1
+    if T == 1024 and npix % 16 == 0 and npix >= 32:
+        return "four-step time FFT (32 x 32 lanes x registers)"
+    if smooth and 16 <= T <= 128:
+        return "per-lane mixed-radix register FFT (time_direct_kernel)"
+    if smooth and 128 < T <= 512:
+        return "mixed-radix register FFT split over the waves of a workgroup (time_split_kernel)"
+    return "chirp-z on the register FFTs" if T <= 512 else "generic LDS kernel"
 
 
 def main():

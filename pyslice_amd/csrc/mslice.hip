@@ -560,20 +560,6 @@ int launch_col_herm(msl_handle* h, const ColJob& job, int kind) {
     return h->Rx == 32 ? launch_col_herm_r<32>(h, job, kind) : launch_col_herm_r<16>(h, job, kind);
 }
 
-// TACAW time transform of 256 frames on 32-column tiles (COL_FWD | COL_INTENSITY only)
-template <int COLS>
-int launch_col_time(msl_handle* h, const ColJob& job, int kind) {
-    constexpr int R = 16, N = R * R, CS = R * (R + 1) + 1;
-    const size_t lds = ((size_t)2 * N + (size_t)COLS * CS) * 8;
-    const long long tiles = (long long)(job.ny / COLS) * job.n_images;
-    const int per_cu = std::max(1, (int)((size_t)h->lds_limit / lds));
-    const int grid = (int)std::min<long long>(tiles, (long long)h->n_cus * std::min(per_cu, 2));
-    (void)hipFuncSetAttribute((const void*)col_pass_kernel<16, COLS>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
-    hipLaunchKernelGGL((col_pass_kernel<16, COLS>), dim3(grid), dim3(COLS * R), lds, h->stream, job);
-    HIPCHK(h, hipGetLastError());
-    return mark_launch(h, kind);
-}
-
 int launch_row_fast(msl_handle* h, const RowJob& job, int kind) {
     return h->Ry == 32 ? launch_row_fast_r<32>(h, job, kind) : launch_row_fast_r<16>(h, job, kind);
 }
@@ -2093,8 +2079,10 @@ int msl_tacaw(msl_handle* h, const void* d_src, void* d_dst, int64_t batch, int3
     if (T < 2) return fail(h, MSL_ERR_INVALID, "msl_tacaw: needs at least 2 frames (got %d)", T);
     if (batch < 1 || npix < 1) return fail(h, MSL_ERR_INVALID, "msl_tacaw: bad batch/npix");
     if (npix > 0x7fffffffLL) return fail(h, MSL_ERR_UNSUPPORTED, "msl_tacaw: npix too large");
-    const int Rt = (c.fft_path == 0) ? fast_radix(T) : 0;           // 256 or 1024 frames: four-step column kernel
-    const bool fast_t = Rt && (npix % 16 == 0) && npix >= 32 && !dbg_env("MSL_TACAW_GENERIC") && !(dbg_env("MSL_TACAW_SPLIT") && time_split_waves(T));
+    // 1024 frames: four-step column kernel (256 frames ran it too until the wave-split kernel overtook it: 39.7 vs 40.2 ms for
+    // 64 probes x 1024^2, 40.7 vs 44.7 ms for 16 x 2048^2)
+    const int Rt = (c.fft_path == 0 && T == 1024) ? fast_radix(T) : 0;
+    const bool fast_t = Rt && (npix % 16 == 0) && npix >= 32 && !dbg_env("MSL_TACAW_GENERIC");
     // any other frame count up to 512, and 256 frames of a grid whose pixel count the four-step kernel cannot tile: chirp-z on the
     // register FFTs (time_cz_kernel), 32-pixel tiles for T <= 128, else 16; any pixel count (ragged last tile, odd counts unvectorised)
     // smooth frame counts from 16 to 128 (100 = 4.5.5 ...): a lane per pixel, the whole time line in its registers (time_direct_kernel)
@@ -2145,14 +2133,10 @@ int msl_tacaw(msl_handle* h, const void* d_src, void* d_dst, int64_t batch, int3
         j.in_image_stride = j.out_image_stride = (long long)T * npix;
         j.in_pitch = j.out_pitch = (int)npix; j.ny = (int)npix; j.n_images = (int)batch;
         j.flags = COL_FWD | COL_INTENSITY; j.scale = 1.f;
-        if (Rt == 16 && npix % 32 == 0 && !dbg_env("MSL_TACAW_COLS16")) {
-            rc = launch_col_time<32>(h, j, K_OTHER);          // 64-pixel tiles (one workgroup per CU): 47.9 vs 41.7 ms
-        } else {
-            const int saved = h->Rx;
-            h->Rx = Rt;
-            rc = launch_col_fast(h, j, K_OTHER);
-            h->Rx = saved;
-        }
+        const int saved = h->Rx;
+        h->Rx = Rt;
+        rc = launch_col_fast(h, j, K_OTHER);
+        h->Rx = saved;
         if (rc) { (void)hipFree(tw4_t); return rc; }
     } else if (direct_t) {
         TimeJob j{};

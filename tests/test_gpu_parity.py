@@ -539,7 +539,7 @@ def test_config_c3_64_probes_1024_200_slices_vs_oracle(ps, orc):
 
 
 def test_tacaw_1024_grid_k_window_256_frames_vs_oracle(ps, orc):
-    """TACAW on C3's grid and frame count: 1024^2, T = 256 frames (four-step time-FFT kernel), a 64 x 64 k-window so that
+    """TACAW on C3's grid and frame count: 1024^2, T = 256 frames (wave-split register kernel), a 64 x 64 k-window so that
     the resident result stays small; against the oracle's time FFT of the oracle's own exit-wave spectra, cropped."""
     from pyslice_amd.synthetic import synthetic_trajectory
     n, nz, T = 1024, 2, 256
@@ -1185,9 +1185,9 @@ def test_g10_probe_defocus(ps, golden):
 @pytest.mark.parametrize("shape", [(8, 8), (6, 8), (7, 9), (5, 14)])
 def test_tacaw_any_frame_count_on_the_register_kernel(ps, T, shape):
     """The reference transforms whatever frame count the trajectory has (tacaw_data.py:94-96; 100 frames in its notebook,
-    example.ipynb:578).  Every T <= 512 that is not 256 runs a register kernel -- the per-lane mixed-radix one for the smooth
-    counts from 16 to 128 (40, 100, 128 here; all of them in the next test), else chirp-z (time_cz_kernel: M = 256 for T <= 128
-    on 32- or 16-pixel tiles, M = 1024 above): against the float64 transform of the same float32 frames, per pixel -- some
+    example.ipynb:578).  Every T <= 512 runs a register kernel -- the mixed-radix ones for the smooth counts (per lane from 16
+    to 128: 40, 100, 128 here; split over waves above: 256, 500, 512; all of them in the next test), else chirp-z
+    (time_cz_kernel: M = 256 for T <= 128 on 32- or 16-pixel tiles, M = 1024 above: 2, 3, 33, 101, 129, 255, 257): against the float64 transform of the same float32 frames, per pixel -- some
     pixels with a time mean 1e4 times their thermal part (the kernel subtracts the line's first sample instead of the mean) --
     and against the generic LDS kernel.  Pixel counts that are multiples of the tile, ragged (48, 70) and odd (63: the reference's
     own 501 x 491 test grid has an odd pixel count)."""
@@ -1220,6 +1220,32 @@ def test_tacaw_any_frame_count_on_the_register_kernel(ps, T, shape):
     assert rel_l2(got.transpose(0, 2, 3, 1)[weak], gen.transpose(0, 2, 3, 1)[weak]) < 1e-5
 
 
+@pytest.mark.parametrize("shape", [(8, 8), (6, 8)])
+def test_tacaw_1024_frames_on_the_four_step_kernel(ps, shape):
+    """T = 1024 (BASELINE C5's frame count) when the whole (P, T, nx, ny) array is resident: the 32 x 32 four-step column kernel
+    (col_pass_kernel, COL_INTENSITY; pixel counts that are multiples of 16), per pixel against the float64 transform, strong-mean
+    pixels included."""
+    from pyslice_amd import _native
+    T = 1024
+    rng = np.random.default_rng(7)
+    nx, ny = shape
+    eng = _native.Engine(nx, ny, 1, 0.1, 0.1, 0.5, 0.037, 1e-3, n_probes=2, n_frames=T)
+    big = (rng.standard_normal((2, 1, nx, ny)) + 1j * rng.standard_normal((2, 1, nx, ny))) * 1e2
+    big[:, :, ::2, ::3] = 0.0
+    small = (rng.standard_normal((2, T, nx, ny)) + 1j * rng.standard_normal((2, T, nx, ny))) * 1e-2
+    frames = (big + small).astype(np.complex64)
+    f64 = frames.astype(np.complex128)
+    want = np.abs(np.fft.fftshift(np.fft.fft(f64 - f64.mean(axis=1, keepdims=True), axis=1), axes=1)) ** 2
+    for t in range(T):
+        eng.upload_frame(t, frames[:, t])
+    eng.tacaw()
+    got = eng.intensity().astype(np.float64)
+    eng.close()
+    assert got[:, T // 2].max() == 0.0
+    err = np.linalg.norm(got - want, axis=1) / np.linalg.norm(want, axis=1)
+    assert err.max() < 5e-5, err.max()
+
+
 TDIR_LENGTHS = [16, 18, 20, 24, 25, 27, 30, 32, 36, 40, 45, 48, 50, 54, 60, 64, 72, 75, 80, 81, 90, 96, 100, 108, 120, 125, 128]
 TSPLIT_LENGTHS = [135, 144, 150, 160, 162, 180, 192, 200, 216, 225, 240, 243, 250, 256, 270, 288, 300, 320, 324, 360, 375, 384, 400, 405,
                   432, 450, 480, 486, 500, 512]
@@ -1229,8 +1255,7 @@ TSPLIT_LENGTHS = [135, 144, 150, 160, 162, 180, 192, 200, 216, 225, 240, 243, 25
 def test_tacaw_smooth_frame_counts_on_the_per_lane_kernel(ps, shape):
     """time_direct_kernel: every 2-3-5-smooth frame count from 16 to 128 (radix-4 / 2 / 5 / 3 register network, one lane per pixel;
     100 = 4.5.5 is the reference notebook's run, example.ipynb:578), and time_split_kernel: every smooth count from 129 to 512 as
-    L x TP over the L = 2 .. 6 waves of a workgroup (500 = 4 x 125, 486 = 6 x 81 ...; 256 through the debug switch, its default
-    being the four-step kernel).  63 pixels (one ragged tile) and 600 (ragged last tile; with 3 probes more tiles than one per
+    L x TP over the L = 2 .. 6 waves of a workgroup (256 = 2 x 128, 500 = 4 x 125, 486 = 6 x 81 ...).  63 pixels (one ragged tile) and 600 (ragged last tile; with 3 probes more tiles than one per
     workgroup only in the split kernel: 30, the bench covers the rest).  Against the float64 transform per pixel -- strong-mean
     pixels included -- and, bin for bin, against the chirp-z kernel."""
     from pyslice_amd import _native
@@ -1246,13 +1271,7 @@ def test_tacaw_smooth_frame_counts_on_the_per_lane_kernel(ps, shape):
         want = np.abs(np.fft.fftshift(np.fft.fft(f64 - f64.mean(axis=1, keepdims=True), axis=1), axes=1)) ** 2
         for t in range(T):
             eng.upload_frame(t, frames[:, t])
-        if T == 256:
-            os.environ["MSL_DEBUG"] = os.environ["MSL_TACAW_SPLIT"] = "1"
-        try:
-            eng.tacaw()
-        finally:
-            if T == 256:
-                del os.environ["MSL_TACAW_SPLIT"], os.environ["MSL_DEBUG"]
+        eng.tacaw()
         got = eng.intensity().astype(np.float64)
         assert got[:, T // 2].max() == 0.0
         err = np.linalg.norm(got - want, axis=1) / np.linalg.norm(want, axis=1)
@@ -1298,9 +1317,9 @@ def test_result_release_returns_the_device_memory(ps, orc):
     assert free0 - torch.cuda.mem_get_info(0)[0] < 512 << 20        # (code objects, the staged copy `wf` still holds, allocator slack)
 
 
-def test_tacaw_fourstep_time_axis_256_frames(ps, orc):
-    """T = 256 frames (BASELINE C3's frame count) takes the four-step time-FFT kernel (pixels as columns of a
-    (T, npix) image, DC zeroed, fftshifted |.|^2 epilogue); compare with the oracle and with the generic kernel."""
+def test_tacaw_time_axis_256_frames(ps, orc):
+    """T = 256 frames (BASELINE C3's frame count) through the calculator: the wave-split register kernel (2 x 128; the
+    four-step column kernel until round 3), DC zeroed, fftshifted |.|^2; compare with the oracle and with the generic kernel."""
     from pyslice_amd.synthetic import synthetic_trajectory
     tr = synthetic_trajectory(32, 2, 256, density=0.3, seed=13)
     pp = [(1.6, 1.6), (0.5, 2.5)]
