@@ -1788,9 +1788,13 @@ struct IfftTBJob {
     float scale, sigma_over_pi;
 };
 
-template <int R>
+// PAIR (second pass of the potential build: job.herm and job.potential set): the lines are spectra of REAL lines, so two of them
+// ride one complex transform, Z = X_a + i X_b -> V_a + i V_b -- half the transforms of this pass.  A group takes the lines
+// g and g + 16 of a 32-line block, so that each of the two store rounds still covers 16 neighbouring lines (128-byte runs).
+template <int R, bool PAIR = false>
 __global__ void __launch_bounds__(16 * R, (R == 32) ? 2 : 4) ifftTB_kernel(IfftTBJob job) {
     constexpr int M = R * R, H = R / 2, NH = M / 2, LINES = 16, NT = LINES * R, TCH = 8;
+    constexpr int BL = PAIR ? 2 * LINES : LINES;              // lines per work item
     constexpr int CS = R * (R + 1) + 2;
     constexpr int POS_PER_IT = NT / LINES, NIT = NH / POS_PER_IT;       // one thread per (position, line) of a tile row
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -1811,30 +1815,53 @@ __global__ void __launch_bounds__(16 * R, (R == 32) ? 2 : 4) ifftTB_kernel(IfftT
     const unsigned wscr_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(tile + (grp - grp % (64 / R)) * CS));
     const float2* fa = bf + ln;
     const float2* fb = bf - ln;
-    const int lblocks = (job.n_lines + LINES - 1) / LINES;
+    const int lblocks = (job.n_lines + BL - 1) / BL;
     const int n_items = lblocks * job.n_images;
     // the next item's line is loaded into registers while the current one is transformed
-    float2 vn[H];
+    float2 vn[PAIR ? R : H];
     auto load_line = [&](int it) {
         const int img = it / lblocks, lb = it - img * lblocks;
-        const int L = min(lb * LINES + grp, job.n_lines - 1);                 // surplus lines of the last block repeat the last one
+        const int L = min(lb * BL + grp, job.n_lines - 1);                    // surplus lines of the last block repeat the last one
         const float2* src = job.in + (long long)img * job.in_is + (long long)L * job.in_pitch;
         const int hx = job.herm ? N / 2 : N;
+        if constexpr (PAIR) {
+            const int Lb = min(lb * BL + LINES + grp, job.n_lines - 1);
+            const float2* srcb = job.in + (long long)img * job.in_is + (long long)Lb * job.in_pitch;
 #pragma unroll
-        for (int j = 0; j < H; ++j) {
-            const int e = j * R + ln;
-            float2 x = (e < N) ? src[e <= hx ? e : N - e] : make_float2(0.f, 0.f);
-            if (e > hx) x.y = -x.y;
-            vn[j] = x;
+            for (int j = 0; j < H; ++j) {
+                const int e = j * R + ln, m = e <= hx ? e : N - e;
+                vn[j] = (e < N) ? src[m] : make_float2(0.f, 0.f);
+                vn[H + j] = (e < N) ? srcb[m] : make_float2(0.f, 0.f);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < H; ++j) {
+                const int e = j * R + ln;
+                float2 x = (e < N) ? src[e <= hx ? e : N - e] : make_float2(0.f, 0.f);
+                if (e > hx) x.y = -x.y;
+                vn[j] = x;
+            }
         }
     };
     if ((int)blockIdx.x < n_items) load_line(blockIdx.x);
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
         const int img = item / lblocks, lb = item - img * lblocks;
-        const int L = min(lb * LINES + grp, job.n_lines - 1);
+        const int L = min(lb * BL + grp, job.n_lines - 1);
         float2 v[R];
+        if constexpr (PAIR) {
+            const int hx = N / 2;
 #pragma unroll
-        for (int j = 0; j < H; ++j) v[j] = vn[j];
+            for (int j = 0; j < H; ++j) {                      // a + i b below the mirror point, conj(a) + i conj(b) above it
+                float2 a = vn[j], b = vn[H + j];
+                // the Nyquist element of an even length is its own mirror image: only its real part belongs to a real line (the
+                // unpaired kernel drops the rest with the imaginary part of its output; here it would land in the partner line)
+                if (2 * (j * R + ln) == N) a.y = b.y = 0.f;
+                v[j] = (j * R + ln <= hx) ? make_float2(a.x - b.y, a.y + b.x) : make_float2(a.x + b.y, b.x - a.y);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < H; ++j) v[j] = vn[j];
+        }
         __builtin_amdgcn_sched_barrier(0);
         if (item + (int)gridDim.x < n_items) load_line(item + (int)gridDim.x);
         __builtin_amdgcn_sched_barrier(0);
@@ -1865,7 +1892,17 @@ __global__ void __launch_bounds__(16 * R, (R == 32) ? 2 : 4) ifftTB_kernel(IfftT
         }
         fourstep_split_addtid<R, true, TCH>(v, wscr, wscr_lds, tw, ln, tid & 63);
         mul_chirp();
-        if (job.potential) {
+        if constexpr (PAIR) {                                  // v[j] = V_a + i V_b: t_a into v[j], t_b into v[H + j]
+#pragma unroll
+            for (int j = 0; j < H; ++j) {
+                if (j % 4 == 0) __builtin_amdgcn_sched_barrier(0);
+                float sn, cs, sn2, cs2;
+                sincospif(job.sigma_over_pi * (v[j].x * job.scale), &sn, &cs);
+                sincospif(job.sigma_over_pi * (v[j].y * job.scale), &sn2, &cs2);
+                v[j] = make_float2(cs, sn);
+                v[H + j] = make_float2(cs2, sn2);
+            }
+        } else if (job.potential) {
 #pragma unroll
             for (int j = 0; j < H; ++j) {
                 if (j % 4 == 0) __builtin_amdgcn_sched_barrier(0);
@@ -1875,27 +1912,37 @@ __global__ void __launch_bounds__(16 * R, (R == 32) ? 2 : 4) ifftTB_kernel(IfftT
             }
         }
         if (job.potential && (slice_of(job, img) & 1) == job.rows_parity) {       // workgroup-uniform: this slice is kept as rows
-            if (lb * LINES + grp < job.n_lines) {
+            if (lb * BL + grp < job.n_lines) {
                 float2* dst = job.out_rows + (long long)img * job.out_rows_is + (long long)L * job.out_rows_pitch;
 #pragma unroll
                 for (int j = 0; j < H; ++j) if (j * R + ln < N) dst[j * R + ln] = v[j];
             }
+            if constexpr (PAIR) {
+                if (lb * BL + LINES + grp < job.n_lines) {
+                    float2* dst = job.out_rows + (long long)img * job.out_rows_is + (long long)(lb * BL + LINES + grp) * job.out_rows_pitch;
+#pragma unroll
+                    for (int j = 0; j < H; ++j) if (j * R + ln < N) dst[j * R + ln] = v[H + j];
+                }
+            }
             continue;
         }
-        wave_lds_fence();
 #pragma unroll
-        for (int j = 0; j < H; ++j) myrow[j * R + ln] = v[j];
-        lds_barrier();
-        const int col = lb * LINES + li;
-        if (col < job.n_lines) {
-            float2* dst = job.out_t + (long long)img * job.out_t_is + col;
+        for (int half = 0; half < (PAIR ? 2 : 1); ++half) {
+            wave_lds_fence();
 #pragma unroll
-            for (int i = 0; i < NIT; ++i) {
-                const int pos = r0 + POS_PER_IT * i;
-                if (pos < N) dst[(long long)pos * job.out_t_pitch] = tile[li * CS + pos];
+            for (int j = 0; j < H; ++j) myrow[j * R + ln] = v[half * H + j];
+            lds_barrier();
+            const int col = lb * BL + half * LINES + li;
+            if (col < job.n_lines) {
+                float2* dst = job.out_t + (long long)img * job.out_t_is + col;
+#pragma unroll
+                for (int i = 0; i < NIT; ++i) {
+                    const int pos = r0 + POS_PER_IT * i;
+                    if (pos < N) dst[(long long)pos * job.out_t_pitch] = tile[li * CS + pos];
+                }
             }
+            lds_barrier();
         }
-        lds_barrier();
     }
 }
 

@@ -1859,10 +1859,15 @@ static int build_potentials(msl_handle* h, const double* pos, const int32_t* Z, 
                 const int R = o.R, M = R * R, NH = M / 2, CS = R * (R + 1) + 2;
                 const size_t lds = ((size_t)M + NH + 2 + NH + (size_t)16 * CS) * 8;
                 const int per_cu = std::max(1, std::min(R == 16 ? 4 : 1, (int)((size_t)h->lds_limit / lds)));
-                const long long items = (long long)((j.n_lines + 15) / 16) * j.n_images;
+                // second pass on a half spectrum: two real lines per transform (32-line work items)
+                const bool pair = R == 32 && j.herm && j.potential && !dbg_env("MSL_NO_PAIRED_IFFT");
+                const long long items = (long long)((j.n_lines + (pair ? 31 : 15)) / (pair ? 32 : 16)) * j.n_images;
                 const int grid = (int)std::min<long long>(items, (long long)h->n_cus * per_cu);
                 j.tw = o.tw; j.bf = o.bf; j.bw = o.bw;
-                if (R == 32) {
+                if (pair) {
+                    (void)hipFuncSetAttribute((const void*)ifftTB_kernel<32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
+                    hipLaunchKernelGGL((ifftTB_kernel<32, true>), dim3(grid), dim3(512), lds, h->stream, j);
+                } else if (R == 32) {
                     (void)hipFuncSetAttribute((const void*)ifftTB_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
                     hipLaunchKernelGGL(ifftTB_kernel<32>, dim3(grid), dim3(512), lds, h->stream, j);
                 } else {
