@@ -1662,12 +1662,15 @@ struct IfftT2Job {
 template <typename Job>
 __device__ __forceinline__ int slice_of(const Job& job, int img) { return job.slice_mod > 0 ? img % job.slice_mod : img; }
 
-template <int R>
+// PAIR (second pass: job.herm and job.potential set, line count a multiple of 32): two real lines per complex transform,
+// Z = X_a + i X_b -> V_a + i V_b; a group takes the lines g and g + 16 of a 32-line block (ifftTB_kernel's note).  Line a of the
+// next item is prefetched in registers as before, line b arrives at the top of the item (two prefetched lines do not fit).
+template <int R, bool PAIR = false>
 __global__ void __launch_bounds__(16 * R, 2) ifftT2_kernel(IfftT2Job job) {
     static_assert(R == 16, "512-point lines only (64 complex values per lane at R = 32 spill: 2048-point axes use ifftTW_kernel)");
     constexpr int N2 = R * R, N = 2 * N2, NT = 16 * R;
+    constexpr int BL = PAIR ? 32 : 16;                             // lines per work item
     constexpr int CPOS = N;
-    constexpr int NCHUNK = 1;
     constexpr int CS = CPOS + 1;
     constexpr int POS_PER_IT = NT / 8;
     constexpr int NIT = CPOS / POS_PER_IT;
@@ -1681,14 +1684,16 @@ __global__ void __launch_bounds__(16 * R, 2) ifftT2_kernel(IfftT2Job job) {
     const int grp = tid / R, ln = tid % R;
     const int q = tid & 7, r0 = tid >> 3;
     float* scratch = reinterpret_cast<float*>(tile + grp * CS);
-    const int lblocks = job.n_lines / 16;
+    const int lblocks = job.n_lines / BL;
     const int n_items = lblocks * job.n_images;
     // the next item's line is loaded into registers while the current one is transformed (two 256-thread workgroups per CU = two
     // waves per SIMD: without it the loads of an item were exposed -- 193 us of a 0.33 ms potential per frame at 512^2 x 100)
     float2 vn[2 * R];
-    auto load_line = [&](int it) {
+    // slot j of set b <- element 2 (j R + ln) + b of line `line`; with herm the mirrored element (conjugated unless RAW)
+    auto load_line = [&](int it, int line_in_block, float2 (&dst)[2 * R], auto raw_c) {
+        constexpr bool RAW = decltype(raw_c)::value;
         const int img = it / lblocks, lb = it - img * lblocks;
-        const float2* src = job.in + (long long)img * job.in_is + (long long)(lb * 16 + grp) * job.in_pitch;
+        const float2* src = job.in + (long long)img * job.in_is + (long long)(lb * BL + line_in_block) * job.in_pitch;
         int lnl = ln;
         asm volatile("" : "+v"(lnl));
         if (job.herm) {                                     // workgroup-uniform: mirrored elements as two 8-byte loads
@@ -1696,71 +1701,90 @@ __global__ void __launch_bounds__(16 * R, 2) ifftT2_kernel(IfftT2Job job) {
             for (int j = 0; j < R; ++j) {
                 const int e0 = 2 * (j * R + lnl), e1 = e0 + 1;
                 float2 a = src[e0 <= N / 2 ? e0 : N - e0], b = src[e1 <= N / 2 ? e1 : N - e1];
-                if (e0 > N / 2) a.y = -a.y;
-                if (e1 > N / 2) b.y = -b.y;
-                vn[j] = a; vn[R + j] = b;
+                if (!RAW && e0 > N / 2) a.y = -a.y;
+                if (!RAW && e1 > N / 2) b.y = -b.y;
+                dst[j] = a; dst[R + j] = b;
             }
         } else {
 #pragma unroll
             for (int j = 0; j < R; ++j) {
                 const float4 x = *reinterpret_cast<const float4*>(src + 2 * (j * R + lnl));
-                vn[j] = make_float2(x.x, x.y); vn[R + j] = make_float2(x.z, x.w);
+                dst[j] = make_float2(x.x, x.y); dst[R + j] = make_float2(x.z, x.w);
             }
         }
     };
-    if ((int)blockIdx.x < n_items) load_line(blockIdx.x);
+    using RawC = std::integral_constant<bool, PAIR>;
+    if ((int)blockIdx.x < n_items) load_line(blockIdx.x, grp, vn, RawC{});
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
         const int img = item / lblocks, lb = item - img * lblocks;
         int lnv = ln;                                       // laundered: keeps dozens of per-lane LDS / global addresses from being
         asm volatile("" : "+v"(lnv));                       // hoisted out of the loop into registers the transform needs
         float2 v[2 * R];
+        if constexpr (PAIR) {
+            float2 vb[2 * R];
+            load_line(item, 16 + grp, vb, RawC{});
 #pragma unroll
-        for (int j = 0; j < 2 * R; ++j) v[j] = vn[j];
+            for (int j = 0; j < 2 * R; ++j) {               // element 2 ((j % R) R + ln) + j / R: a + i b, mirrored half conj(a) + i conj(b)
+                const int e = 2 * ((j % R) * R + lnv) + j / R;
+                float2 a = vn[j], b = vb[j];
+                if (e == N / 2) a.y = b.y = 0.f;            // (the Nyquist element is its own mirror image: ifftTB_kernel's note)
+                v[j] = (e <= N / 2) ? make_float2(a.x - b.y, a.y + b.x) : make_float2(a.x + b.y, b.x - a.y);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2 * R; ++j) v[j] = vn[j];
+        }
         __builtin_amdgcn_sched_barrier(0);
-        if (item + (int)gridDim.x < n_items) load_line(item + (int)gridDim.x);
+        if (item + (int)gridDim.x < n_items) load_line(item + (int)gridDim.x, grp, vn, RawC{});
         __builtin_amdgcn_sched_barrier(0);
         float* scr = scratch;
         asm volatile("" : "+v"(scr));
         line2_transform<R, true>(v, scr, tw, tw2, lnv);
         // exp(i sigma V) through sincospi: its range reduction is exact, where sincosf carries a slow path with a private
         // array (scratch); sigma / pi is formed in double on the host.
-        auto trans_of = [&](float2 x) {
+        auto trans_of = [&](float x) {
             float sn, cs;
-            sincospif(job.sigma_over_pi * (x.x * job.scale), &sn, &cs);
+            sincospif(job.sigma_over_pi * (x * job.scale), &sn, &cs);
             return make_float2(cs, sn);
         };
-        if (job.potential) {
+        float vy[PAIR ? 2 * R : 1];
+        if constexpr (PAIR) {
 #pragma unroll
-            for (int j = 0; j < 2 * R; ++j) {
-                if (j % 4 == 0) __builtin_amdgcn_sched_barrier(0);          // four evaluations in flight, not all of them
-                v[j] = trans_of(v[j]);
+            for (int j = 0; j < 2 * R; ++j) vy[j] = v[j].y;
+        }
+        const bool as_rows = job.potential && (slice_of(job, img) & 1) == job.rows_parity;       // workgroup-uniform
+#pragma unroll
+        for (int half = 0; half < (PAIR ? 2 : 1); ++half) {
+            if (job.potential) {
+#pragma unroll
+                for (int j = 0; j < 2 * R; ++j) {
+                    if (j % 4 == 0) __builtin_amdgcn_sched_barrier(0);          // four evaluations in flight, not all of them
+                    v[j] = trans_of(half == 0 ? v[j].x : vy[j]);
+                }
             }
-        }
-        if (job.potential && (slice_of(job, img) & 1) == job.rows_parity) {       // workgroup-uniform
-            float2* dst = job.out_rows + (long long)img * job.out_rows_is + (long long)(lb * 16 + grp) * job.out_rows_pitch;
+            if (as_rows) {
+                float2* dst = job.out_rows + (long long)img * job.out_rows_is + (long long)(lb * BL + half * 16 + grp) * job.out_rows_pitch;
 #pragma unroll
-            for (int j = 0; j < 2 * R; ++j) dst[(j / R) * N2 + (j % R) * R + lnv] = v[j];
-            continue;
-        }
-        float2* dst = job.out_t + (long long)img * job.out_t_is + lb * 16;
-        int off0 = 2 * q + r0 * job.out_t_pitch;
-        asm volatile("" : "+v"(off0));
-        const int ostep = POS_PER_IT * job.out_t_pitch;
-#pragma unroll
-        for (int c = 0; c < NCHUNK; ++c) {
-            lds_barrier();                             // the tile (and, for c == 0, every group's scratch use) is free
+                for (int j = 0; j < 2 * R; ++j) dst[(j / R) * N2 + (j % R) * R + lnv] = v[j];
+                continue;
+            }
+            float2* dst = job.out_t + (long long)img * job.out_t_is + lb * BL + half * 16;
+            int off0 = 2 * q + r0 * job.out_t_pitch;
+            asm volatile("" : "+v"(off0));
+            const int ostep = POS_PER_IT * job.out_t_pitch;
+            lds_barrier();                             // the tile (and every group's scratch use) is free
             float2* myrow = reinterpret_cast<float2*>(scr);
 #pragma unroll
-            for (int j = 0; j < CPOS / R; ++j) myrow[j * R + lnv] = v[c * (CPOS / R) + j];
+            for (int j = 0; j < CPOS / R; ++j) myrow[j * R + lnv] = v[j];
             lds_barrier();
 #pragma unroll
             for (int i = 0; i < NIT; ++i) {
                 const int pos = r0 + POS_PER_IT * i;
                 const float2 a = tile[(2 * q) * CS + pos], b = tile[(2 * q + 1) * CS + pos];
-                st_stream(dst + (off0 + (c * NIT + i) * ostep), a.x, a.y, b.x, b.y);
+                st_stream(dst + (off0 + i * ostep), a.x, a.y, b.x, b.y);
             }
         }
-        lds_barrier();
+        if (!as_rows) lds_barrier();
     }
 }
 

@@ -1897,8 +1897,16 @@ static int build_potentials(msl_handle* h, const double* pos, const int32_t* Z, 
                 constexpr int R = 16, N2 = R * R, N = 2 * N2;
                 const size_t lds = ((size_t)2 * N2 + (size_t)16 * (N + 1)) * 8;
                 const int per_cu = std::max(1, std::min(2, (int)((size_t)h->lds_limit / lds)));
-                const long long items = (long long)(j.n_lines / 16) * j.n_images;
+                // second pass on a half spectrum: two real lines per transform (32-line work items)
+                const bool pair = j.herm && j.potential && j.n_lines % 32 == 0 && !dbg_env("MSL_NO_PAIRED_IFFT");
+                const long long items = (long long)(j.n_lines / (pair ? 32 : 16)) * j.n_images;
                 const int grid = (int)std::min<long long>(items, (long long)h->n_cus * per_cu);
+                if (pair) {
+                    (void)hipFuncSetAttribute((const void*)ifftT2_kernel<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
+                    hipLaunchKernelGGL((ifftT2_kernel<16, true>), dim3(grid), dim3(256), lds, h->stream, j);
+                    HIPCHK(h, hipGetLastError());
+                    return mark_launch(h, K_OTHER);
+                }
                 (void)hipFuncSetAttribute((const void*)ifftT2_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
                 hipLaunchKernelGGL(ifftT2_kernel<16>, dim3(grid), dim3(256), lds, h->stream, j);
                 HIPCHK(h, hipGetLastError());

@@ -150,8 +150,9 @@ def test_m0_is_only_touched_by_the_addtid_exchange(tmp_path):
     text = "\n".join(lines)
     shipped = ["rowT_pass_kernelILi32ELi16E", "rowT_pass_kernelILi16ELi16E", "rowT2_pass_kernelILi16E", "rowTW_pass_kernelILb1ELb1E",
                "rowTB_pass_kernelILi32E", "rowTB_pass_kernelILi16E", "rowTB2_pass_kernelILb0ELb0E", "rowTC2_pass_kernel",
-               "ifftTB_kernelILi32E", "ifftTB_kernelILi16E", "ifftTB2_kernel", "ifftTW_kernel", "ifftT2_kernelILi16E",
-               "structure_factor_quad_kernel", "structure_factor_stream_kernel", "structure_factor_edge_kernel", "col_pass_kernelILi32ELi16ELb1E", "col_pass_kernelILi16ELi32ELb0E",
+               "ifftTB_kernelILi32ELb0E", "ifftTB_kernelILi32ELb1E", "ifftTB_kernelILi16ELb0E", "ifftTB2_kernel", "ifftTW_kernel",
+               "ifftT2_kernelILi16ELb0E", "ifftT2_kernelILi16ELb1E",
+               "structure_factor_quad_kernel", "structure_factor_stream_kernel", "structure_factor_edge_kernel", "col_pass_kernelILi32ELi16ELb1E",
                "time_cz_kernelILi16ELi32ELb1E", "time_cz_kernelILi32ELi16ELb1E", "time_cz_kernelILi16ELi32ELb0E", "time_cz_kernelILi32ELi16ELb0E", "tacaw_fold_kernel", "row_pass_pf_kernelILi32E", "row_pass2_kernelILi32E"]
     names = re.findall(r"\.amdhsa_kernel (\S+)", text)
     assert not [n for n in names if re.search(r"rowTP|rowT3|rowTC_pass|structure_factor_mfma|structure_factor_nyquist", n)], "superseded kernels are back"
@@ -163,6 +164,13 @@ def test_m0_is_only_touched_by_the_addtid_exchange(tmp_path):
         vgpr = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1))
         assert scratch == 0, (name, scratch)
         assert vgpr <= (512 if name == "structure_factor_stream_kernel" else 256), (name, vgpr)     # (one wave per SIMD by design)
+    # the per-lane / wave-split time transforms (57 instantiations): one wave per SIMD where the line needs the 512-register file,
+    # never private memory
+    timek = re.findall(r"\.amdhsa_kernel (_ZN3msl\d+time_(?:direct|split)_kernel\S*)(.*?)\.end_amdhsa_kernel", text, re.S)
+    assert len(timek) == 57, len(timek)
+    for name, body in timek:
+        assert int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1)) == 0, name
+        assert int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1)) <= 512, name
 
 
 def test_default_frame_batch_rule():
