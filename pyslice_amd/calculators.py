@@ -39,9 +39,11 @@ def default_frame_batch(n_probes: int, n_slices: int, nx: int, ny: int) -> int:
     About 256 images (probes x frames) per launch: a launch of the slice loop is one round of persistent workgroups over the
     256 CUs, and its fixed part (tables into LDS, the first un-prefetched line, the tail of the last round) is amortised over
     the items of a workgroup -- 64 probes x 1024^2 x 200 slices: 277 / 270 / 267 us per 64 images at 1 / 2 / 4 frames per
-    launch.  Bounded by 16 GB for the two orientations of the batch's transmission stacks and 8 GB for the three work buffers."""
+    launch.  Bounded by 48 GB for the two orientations of the batch's transmission stacks (a sixth of the card; single-probe runs
+    still gain from 32 -> 128 frames per launch: 501^2 x 100 slices 160 k -> 167 k slice-steps/s) and 8 GB for the three work
+    buffers; setup() halves the batch when the device cannot hold it next to the result."""
     by_images = -(-256 // max(1, n_probes))
-    by_stacks = int(16e9 // (16.0 * n_slices * nx * ny))
+    by_stacks = int(48e9 // (16.0 * n_slices * nx * ny))
     by_work = int(8e9 // (24.0 * nx * ny * max(1, n_probes)))
     batch = max(1, min(by_images, by_stacks, by_work))
     if batch >= 16:

@@ -176,7 +176,7 @@ def test_m0_is_only_touched_by_the_addtid_exchange(tmp_path):
 def test_default_frame_batch_rule():
     from pyslice_amd.calculators import default_frame_batch
     assert default_frame_batch(64, 200, 1024, 1024) == 4          # C3: about 256 images per launch
-    assert default_frame_batch(1, 100, 512, 512) == 32            # C2: 16 GB of transmission stacks bound it (38 -> a multiple of 16)
+    assert default_frame_batch(1, 100, 512, 512) == 112           # C2: 48 GB of transmission stacks bound it (114 -> a multiple of 16)
     assert default_frame_batch(1, 50, 256, 256) == 256            # C1
     assert default_frame_batch(16, 400, 2048, 2048) == 1          # C5: one frame's stacks are 27 GB
     assert default_frame_batch(300, 10, 64, 64) == 1
