@@ -1194,26 +1194,38 @@ static int launch_time_direct_t(msl_handle* h, const TimeJob& j) {
 #define MSL_TSPLIT_SHAPES(X) X(45, 3) X(72, 2) X(75, 2) X(80, 2) X(81, 2) X(90, 2) X(96, 2) X(100, 2) X(108, 2) X(75, 3) X(120, 2) X(81, 3) \
     X(125, 2) X(128, 2) X(45, 6) X(72, 4) X(75, 4) X(80, 4) X(81, 4) X(90, 4) X(125, 3) X(96, 4) X(100, 4) X(81, 5) X(108, 4) X(75, 6) \
     X(120, 4) X(81, 6) X(125, 4) X(128, 4)
-static int time_split_waves(int T) {           // L, or 0: no such kernel
-    if (T <= TDIR_MAX || T > 512 || !fft_smooth(T)) return 0;
-    for (int L : {2, 4, 6, 3, 5})
-        if (T % L == 0 && T / L <= TDIR_MAX && (L <= 4 || T / L <= 100)) return L;
+// ... and 513 .. 1024 as 8 x TP (else 6 x TP) with two blocks per wave on 32-pixel tiles (HB = 2)
+#define MSL_TSPLIT2_SHAPES(X) X(90, 6) X(72, 8) X(75, 8) X(80, 8) X(81, 8) X(90, 8) X(125, 6) X(96, 8) X(100, 8) X(108, 8) X(120, 8) \
+    X(125, 8) X(128, 8)
+static int time_split_waves(int T, int* hb = nullptr) {           // L (and the blocks per wave), or 0: no such kernel
+    if (hb) *hb = 1;
+    if (T <= TDIR_MAX || T > 1024 || !fft_smooth(T)) return 0;
+    if (T <= 512) {
+        for (int L : {2, 4, 6, 3, 5})
+            if (T % L == 0 && T / L <= TDIR_MAX && (L <= 4 || T / L <= 100)) return L;
+        return 0;
+    }
+    if (hb) *hb = 2;
+    for (int L : {8, 6})
+        if (T % L == 0 && T / L <= TDIR_MAX) return L;
     return 0;
 }
-template <int TP, int L>
+template <int TP, int L, int HB>
 static int launch_time_split_t(msl_handle* h, const TimeJob& j) {
-    const size_t lds = tsplit_lds_bytes(TP, L);
-    const long long tiles = ((long long)(j.npix + 63) / 64) * j.n_images;
-    (void)hipFuncSetAttribute((const void*)time_split_kernel<TP, L>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
+    const size_t lds = tsplit_lds_bytes(TP, L, HB);
+    const int threads = 64 * L / HB;
+    const long long tiles = ((long long)(j.npix + 64 / HB - 1) / (64 / HB)) * j.n_images;
+    (void)hipFuncSetAttribute((const void*)time_split_kernel<TP, L, HB>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
     int per_cu = 1;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)time_split_kernel<TP, L>, 64 * L, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)time_split_kernel<TP, L, HB>, threads, lds) != hipSuccess || per_cu < 1) per_cu = 1;
     const int grid = (int)std::min<long long>(tiles, (long long)h->n_cus * per_cu);
-    hipLaunchKernelGGL((time_split_kernel<TP, L>), dim3(grid), dim3(64 * L), lds, h->stream, j);
+    hipLaunchKernelGGL((time_split_kernel<TP, L, HB>), dim3(grid), dim3(threads), lds, h->stream, j);
     HIPCHK(h, hipGetLastError());
     return mark_launch(h, K_OTHER);
 }
 static int launch_time_split(msl_handle* h, TimeJob j) {
-    const int T = j.T, L = time_split_waves(T);
+    int HB = 1;
+    const int T = j.T, L = time_split_waves(T, &HB);
     if (h->tsplit_T != T) {
         h->tsplit_T = 0;
         std::vector<float2> w(T);
@@ -1224,8 +1236,11 @@ static int launch_time_split(msl_handle* h, TimeJob j) {
         h->tsplit_T = T;
     }
     j.tw = h->tsplit_tw;
-#define X(tp, l) if (T == (tp) * (l) && L == (l)) return launch_time_split_t<tp, l>(h, j);
+#define X(tp, l) if (HB == 1 && T == (tp) * (l) && L == (l)) return launch_time_split_t<tp, l, 1>(h, j);
     MSL_TSPLIT_SHAPES(X)
+#undef X
+#define X(tp, l) if (HB == 2 && T == (tp) * (l) && L == (l)) return launch_time_split_t<tp, l, 2>(h, j);
+    MSL_TSPLIT2_SHAPES(X)
 #undef X
     return fail(h, MSL_ERR_UNSUPPORTED, "no wave-split time kernel for %d frames", T);
 }
@@ -2092,18 +2107,18 @@ int msl_tacaw(msl_handle* h, const void* d_src, void* d_dst, int64_t batch, int3
     if (T < 2) return fail(h, MSL_ERR_INVALID, "msl_tacaw: needs at least 2 frames (got %d)", T);
     if (batch < 1 || npix < 1) return fail(h, MSL_ERR_INVALID, "msl_tacaw: bad batch/npix");
     if (npix > 0x7fffffffLL) return fail(h, MSL_ERR_UNSUPPORTED, "msl_tacaw: npix too large");
-    // 1024 frames: four-step column kernel (256 frames ran it too until the wave-split kernel overtook it: 39.7 vs 40.2 ms for
-    // 64 probes x 1024^2, 40.7 vs 44.7 ms for 16 x 2048^2)
-    const int Rt = (c.fft_path == 0 && T == 1024) ? fast_radix(T) : 0;
+    // smooth counts up to 1024: the register network split over the waves of a workgroup (time_split_kernel); above 512 frames a
+    // wave holds two blocks and reaches the second through the 32-bit lane offset (pixel + TP rows), which bounds the image size
+    const bool split_t = c.fft_path == 0 && time_split_waves(T) > 0
+                         && (unsigned long long)(T > 512 ? TDIR_MAX + 1 : 65) * (unsigned long long)npix * 8ull < (1ull << 32)
+                         && !dbg_env("MSL_TACAW_GENERIC") && !dbg_env("MSL_TACAW_CHIRPZ") && !(T == 1024 && dbg_env("MSL_TACAW_FOURSTEP"));
+    // 1024 frames of images too large for that: the four-step column kernel (it served 256 and 1024 frames until the split kernel
+    // overtook it: T = 256, 64 probes x 1024^2 40.2 -> 39.7 ms, 16 x 2048^2 44.7 -> 40.7 ms; T = 1024, 8 x 1024^2 33.7 -> 29.3 ms)
+    const int Rt = (c.fft_path == 0 && T == 1024 && !split_t) ? fast_radix(T) : 0;
     const bool fast_t = Rt && (npix % 16 == 0) && npix >= 32 && !dbg_env("MSL_TACAW_GENERIC");
-    // any other frame count up to 512, and 256 frames of a grid whose pixel count the four-step kernel cannot tile: chirp-z on the
-    // register FFTs (time_cz_kernel), 32-pixel tiles for T <= 128, else 16; any pixel count (ragged last tile, odd counts unvectorised)
     // smooth frame counts from 16 to 128 (100 = 4.5.5 ...): a lane per pixel, the whole time line in its registers (time_direct_kernel)
     const bool direct_t = !fast_t && c.fft_path == 0 && time_direct_has(T) && (unsigned long long)((T + 1) / 2) * (unsigned long long)npix * 8ull < (1ull << 32)
                           && !dbg_env("MSL_TACAW_GENERIC") && !dbg_env("MSL_TACAW_CHIRPZ");
-    // smooth counts up to 512: the same network split over the 2 .. 6 waves of a workgroup (time_split_kernel)
-    const bool split_t = !fast_t && c.fft_path == 0 && time_split_waves(T) > 0 && (unsigned long long)65 * (unsigned long long)npix * 8ull < (1ull << 32)
-                         && !dbg_env("MSL_TACAW_GENERIC") && !dbg_env("MSL_TACAW_CHIRPZ");
     const bool cz_t = !fast_t && !direct_t && !split_t && c.fft_path == 0 && T <= 512 && !dbg_env("MSL_TACAW_GENERIC");
     int rc = MSL_OK;
     float2* tw4_t = nullptr;

@@ -304,51 +304,62 @@ __global__ void __launch_bounds__(256) time_direct_kernel(TimeJob job) {
 // TP-point register network on its own.  The exchange goes in chunks of CH samples through two alternating buffers (L x CH x 64
 // complex each), one barrier per chunk: a wave passes barrier n + 1 only after it has read chunk n, so chunk n + 2 may overwrite
 // it.  L = 2, 3, 4 run one wave per SIMD with 512 registers per lane; L = 5, 6 two, with 256 (and TP <= 100).
-__host__ __device__ constexpr int tsplit_chunk(int L) { return L <= 4 ? 32 : 16; }
-__host__ __device__ constexpr int tsplit_prefetch(int TP, int L) {
-    const int room = ((L <= 4 ? 512 : 256) - 224 - 2 * TP) / 2;
+// HB = 2 (T above 512: L = 6, 8): a wave holds TWO blocks, lanes 0..31 block 2w and lanes 32..63 block 2w + 1 of 32 pixels (256- /
+// 128-byte runs) -- eight blocks of 128 samples on four waves with the whole register file each; q, the coefficients and the row
+// addresses are then per-lane values, the second block's rows are reached through the lane offset (host: (TP + 65) npix 8 < 4 GB).
+__host__ __device__ constexpr int tsplit_chunk(int L, int HB = 1) { return 2 * L * 32 * (64 / HB) * 8 + TDIR_MAX * L * 8 <= 150 * 1024 ? 32 : 16; }
+__host__ __device__ constexpr int tsplit_prefetch(int TP, int W, int HB = 1) {          // W: waves of the workgroup
+    const int room = ((W <= 4 ? 512 : 256) - (HB == 1 ? 224 : 256) - 2 * TP) / 2;       // (per-lane coefficients and addresses at HB = 2)
     return room < 0 ? 0 : (room > TP ? TP : room);
 }
-__host__ __device__ constexpr size_t tsplit_lds_bytes(int TP, int L) { return ((size_t)TP * L + (size_t)2 * L * tsplit_chunk(L) * 64) * 8; }
+__host__ __device__ constexpr size_t tsplit_lds_bytes(int TP, int L, int HB = 1) {
+    return ((size_t)TP * L + (size_t)2 * L * tsplit_chunk(L, HB) * (64 / HB)) * 8;
+}
 
-template <int TP, int L>
-__global__ void __launch_bounds__(64 * L) time_split_kernel(TimeJob job) {
-    constexpr int T = TP * L, half = T / 2, KH = (TP + 1) / 2, CH = tsplit_chunk(L);
+template <int TP, int L, int HB = 1>
+__global__ void __launch_bounds__(64 * L / HB) time_split_kernel(TimeJob job) {
+    static_assert(HB == 1 || (HB == 2 && L % 2 == 0), "one block per wave, or two on its halves");
+    constexpr int T = TP * L, half = T / 2, KH = (TP + 1) / 2, CH = tsplit_chunk(L, HB), W = L / HB, PW = 64 / HB;
     // Prefetch of the next tile: PF rows before the transform starts -- what fits beside the 2 TP data registers -- and the others
     // block by block: the register network's first level leaves R1 independent blocks of M1 samples; as soon as a block is
     // transformed and stored its registers take the next LATE rows.  All TP rows of the next tile are in flight or landed when the
     // tile ends, and the loads are spread over the whole of it.
     // (Rows that still do not fit -- two waves per SIMD leave few spare registers -- are fetched at the top of the tile.)
     constexpr int R1 = fft_radix(TP), M1 = TP / R1;
-    constexpr int PF = tsplit_prefetch(TP, L);
+    constexpr int PF = tsplit_prefetch(TP, W, HB);
     constexpr int LATE_ALL = (R1 - 1) * M1 < TP - PF ? (R1 - 1) * M1 : TP - PF;      // rows fetched behind finished blocks
     constexpr int NPRE = PF + LATE_ALL;                                                // rows of the next tile in flight at its start
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float2* twl = reinterpret_cast<float2*>(smem_raw);             // W_T^n, n < T
     float2* xbuf = twl + T;                                        // two exchange buffers [j][k][lane]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
-    for (int i = tid; i < T; i += 64 * L) twl[i] = job.tw[i];
+    const int tid = threadIdx.x, lane = tid & 63, px = lane % PW, hb = lane / PW;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = HB == 1 ? wave : wave * HB + hb;
+    for (int i = tid; i < T; i += 64 * W) twl[i] = job.tw[i];
     __syncthreads();
     float cr[L], ci[L];                                            // W_L^{j q} = W_T^{(j q mod L) TP}
 #pragma unroll
     for (int j = 1; j < L; ++j) {
         const float2 w = twl[((j * q) % L) * TP];
-        cr[j] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(w.x)));
-        ci[j] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(w.y)));
+        if constexpr (HB == 1) {
+            cr[j] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(w.x)));
+            ci[j] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(w.y)));
+        } else {
+            cr[j] = w.x; ci[j] = w.y;
+        }
     }
-    const int tiles_per_image = (job.npix + 63) / 64;
+    const int tiles_per_image = (job.npix + PW - 1) / PW;
     const long long n_tiles = (long long)tiles_per_image * job.n_images;
     const long long step = gridDim.x;
     // (ragged last tile: the surplus lanes repeat the image's last pixel, as in time_direct_kernel)
     auto column = [&](long long t, msl_i4v& rows0, msl_i4v& rows, msl_i4v& rows_hi, float*& orow, unsigned& c) {
         const int p = __builtin_amdgcn_readfirstlane((int)(t / tiles_per_image));
-        const int c0 = __builtin_amdgcn_readfirstlane((int)(t % tiles_per_image) * 64);
-        c = c0 + lane < job.npix ? (unsigned)(c0 + lane) : (unsigned)(job.npix - 1);
+        const int c0 = __builtin_amdgcn_readfirstlane((int)(t % tiles_per_image) * PW);
+        c = c0 + px < job.npix ? (unsigned)(c0 + px) : (unsigned)(job.npix - 1);
         const float2* img = job.in + (long long)p * job.image_stride;
         rows0 = make_raw_rsrc(img);
-        rows = make_raw_rsrc(img + (long long)(q * TP) * job.npix);
-        rows_hi = make_raw_rsrc(img + (long long)(q * TP + KH) * job.npix);
+        rows = make_raw_rsrc(img + (long long)(wave * HB * TP) * job.npix);
+        rows_hi = make_raw_rsrc(img + (long long)(wave * HB * TP + KH) * job.npix);
         orow = job.out + (long long)p * job.image_stride;
     };
     // (row offsets, LDS addresses beyond the 64 KB an instruction's offset field reaches: all the same for every tile, and the
@@ -356,8 +367,10 @@ __global__ void __launch_bounds__(64 * L) time_split_kernel(TimeJob job) {
     auto hide_s = [](int x) { asm volatile("" : "+s"(x)); return x; };
     auto hide_v = [](int x) { asm volatile("" : "+v"(x)); return x; };
     auto load_row = [&](const msl_i4v& rows, const msl_i4v& rows_hi, int k, unsigned c, int npix_now) {
-        const msl_f2v t = k < KH ? msl_raw_buffer_load_f2(rows, (int)(8u * c), (int)(8u * (unsigned)k * (unsigned)npix_now), 2)
-                                 : msl_raw_buffer_load_f2(rows_hi, (int)(8u * c), (int)(8u * (unsigned)(k - KH) * (unsigned)npix_now), 2);
+        // (HB = 2: the upper half-wave's block lies TP rows further on)
+        const unsigned vo = HB == 1 ? 8u * c : 8u * c + (unsigned)hb * (8u * (unsigned)TP * (unsigned)npix_now);
+        const msl_f2v t = k < KH ? msl_raw_buffer_load_f2(rows, (int)vo, (int)(8u * (unsigned)k * (unsigned)npix_now), 2)
+                                 : msl_raw_buffer_load_f2(rows_hi, (int)vo, (int)(8u * (unsigned)(k - KH) * (unsigned)npix_now), 2);
         return make_float2(t.x, t.y);
     };
     long long tile = blockIdx.x;
@@ -391,15 +404,16 @@ __global__ void __launch_bounds__(64 * L) time_split_kernel(TimeJob job) {
         __builtin_amdgcn_sched_barrier(0);
         static_for<0, (TP + CH - 1) / CH>([&](auto cc) {
             constexpr int cb = decltype(cc)::value * CH;
-            float2* buf = xbuf + par * (L * CH * 64) + hide_v(lane);
+            float2* buf = xbuf + par * (L * CH * PW) + hide_v(px);
+            const int qx = HB == 1 ? q : hide_v(q);            // (per-lane q: its multiples are loop-invariant vector values, see hide_v)
             par ^= 1;
 #pragma unroll
             for (int k = cb; k < cb + CH; ++k)
-                if (k < TP) buf[(q * CH + (k - cb)) * 64] = make_float2(v[k].x - ref.x, v[k].y - ref.y);
+                if (k < TP) buf[(qx * CH + (k - cb)) * PW] = make_float2(v[k].x - ref.x, v[k].y - ref.y);
             lds_barrier();
             // the butterfly of my wave, four samples at a time, the next four already on their way from the LDS (one wave per
-            // SIMD: nobody else would cover the round trip).  L = 2 and 4 use the trivial coefficients' structure:
-            // a0 + s a1, resp. (a0 + s a2) + W_4^q (a1 + s a3) with s = W_L^{(L/2) q} = +-1.
+            // SIMD: nobody else would cover the round trip).  Even L use the structure of the coefficients:
+            // sum_m W_L^{m q} (a_m + s a_{m + L/2}) with s = W_L^{(L/2) q} = +-1.
             constexpr int G = L <= 4 ? 4 : 2, KEND = cb + CH < TP ? cb + CH : TP;
             float2 A[G][L], W[G];
             auto fetch = [&](int k0, float2 (&a)[G][L], float2 (&w)[G]) {
@@ -407,8 +421,8 @@ __global__ void __launch_bounds__(64 * L) time_split_kernel(TimeJob job) {
                 for (int g = 0; g < G; ++g)
                     if (k0 + g < KEND) {
 #pragma unroll
-                        for (int j = 0; j < L; ++j) a[g][j] = buf[(j * CH + (k0 + g - cb)) * 64];
-                        w[g] = twl[(k0 + g) * q];
+                        for (int j = 0; j < L; ++j) a[g][j] = buf[(j * CH + (k0 + g - cb)) * PW];
+                        w[g] = twl[(k0 + g) * qx];
                     }
             };
             fetch(cb, A, W);
@@ -420,13 +434,20 @@ __global__ void __launch_bounds__(64 * L) time_split_kernel(TimeJob job) {
                 for (int g = 0; g < G; ++g) {
                     if (k0 + g < KEND) {
                         float2 acc;
-                        if constexpr (L == 2) {
-                            acc = make_float2(fmaf(A[g][1].x, cr[1], A[g][0].x), fmaf(A[g][1].y, cr[1], A[g][0].y));
-                        } else if constexpr (L == 4) {
-                            const float2 t = make_float2(fmaf(A[g][2].x, cr[2], A[g][0].x), fmaf(A[g][2].y, cr[2], A[g][0].y));
-                            const float2 u = make_float2(fmaf(A[g][3].x, cr[2], A[g][1].x), fmaf(A[g][3].y, cr[2], A[g][1].y));
-                            acc.x = fmaf(u.x, cr[1], fmaf(-u.y, ci[1], t.x));
-                            acc.y = fmaf(u.x, ci[1], fmaf(u.y, cr[1], t.y));
+                        if constexpr (L % 2 == 0) {
+                            // W_L^{(m + L/2) q} = (-1)^q W_L^{m q}: fold the upper half onto the lower one first (real sign),
+                            // then L/2 - 1 complex coefficients instead of L - 1
+                            constexpr int HL = L / 2;
+                            float2 b[HL];
+#pragma unroll
+                            for (int m = 0; m < HL; ++m)
+                                b[m] = make_float2(fmaf(A[g][m + HL].x, cr[HL], A[g][m].x), fmaf(A[g][m + HL].y, cr[HL], A[g][m].y));
+                            acc = b[0];
+#pragma unroll
+                            for (int m = 1; m < HL; ++m) {
+                                acc.x = fmaf(b[m].x, cr[m], fmaf(-b[m].y, ci[m], acc.x));
+                                acc.y = fmaf(b[m].x, ci[m], fmaf(b[m].y, cr[m], acc.y));
+                            }
                         } else {
                             acc = A[g][0];
 #pragma unroll
@@ -458,14 +479,18 @@ __global__ void __launch_bounds__(64 * L) time_split_kernel(TimeJob job) {
             constexpr int B = decltype(bc)::value;
             dif<M1, 1, false, true>(v + B * M1);
             npix_now = hide_s(npix_now);
+            const int qs = HB == 1 ? q : hide_v(q);
             static_for<B * M1, (B + 1) * M1>([&](auto ic) {
                 constexpr int I = decltype(ic)::value;
                 constexpr int F = dif_out_index(I, TP);            // sub-frequency held by register I: bin L F + q
-                int row = L * F + q + half;                        // np.fft.fftshift (uniform)
+                int row = L * F + qs + half;                        // np.fft.fftshift (uniform when a wave holds one block)
                 if (row >= T) row -= T;
                 float val = fmaf(v[I].x, v[I].x, v[I].y * v[I].y);
-                if (F == 0 && q == 0) val = 0.f;
-                __builtin_nontemporal_store(val, reinterpret_cast<float*>(reinterpret_cast<char*>(out_rows + (long long)row * npix_now) + 4u * my_c));
+                if (F == 0 && qs == 0) val = 0.f;
+                if constexpr (HB == 1)
+                    __builtin_nontemporal_store(val, reinterpret_cast<float*>(reinterpret_cast<char*>(out_rows + (long long)row * npix_now) + 4u * my_c));
+                else
+                    __builtin_nontemporal_store(val, out_rows + ((long long)row * npix_now + my_c));
             });
             if constexpr (B < R1 - 1 && PF + B * M1 < NPRE) {
                 constexpr int K0 = PF + B * M1, K1 = K0 + M1 < NPRE ? K0 + M1 : NPRE;
