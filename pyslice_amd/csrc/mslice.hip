@@ -1189,20 +1189,21 @@ static int launch_time_direct_t(msl_handle* h, const TimeJob& j) {
     HIPCHK(h, hipGetLastError());
     return mark_launch(h, K_OTHER);
 }
-// smooth frame counts 129 .. 512 as L x TP with TP <= 128: L = 2 (two workgroups per CU), else 4, else 6 -- a multiple of the four
-// SIMDs' worth of waves or close -- else 3 or 5 (odd counts); two waves per SIMD from L = 5 on: TP <= 100
-#define MSL_TSPLIT_SHAPES(X) X(45, 3) X(72, 2) X(75, 2) X(80, 2) X(81, 2) X(90, 2) X(96, 2) X(100, 2) X(108, 2) X(75, 3) X(120, 2) X(81, 3) \
-    X(125, 2) X(128, 2) X(45, 6) X(72, 4) X(75, 4) X(80, 4) X(81, 4) X(90, 4) X(125, 3) X(96, 4) X(100, 4) X(81, 5) X(108, 4) X(75, 6) \
-    X(120, 4) X(81, 6) X(125, 4) X(128, 4)
-// ... and 513 .. 1024 as 8 x TP (else 6 x TP) with two blocks per wave on 32-pixel tiles (HB = 2)
-#define MSL_TSPLIT2_SHAPES(X) X(90, 6) X(72, 8) X(75, 8) X(80, 8) X(81, 8) X(90, 8) X(125, 6) X(96, 8) X(100, 8) X(108, 8) X(120, 8) \
-    X(125, 8) X(128, 8)
+// smooth frame counts 129 .. 512 as L x TP with TP <= 128: L = 2, else 4, else 6, else 3 or 5 (odd counts; two waves per SIMD from
+// L = 5 on: TP <= 100).  L = 2 and 4 put two blocks on the halves of a wave (HB = 2: 32-pixel tiles, workgroups of one or two
+// waves, two to four of them per CU -- independent workgroups cover each other's barriers: T = 500 0.56 -> 0.61, T = 300 0.49 ->
+// 0.62, T = 256 0.63 -> 0.69 in same-box A/Bs; L = 6 lost that way, 0.53 -> 0.42, and keeps a block per wave)
+#define MSL_TSPLIT_SHAPES(X) X(45, 3) X(75, 3) X(81, 3) X(45, 6) X(125, 3) X(81, 5) X(75, 6) X(81, 6)
+// ... and 513 .. 1024 as 8 x TP (else 6 x TP), two blocks per wave as well
+#define MSL_TSPLIT2_SHAPES(X) X(72, 2) X(75, 2) X(80, 2) X(81, 2) X(90, 2) X(96, 2) X(100, 2) X(108, 2) X(120, 2) X(125, 2) X(128, 2) \
+    X(72, 4) X(75, 4) X(80, 4) X(81, 4) X(90, 4) X(96, 4) X(100, 4) X(108, 4) X(120, 4) X(125, 4) X(128, 4) \
+    X(90, 6) X(72, 8) X(75, 8) X(80, 8) X(81, 8) X(90, 8) X(125, 6) X(96, 8) X(100, 8) X(108, 8) X(120, 8) X(125, 8) X(128, 8)
 static int time_split_waves(int T, int* hb = nullptr) {           // L (and the blocks per wave), or 0: no such kernel
     if (hb) *hb = 1;
     if (T <= TDIR_MAX || T > 1024 || !fft_smooth(T)) return 0;
     if (T <= 512) {
         for (int L : {2, 4, 6, 3, 5})
-            if (T % L == 0 && T / L <= TDIR_MAX && (L <= 4 || T / L <= 100)) return L;
+            if (T % L == 0 && T / L <= TDIR_MAX && (L <= 4 || T / L <= 100)) { if (hb && L <= 4 && L % 2 == 0) *hb = 2; return L; }
         return 0;
     }
     if (hb) *hb = 2;
