@@ -15,58 +15,9 @@
 #include <type_traits>
 #include <hip/hip_runtime.h>
 #include "fft_regs.h"
+#include "kernel_util.h"
 
 namespace msl {
-
-__device__ __forceinline__ float2 cmulf(float2 a, float2 b) {
-    return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x));
-}
-__device__ __forceinline__ float2 cmulf_conj(float2 a, float2 b) {      // a * conj(b)
-    return make_float2(fmaf(a.x, b.x, a.y * b.y), fmaf(a.y, b.x, -a.x * b.y));
-}
-
-// LDS ordering inside one wave: DS instructions of a wave execute in order, so only the compiler
-// must be kept from reordering the accesses of the transpose (LLVM AMDGPU memory model: LDS operations of one
-// wavefront are issued and complete in program order -- "ds" instructions return in order and lgkmcnt counts them
-// in order).  This holds only while a scratch area is touched by ONE wave: every transform below asserts that an
-// R-lane group never straddles a wave (64 % R == 0).  A/B check: build with -DMSL_LDS_ORDER_ONLY=0.
-#ifndef MSL_LDS_ORDER_ONLY
-#define MSL_LDS_ORDER_ONLY 1
-#endif
-// Ordering point between LDS phases of ONE wave (write a scratch, read it back transposed, write the next part ...).
-// The LDS executes the operations of a wave in issue order, so no wait is needed for correctness -- only the compiler
-// must not reorder the accesses: a scheduling barrier and a compiler memory barrier.  (With real wavefront-scope fences
-// every phase change costs a full s_waitcnt lgkmcnt(0); MSL_LDS_ORDER_ONLY=0 restores them.)
-__device__ __forceinline__ void wave_lds_fence() {
-#if MSL_LDS_ORDER_ONLY
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("" ::: "memory");
-#else
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#endif
-}
-
-// psi is read once and written once per pass: non-temporal ("nt") accesses mark the lines for early eviction, so they do not
-// push t_k, the tables and the other streams out of L2 / Infinity Cache (1024^2 x 64 probes: loads +0.3 %, stores +1.2 %,
-// both +2.0 % in a same-box A/B: 1 041 -> 1 020 us per launch of 256 images; 512^2 +2.8 %, 2048^2 and the TACAW time
-// transform unchanged, the chirp-z kernel for N <= 512 1.8 % slower: it keeps plain accesses).
-typedef float msl_f2v __attribute__((ext_vector_type(2)));
-typedef float msl_f4v __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float2 ld_stream(const float2* p) {
-    const msl_f2v t = __builtin_nontemporal_load(reinterpret_cast<const msl_f2v*>(p));
-    return make_float2(t.x, t.y);
-}
-__device__ __forceinline__ void st_stream(float2* p, float ax, float ay, float bx, float by) {     // two complex values, 16 bytes
-    const msl_f4v t = {ax, ay, bx, by};
-    __builtin_nontemporal_store(t, reinterpret_cast<msl_f4v*>(p));
-}
-
-// workgroup barrier that drains LDS traffic only (global loads/stores stay in flight across it)
-__device__ __forceinline__ void lds_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
 
 // Multiply v[j] (j = J0..R-1) by tab[j*R + ln] (conjugated when CONJ) in chunks of CH with a scheduling
 // barrier between chunks, so the compiler cannot hoist all R table loads at once (register pressure).  Every chunk
@@ -112,10 +63,10 @@ __device__ __forceinline__ void fourstep_split(float2 (&v)[R], float* scratch, c
 // register and runs at twice the rate of ds_write_b32 (128 B/clk: MI355X_MICROARCH.md, LDS).  The 64 / R line groups of a wave
 // share one scratch of R rows x 68 floats: row k1 holds the k1-th register of all 64 lanes (group g at columns [g R, (g+1) R)),
 // and lane (g, l) reads back row l, columns g R + n2, as R/4 ds_read_b128 (row pitch 68: 16-byte aligned, conflict-free).
-// wave_scratch: LDS address (bytes) of the wave's scratch, wave-uniform; M0 is not used by anything else in these kernels (the
-// s_mov declares its clobber; the stores that read it stay separate statements -- one asm block per 16 stores, self-contained with
-// its own s_mov, cost 0.7 % at 1024^2 and 1.8 % at 512^2 -- and tests/test_abi_and_host.py checks on the ISA that every write of
-// M0 in the library is one of these).
+// wave_scratch: LDS address (bytes) of the wave's scratch, wave-uniform; M0 is not used by anything else in these kernels, which
+// tests/test_abi_and_host.py checks on the ISA (every write of M0 in the library is one of these s_mov).  Declaring an "m0" clobber
+// draws clang's reserved-register diagnostic ("may lead to undefined behaviour"); one self-contained asm block per 16 stores, with
+// its own s_mov, cost 0.7 % at 1024^2 and 1.8 % at 512^2 -- so the statements stay as they are.
 template <int R, bool INV, int CH = 8>
 __device__ __forceinline__ void fourstep_split_addtid(float2 (&v)[R], const float* scratch_base, unsigned wave_scratch, const float2* tw, int ln, int lane64) {
     static_assert(64 % R == 0 && R % 4 == 0, "R-lane groups inside one wave; rows are read four floats at a time");
@@ -124,7 +75,7 @@ __device__ __forceinline__ void fourstep_split_addtid(float2 (&v)[R], const floa
     mul_table<R, 1, INV, R, CH>(v, tw, ln);
     const float* rd = scratch_base + ln * PW + (lane64 / R) * R;
     // (an s_mov to M0 needs a wait state before an add-tid LDS instruction; the hazard recogniser does not see into inline asm)
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 1" :: "s"(wave_scratch) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 1" :: "s"(wave_scratch) : "memory");
 #pragma unroll
     for (int k1 = 0; k1 < R; ++k1) asm volatile("ds_write_addtid_b32 %0 offset:%1" :: "v"(v[k1].x), "n"(k1 * PW * 4) : "memory");
     wave_lds_fence();
@@ -134,7 +85,7 @@ __device__ __forceinline__ void fourstep_split_addtid(float2 (&v)[R], const floa
         v[4 * g].x = q.x; v[4 * g + 1].x = q.y; v[4 * g + 2].x = q.z; v[4 * g + 3].x = q.w;
     }
     wave_lds_fence();
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 1" :: "s"(wave_scratch) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 1" :: "s"(wave_scratch) : "memory");
 #pragma unroll
     for (int k1 = 0; k1 < R; ++k1) asm volatile("ds_write_addtid_b32 %0 offset:%1" :: "v"(v[k1].y), "n"(k1 * PW * 4) : "memory");
     wave_lds_fence();
@@ -1502,13 +1453,13 @@ __device__ __forceinline__ void line2_transform(float2 (&v)[2 * R], float* scrat
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        { if constexpr (XM == 2) fourstep_split_addtid<R, false>(lo, wscr, wscr_lds, tw, ln, lane64); else if constexpr (XM == 1) fourstep_split_wide<R, false>(lo, scratch, tw, ln); else fourstep_split<R, false>(lo, scratch, tw, ln); }
+        { if constexpr (XM == 2) fourstep_split_addtid<R, false>(lo, wscr, wscr_lds, tw, ln, lane64); else fourstep_split<R, false>(lo, scratch, tw, ln); }
         __builtin_amdgcn_sched_barrier(0);
-        { if constexpr (XM == 2) fourstep_split_addtid<R, false>(hi, wscr, wscr_lds, tw, ln, lane64); else if constexpr (XM == 1) fourstep_split_wide<R, false>(hi, scratch, tw, ln); else fourstep_split<R, false>(hi, scratch, tw, ln); }
+        { if constexpr (XM == 2) fourstep_split_addtid<R, false>(hi, wscr, wscr_lds, tw, ln, lane64); else fourstep_split<R, false>(hi, scratch, tw, ln); }
     } else {
-        { if constexpr (XM == 2) fourstep_split_addtid<R, true>(lo, wscr, wscr_lds, tw, ln, lane64); else if constexpr (XM == 1) fourstep_split_wide<R, true>(lo, scratch, tw, ln); else fourstep_split<R, true>(lo, scratch, tw, ln); }
+        { if constexpr (XM == 2) fourstep_split_addtid<R, true>(lo, wscr, wscr_lds, tw, ln, lane64); else fourstep_split<R, true>(lo, scratch, tw, ln); }
         __builtin_amdgcn_sched_barrier(0);
-        { if constexpr (XM == 2) fourstep_split_addtid<R, true>(hi, wscr, wscr_lds, tw, ln, lane64); else if constexpr (XM == 1) fourstep_split_wide<R, true>(hi, scratch, tw, ln); else fourstep_split<R, true>(hi, scratch, tw, ln); }
+        { if constexpr (XM == 2) fourstep_split_addtid<R, true>(hi, wscr, wscr_lds, tw, ln, lane64); else fourstep_split<R, true>(hi, scratch, tw, ln); }
 #pragma unroll
         for (int c = 0; c < R; c += CH) {
             float2 w[CH];

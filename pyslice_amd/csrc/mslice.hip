@@ -18,6 +18,7 @@
 #include "reduce.h"
 #include "stream.h"
 #include "tacaw_time.h"
+#include "tacaw_launch.h"
 
 using namespace msl;
 
@@ -1174,59 +1175,15 @@ int fill_propagator(msl_handle* h) {
 
 }  // namespace
 
-// frame counts with a per-lane kernel: the 2-3-5-smooth numbers in [TDIR_MIN, TDIR_MAX]
-#define MSL_TDIR_LENGTHS(X) X(16) X(18) X(20) X(24) X(25) X(27) X(30) X(32) X(36) X(40) X(45) X(48) X(50) X(54) X(60) X(64) X(72) X(75) \
-    X(80) X(81) X(90) X(96) X(100) X(108) X(120) X(125) X(128)
-static bool time_direct_has(int T) { return T >= TDIR_MIN && T <= TDIR_MAX && fft_smooth(T); }
-template <int T>
-static int launch_time_direct_t(msl_handle* h, const TimeJob& j) {
-    static_assert(fft_smooth(T) && T >= TDIR_MIN && T <= TDIR_MAX, "no per-lane time kernel for this frame count");
-    const long long tiles = ((long long)(j.npix + 255) / 256) * j.n_images;
-    int per_cu = 1;                                  // 1 for the long lines (512 registers per lane), more for the short ones
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)time_direct_kernel<T>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
-    const int grid = (int)std::min<long long>(tiles, (long long)h->n_cus * per_cu);
-    hipLaunchKernelGGL((time_direct_kernel<T>), dim3(grid), dim3(256), 0, h->stream, j);
-    HIPCHK(h, hipGetLastError());
-    return mark_launch(h, K_OTHER);
-}
-// smooth frame counts 129 .. 512 as L x TP with TP <= 128: L = 2, else 4, else 6, else 3 or 5 (odd counts; two waves per SIMD from
-// L = 5 on: TP <= 100).  L = 2 and 4 put two blocks on the halves of a wave (HB = 2: 32-pixel tiles, workgroups of one or two
-// waves, two to four of them per CU -- independent workgroups cover each other's barriers: T = 500 0.56 -> 0.61, T = 300 0.49 ->
-// 0.62, T = 256 0.63 -> 0.69 in same-box A/Bs; L = 6 lost that way, 0.53 -> 0.42, and keeps a block per wave)
-#define MSL_TSPLIT_SHAPES(X) X(45, 3) X(75, 3) X(81, 3) X(45, 6) X(125, 3) X(81, 5) X(75, 6) X(81, 6)
-// ... and 513 .. 1024 as 8 x TP (else 6 x TP), two blocks per wave as well
-#define MSL_TSPLIT2_SHAPES(X) X(72, 2) X(75, 2) X(80, 2) X(81, 2) X(90, 2) X(96, 2) X(100, 2) X(108, 2) X(120, 2) X(125, 2) X(128, 2) \
-    X(72, 4) X(75, 4) X(80, 4) X(81, 4) X(90, 4) X(96, 4) X(100, 4) X(108, 4) X(120, 4) X(125, 4) X(128, 4) \
-    X(90, 6) X(72, 8) X(75, 8) X(80, 8) X(81, 8) X(90, 8) X(125, 6) X(96, 8) X(100, 8) X(108, 8) X(120, 8) X(125, 8) X(128, 8)
-static int time_split_waves(int T, int* hb = nullptr) {           // L (and the blocks per wave), or 0: no such kernel
-    if (hb) *hb = 1;
-    if (T <= TDIR_MAX || T > 1024 || !fft_smooth(T)) return 0;
-    if (T <= 512) {
-        for (int L : {2, 4, 6, 3, 5})
-            if (T % L == 0 && T / L <= TDIR_MAX && (L <= 4 || T / L <= 100)) { if (hb && L <= 4 && L % 2 == 0) *hb = 2; return L; }
-        return 0;
-    }
-    if (hb) *hb = 2;
-    for (int L : {8, 6})
-        if (T % L == 0 && T / L <= TDIR_MAX) return L;
-    return 0;
-}
-template <int TP, int L, int HB>
-static int launch_time_split_t(msl_handle* h, const TimeJob& j) {
-    const size_t lds = tsplit_lds_bytes(TP, L, HB);
-    const int threads = 64 * L / HB;
-    const long long tiles = ((long long)(j.npix + 64 / HB - 1) / (64 / HB)) * j.n_images;
-    (void)hipFuncSetAttribute((const void*)time_split_kernel<TP, L, HB>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
-    int per_cu = 1;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)time_split_kernel<TP, L, HB>, threads, lds) != hipSuccess || per_cu < 1) per_cu = 1;
-    const int grid = (int)std::min<long long>(tiles, (long long)h->n_cus * per_cu);
-    hipLaunchKernelGGL((time_split_kernel<TP, L, HB>), dim3(grid), dim3(threads), lds, h->stream, j);
+// The per-lane / wave-split time kernels (70 instantiations) are compiled in translation units of their own (tacaw_direct.hip,
+// tacaw_split.hip, tacaw_split2.hip: built in parallel with this file); tacaw_launch.h declares their launchers.
+static int launch_time_direct(msl_handle* h, const TimeJob& j) {
+    if (!time_direct_launch(j, h->n_cus, h->stream)) return fail(h, MSL_ERR_UNSUPPORTED, "no per-lane time kernel for %d frames", j.T);
     HIPCHK(h, hipGetLastError());
     return mark_launch(h, K_OTHER);
 }
 static int launch_time_split(msl_handle* h, TimeJob j) {
-    int HB = 1;
-    const int T = j.T, L = time_split_waves(T, &HB);
+    const int T = j.T;
     if (h->tsplit_T != T) {
         h->tsplit_T = 0;
         std::vector<float2> w(T);
@@ -1237,21 +1194,9 @@ static int launch_time_split(msl_handle* h, TimeJob j) {
         h->tsplit_T = T;
     }
     j.tw = h->tsplit_tw;
-#define X(tp, l) if (HB == 1 && T == (tp) * (l) && L == (l)) return launch_time_split_t<tp, l, 1>(h, j);
-    MSL_TSPLIT_SHAPES(X)
-#undef X
-#define X(tp, l) if (HB == 2 && T == (tp) * (l) && L == (l)) return launch_time_split_t<tp, l, 2>(h, j);
-    MSL_TSPLIT2_SHAPES(X)
-#undef X
-    return fail(h, MSL_ERR_UNSUPPORTED, "no wave-split time kernel for %d frames", T);
-}
-static int launch_time_direct(msl_handle* h, const TimeJob& j) {
-    switch (j.T) {
-#define X(n) case n: return launch_time_direct_t<n>(h, j);
-        MSL_TDIR_LENGTHS(X)
-#undef X
-    }
-    return fail(h, MSL_ERR_UNSUPPORTED, "no per-lane time kernel for %d frames", j.T);
+    if (!time_split_launch(j, h->n_cus, (size_t)h->lds_limit, h->stream)) return fail(h, MSL_ERR_UNSUPPORTED, "no wave-split time kernel for %d frames", T);
+    HIPCHK(h, hipGetLastError());
+    return mark_launch(h, K_OTHER);
 }
 
 extern "C" {

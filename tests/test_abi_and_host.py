@@ -135,10 +135,17 @@ def test_m0_is_only_touched_by_the_addtid_exchange(tmp_path):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not available")
-    out = tmp_path / "dev.s"
-    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "--cuda-device-only", "-S", "-o", str(out),
-                    os.path.join(REPO, "pyslice_amd", "csrc", "mslice.hip")], check=True, capture_output=True)
-    lines = [l.strip() for l in open(out)]
+    from concurrent.futures import ThreadPoolExecutor
+    from pyslice_amd.build_native import SOURCES
+
+    def device_asm(src):
+        out = tmp_path / (os.path.splitext(src)[0] + ".s")
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "--cuda-device-only", "-S", "-o", str(out),
+                        os.path.join(REPO, "pyslice_amd", "csrc", src)], check=True, capture_output=True)
+        return [l.strip() for l in open(out)]
+
+    with ThreadPoolExecutor(max_workers=len(SOURCES)) as pool:            # every translation unit of the library
+        lines = [l for part in pool.map(device_asm, SOURCES) for l in part]
     m0 = [i for i, l in enumerate(lines) if re.search(r"\bm0\b", l) and not l.startswith(";")]
     assert m0, "no add-tid exchange in the build?"
     for i in m0:
