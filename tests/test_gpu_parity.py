@@ -1254,6 +1254,44 @@ def test_tacaw_1024_frames_on_the_four_step_kernel(ps, shape):
     assert not np.array_equal(got, split) and rel_l2(got, split) < 2e-5
 
 
+@pytest.mark.parametrize("T", [100, 125, 200, 300, 375, 486, 500, 101, 1000, 1024])
+def test_tacaw_many_tiles_per_workgroup(ps, T):
+    """The time kernels are persistent: a workgroup walks over many tiles with the next tile's samples prefetched in registers
+    (rolling prefetch, alternating exchange buffers, the last tile prefetching itself).  The small parity cases give every
+    workgroup ONE tile; here 2 probes x 300 007 pixels (odd: unvectorised chirp-z path, ragged last tile everywhere) make 2 300 to
+    18 800 tiles for at most 1 024 workgroups -- one frame count per kernel family: per-lane (100; 125: partial prefetch), two
+    blocks per wave (200 = 2 x 100, 300 = 4 x 75, 500 = 4 x 125, 1000 = 8 x 125, 1024), one block per wave (375 = 3 x 125,
+    486 = 6 x 81), chirp-z (101).  Checked on 3 000 random pixels per probe against the float64 transform of the same float32
+    samples (strong-mean pixels included) and on ALL pixels through Parseval: sum_w I[w] = T sum_t |x_t - <x>|^2."""
+    import torch
+    from pyslice_amd import _native
+    P, npix = 2, 300007
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(T)
+    big = torch.randn((P, 1, npix, 2), generator=g, device=dev) * 1e2
+    big[:, :, ::3] = 0.0
+    src = torch.view_as_complex((big + torch.randn((P, T, npix, 2), generator=g, device=dev) * 1e-2).contiguous())
+    dst = torch.full((P, T, npix), -1.0, dtype=torch.float32, device=dev)
+    eng = _native.Engine(2, 2, 1, 1.0, 1.0, 1.0, 1.0, 0.0, n_probes=1, n_frames=0, device=0)
+    eng.tacaw(src.data_ptr(), dst.data_ptr(), P, T, npix)
+    eng.synchronize()
+    eng.close()
+    assert float(dst.min()) >= 0.0                                     # every element was written
+    assert float(dst[:, T // 2].max()) == 0.0
+    x64 = src.to(torch.complex128)
+    x64 = x64 - x64.mean(dim=1, keepdim=True)
+    want_sum = T * (x64.abs() ** 2).sum(dim=1)
+    got_sum = dst.to(torch.float64).sum(dim=1)
+    assert float(((got_sum - want_sum).abs() / want_sum).max()) < 2e-5
+    pick = torch.from_numpy(np.random.default_rng(T).choice(npix, 3000, replace=False)).to(dev)
+    pick[:4] = torch.tensor([0, 1, npix - 2, npix - 1], device=dev)
+    sub = x64[:, :, pick].cpu().numpy()
+    want = np.abs(np.fft.fftshift(np.fft.fft(sub, axis=1), axes=1)) ** 2
+    got = dst[:, :, pick].cpu().numpy().astype(np.float64)
+    err = np.linalg.norm(got - want, axis=1) / np.linalg.norm(want, axis=1)
+    assert err.max() < 5e-5, (T, err.max())
+
+
 TDIR_LENGTHS = [16, 18, 20, 24, 25, 27, 30, 32, 36, 40, 45, 48, 50, 54, 60, 64, 72, 75, 80, 81, 90, 96, 100, 108, 120, 125, 128]
 TSPLIT2_LENGTHS = [540, 576, 600, 640, 648, 720, 750, 768, 800, 864, 960, 1000, 1024]       # two blocks per wave
 TSPLIT_LENGTHS = [135, 144, 150, 160, 162, 180, 192, 200, 216, 225, 240, 243, 250, 256, 270, 288, 300, 320, 324, 360, 375, 384, 400, 405,
