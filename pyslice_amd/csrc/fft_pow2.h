@@ -1768,7 +1768,7 @@ struct IfftTBJob {
 
 // PAIR (second pass of the potential build: job.herm and job.potential set): the lines are spectra of REAL lines, so two of them
 // ride one complex transform, Z = X_a + i X_b -> V_a + i V_b -- half the transforms of this pass.  A group takes the lines
-// g and g + 16 of a 32-line block, so that each of the two store rounds still covers 16 neighbouring lines (128-byte runs).
+// g and g + 16 of a 32-line block; both leave through one 32-row tile round (256-byte runs).
 template <int R, bool PAIR = false>
 __global__ void __launch_bounds__(16 * R, (R == 32) ? 2 : 4) ifftTB_kernel(IfftTBJob job) {
     constexpr int M = R * R, H = R / 2, NH = M / 2, LINES = 16, NT = LINES * R, TCH = 8;
@@ -1788,9 +1788,14 @@ __global__ void __launch_bounds__(16 * R, (R == 32) ? 2 : 4) ifftTB_kernel(IfftT
     __syncthreads();
     const int grp = tid / R, ln = tid % R;
     const int li = tid % LINES, r0 = tid / LINES;             // store role: line li of the tile, positions r0 + POS_PER_IT * i
-    float2* myrow = tile + grp * CS;
-    const float* wscr = reinterpret_cast<const float*>(tile + (grp - grp % (64 / R)) * CS);
-    const unsigned wscr_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(tile + (grp - grp % (64 / R)) * CS));
+    // PAIR: a 32-row tile of the N <= 512 positions (pitch CSP), row 2 g + h = line g + 16 h -- both lines leave in ONE round of
+    // 256-byte runs, and a wave's four contiguous rows hold its exchange scratch (ifftTB_two_kernel's layout)
+    constexpr int CSP = NH + 2;
+    static_assert(!PAIR || (R == 32 && 4 * CSP >= R * 68 / 2), "paired lines: 1024-point transforms only");
+    float2* myrow = PAIR ? tile + (2 * grp) * CSP : tile + grp * CS;
+    float2* const wtile = PAIR ? tile + (4 * (grp / 2)) * CSP : tile + (grp - grp % (64 / R)) * CS;
+    const float* wscr = reinterpret_cast<const float*>(wtile);
+    const unsigned wscr_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)wtile);
     const float2* fa = bf + ln;
     const float2* fb = bf - ln;
     const int lblocks = (job.n_lines + BL - 1) / BL;
@@ -1904,13 +1909,31 @@ __global__ void __launch_bounds__(16 * R, (R == 32) ? 2 : 4) ifftTB_kernel(IfftT
             }
             continue;
         }
-#pragma unroll
-        for (int half = 0; half < (PAIR ? 2 : 1); ++half) {
+        if constexpr (PAIR) {
             wave_lds_fence();
 #pragma unroll
-            for (int j = 0; j < H; ++j) myrow[j * R + ln] = v[half * H + j];
+            for (int j = 0; j < H; ++j) { myrow[j * R + ln] = v[j]; myrow[CSP + j * R + ln] = v[H + j]; }
             lds_barrier();
-            const int col = lb * BL + half * LINES + li;
+            const int l32 = tid % BL;
+            int p0 = tid / BL;                                  // (laundered: 32 row offsets of 64 bits would be kept across the loop)
+            asm volatile("" : "+v"(p0));
+            const int col = lb * BL + l32;
+            if (col < job.n_lines) {
+                float2* dst = job.out_t + (long long)img * job.out_t_is + col;
+                const float2* srow = tile + (2 * (l32 & 15) + (l32 >> 4)) * CSP;
+#pragma unroll
+                for (int i = 0; i < NH / (NT / BL); ++i) {
+                    const int pos = p0 + (NT / BL) * i;
+                    if (pos < N) dst[(long long)pos * job.out_t_pitch] = srow[pos];
+                }
+            }
+            lds_barrier();
+        } else {
+            wave_lds_fence();
+#pragma unroll
+            for (int j = 0; j < H; ++j) myrow[j * R + ln] = v[j];
+            lds_barrier();
+            const int col = lb * BL + li;
             if (col < job.n_lines) {
                 float2* dst = job.out_t + (long long)img * job.out_t_is + col;
 #pragma unroll
@@ -1921,6 +1944,123 @@ __global__ void __launch_bounds__(16 * R, (R == 32) ? 2 : 4) ifftTB_kernel(IfftT
             }
             lds_barrier();
         }
+    }
+}
+
+// First pass of the potential build (no epilogue) with TWO lines per group and item: ifftTB_kernel spends one tile round -- write,
+// barrier, 16 x (LDS read + store), barrier -- per transform, twice the share it has in the slice-loop kernels with their four
+// transforms per line, and its vector pipe idles half the time (50 % busy against rowTB_pass_kernel's 82 %, profiles/r03_*).  Here
+// a group transforms line g, parks the 16 result registers, transforms line g + 16, and ONE round stores the 32-line tile: 256-byte
+// runs, half the barriers per line.  Tile rows hold the N <= 512 positions only (pitch 514); row 2 g + h is line g + 16 h, so that a
+// wave's four rows are contiguous and hold its exchange scratch without reaching into another wave's rows.  Line a of the next
+// item is prefetched before the first transform, line b once the results are in the tile (it is needed a whole transform later).
+__global__ void __launch_bounds__(512, 2) ifftTB_two_kernel(IfftTBJob job) {
+    constexpr int R = 32, M = R * R, H = R / 2, NH = M / 2, GROUPS = 16, BL = 32, NT = GROUPS * R, TCH = 8;
+    constexpr int CSN = NH + 2;                               // tile row pitch (float2): 2 mod 32, as the 16-line tiles' 1058
+    constexpr int POS_PER_IT = NT / BL, NIT = NH / POS_PER_IT;          // one thread per (position, line): 16 positions per sweep
+    static_assert(4 * CSN >= R * 68 / 2, "a wave's four tile rows hold its exchange scratch (R rows x 68 floats)");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float2* tw = reinterpret_cast<float2*>(smem_raw);         // M
+    float2* bf = tw + M;                                      // NH + 2
+    float2* bw = bf + NH + 2;                                 // NH
+    float2* tile = bw + NH;                                   // BL * CSN
+    const int tid = threadIdx.x;
+    const int N = job.n_line;
+    for (int i = tid; i < M; i += NT) tw[i] = job.tw[i];
+    for (int i = tid; i <= NH; i += NT) bf[i] = job.bf[i];
+    for (int i = tid; i < NH; i += NT) bw[i] = job.bw[i];
+    __syncthreads();
+    const int grp = tid / R, ln = tid % R;
+    const int li = tid % BL, r0 = tid / BL;                   // store role: line li of the block, positions r0 + 16 i
+    float2* rowa = tile + (2 * grp) * CSN;                    // my two rows: lines grp and grp + 16
+    const float* wscr = reinterpret_cast<const float*>(tile + (4 * (grp / 2)) * CSN);
+    const unsigned wscr_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(tile + (4 * (grp / 2)) * CSN));
+    const float2* fa = bf + ln;
+    const float2* fb = bf - ln;
+    const int lblocks = (job.n_lines + BL - 1) / BL;
+    const int n_items = lblocks * job.n_images;
+    float2 vna[H], vnb[H];
+    auto load_line = [&](int it, int h, float2 (&dst)[H]) {
+        const int img = it / lblocks, lb = it - img * lblocks;
+        const int L = min(lb * BL + h * GROUPS + grp, job.n_lines - 1);      // surplus lines of the last block repeat the last one
+        const float2* src = job.in + (long long)img * job.in_is + (long long)L * job.in_pitch;
+        const int hx = job.herm ? N / 2 : N;
+        int lnl = ln;                                       // laundered: the 16 element indices are the same for every item, and
+        asm volatile("" : "+v"(lnl));                       // the compiler would keep them all in registers across the loop (and spill)
+#pragma unroll
+        for (int j = 0; j < H; ++j) {
+            const int e = j * R + lnl;
+            float2 x = (e < N) ? src[e <= hx ? e : N - e] : make_float2(0.f, 0.f);
+            if (e > hx) x.y = -x.y;
+            dst[j] = x;
+        }
+    };
+    if ((int)blockIdx.x < n_items) { load_line(blockIdx.x, 0, vna); load_line(blockIdx.x, 1, vnb); }
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int img = item / lblocks, lb = item - img * lblocks;
+        // (the last item of a workgroup prefetches itself again: a conditional load would keep the old registers alive as the other
+        // arm of the merge)
+        const int nitem = item + (int)gridDim.x < n_items ? item + (int)gridDim.x : item;
+        float2 v[R];
+        auto mul_chirp = [&]() {
+#pragma unroll
+            for (int c = 0; c < H; c += TCH) {
+                float2 w[TCH];
+#pragma unroll
+                for (int j = 0; j < TCH; ++j) w[j] = bw[(c + j) * R + ln];
+#pragma unroll
+                for (int j = 0; j < TCH; ++j) v[c + j] = cmulf_conj(v[c + j], w[j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int j = H; j < R; ++j) v[j] = make_float2(0.f, 0.f);
+        };
+        auto transform = [&]() __attribute__((always_inline)) {
+            mul_chirp();
+            fourstep_split_addtid<R, false, TCH>(v, wscr, wscr_lds, tw, ln, tid & 63);
+#pragma unroll
+            for (int c = 0; c < R; c += TCH) {
+                float2 w[TCH];
+#pragma unroll
+                for (int j = 0; j < TCH; ++j) w[j] = (c + j < H) ? fa[(c + j) * R] : fb[(R - (c + j)) * R];
+#pragma unroll
+                for (int j = 0; j < TCH; ++j) v[c + j] = cmulf_conj(v[c + j], w[j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            fourstep_split_addtid<R, true, TCH>(v, wscr, wscr_lds, tw, ln, tid & 63);
+            mul_chirp();
+        };
+#pragma unroll
+        for (int j = 0; j < H; ++j) v[j] = vna[j];
+        __builtin_amdgcn_sched_barrier(0);
+        load_line(nitem, 0, vna);
+        __builtin_amdgcn_sched_barrier(0);
+        transform();
+        float2 pa[H];
+#pragma unroll
+        for (int j = 0; j < H; ++j) { pa[j] = v[j]; v[j] = vnb[j]; }
+        __builtin_amdgcn_sched_barrier(0);
+        transform();
+        wave_lds_fence();
+#pragma unroll
+        for (int j = 0; j < H; ++j) { rowa[j * R + ln] = pa[j]; rowa[CSN + j * R + ln] = v[j]; }
+        __builtin_amdgcn_sched_barrier(0);
+        load_line(nitem, 1, vnb);                           // (needed a whole transform from now)
+        __builtin_amdgcn_sched_barrier(0);
+        lds_barrier();
+        const int col = lb * BL + li;
+        if (col < job.n_lines) {
+            float2* dst = job.out_t + (long long)img * job.out_t_is + col;
+            const float2* srow = tile + (2 * (li & 15) + (li >> 4)) * CSN;
+            int r0v = r0;                                   // (laundered like the lane index above: 32 row offsets of 64 bits)
+            asm volatile("" : "+v"(r0v));
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) {
+                const int pos = r0v + POS_PER_IT * i;
+                if (pos < N) dst[(long long)pos * job.out_t_pitch] = srow[pos];
+            }
+        }
+        lds_barrier();
     }
 }
 

@@ -1820,6 +1820,18 @@ static int build_potentials(msl_handle* h, const double* pos, const int32_t* Z, 
                 const int R = o.R, M = R * R, NH = M / 2, CS = R * (R + 1) + 2;
                 const size_t lds = ((size_t)M + NH + 2 + NH + (size_t)16 * CS) * 8;
                 const int per_cu = std::max(1, std::min(R == 16 ? 4 : 1, (int)((size_t)h->lds_limit / lds)));
+                // first pass (no epilogue): two lines per group and tile round
+                if (R == 32 && !j.potential && !dbg_env("MSL_NO_TWO_LINE_IFFT")) {
+                    constexpr int CSN = 514;
+                    const size_t lds2 = ((size_t)M + NH + 2 + NH + (size_t)32 * CSN) * 8;
+                    const long long items2 = (long long)((j.n_lines + 31) / 32) * j.n_images;
+                    const int grid2 = (int)std::min<long long>(items2, (long long)h->n_cus);
+                    j.tw = o.tw; j.bf = o.bf; j.bw = o.bw;
+                    (void)hipFuncSetAttribute((const void*)ifftTB_two_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
+                    hipLaunchKernelGGL(ifftTB_two_kernel, dim3(grid2), dim3(512), lds2, h->stream, j);
+                    HIPCHK(h, hipGetLastError());
+                    return mark_launch(h, K_OTHER);
+                }
                 // second pass on a half spectrum: two real lines per transform (32-line work items)
                 const bool pair = R == 32 && j.herm && j.potential && !dbg_env("MSL_NO_PAIRED_IFFT");
                 const long long items = (long long)((j.n_lines + (pair ? 31 : 15)) / (pair ? 32 : 16)) * j.n_images;

@@ -157,7 +157,7 @@ def test_m0_is_only_touched_by_the_addtid_exchange(tmp_path):
     text = "\n".join(lines)
     shipped = ["rowT_pass_kernelILi32ELi16E", "rowT_pass_kernelILi16ELi16E", "rowT2_pass_kernelILi16E", "rowTW_pass_kernelILb1ELb1E",
                "rowTB_pass_kernelILi32E", "rowTB_pass_kernelILi16E", "rowTB2_pass_kernelILb0ELb0E", "rowTC2_pass_kernel",
-               "ifftTB_kernelILi32ELb0E", "ifftTB_kernelILi32ELb1E", "ifftTB_kernelILi16ELb0E", "ifftTB2_kernel", "ifftTW_kernel",
+               "ifftTB_kernelILi32ELb0E", "ifftTB_kernelILi32ELb1E", "ifftTB_kernelILi16ELb0E", "ifftTB_two_kernel", "ifftTB2_kernel", "ifftTW_kernel",
                "ifftT2_kernelILi16ELb0E", "ifftT2_kernelILi16ELb1E",
                "structure_factor_quad_kernel", "structure_factor_stream_kernel", "structure_factor_edge_kernel", "col_pass_kernelILi32ELi16ELb1E",
                "time_cz_kernelILi16ELi32ELb1E", "time_cz_kernelILi32ELi16ELb1E", "time_cz_kernelILi16ELi32ELb0E", "time_cz_kernelILi32ELi16ELb0E", "tacaw_fold_kernel", "row_pass_pf_kernelILi32E", "row_pass2_kernelILi32E"]
