@@ -244,6 +244,11 @@ int  msl_adf(msl_handle* h, const void* d_src_c64, int64_t B, int64_t T, int64_t
 /* Copy a device buffer to the host (dst must hold `bytes` = full buffer size, see msl_buffer_bytes).
  * For MSL_BUF_WAVEFUNCTION `first`/`count` select a probe range (count==0: all). */
 int  msl_download(msl_handle* h, msl_buffer what, void* dst, size_t bytes, int64_t first, int64_t count);
+/* The (P, T_local, nx, ny) result as complex128 -- the dtype the reference returns (calculators.py:161, 284-290: its arrays are
+ * torch.complex128) -- for the frames [0, n_frames_used) of every probe: widened on the device chunk by chunk and copied out as
+ * 16 B per element, instead of a complex64 download followed by a single-threaded astype on the host.
+ * dst_c128: host, n_probes * n_frames_used * wx * wy complex128. */
+int  msl_download_wavefunction_c128(msl_handle* h, int32_t n_frames_used, void* dst_c128, size_t bytes);
 size_t msl_buffer_bytes(const msl_handle* h, msl_buffer what);
 /* Raw device pointer of a library buffer, for zero-copy use by the caller's collective (RCCL). */
 void* msl_device_ptr(msl_handle* h, msl_buffer what);

@@ -21,7 +21,7 @@ EXPORTS = [
     "msl_abi_version", "msl_last_error", "msl_create", "msl_destroy", "msl_set_kirkland", "msl_set_slices",
     "msl_set_beam", "msl_resize_probes", "msl_set_probes", "msl_upload_probes", "msl_shift_probes",
     "msl_build_potential", "msl_upload_potential", "msl_propagate", "msl_propagate_frame", "msl_tacaw",
-    "msl_download", "msl_download_frame", "msl_upload_frame", "msl_buffer_bytes", "msl_device_ptr", "msl_synchronize",
+    "msl_download", "msl_download_wavefunction_c128", "msl_download_frame", "msl_upload_frame", "msl_buffer_bytes", "msl_device_ptr", "msl_synchronize",
     "msl_get_counters",
     "msl_reset_counters", "msl_fft2_host",
     "msl_tacaw_spectrum", "msl_tacaw_spectrum_weighted", "msl_tacaw_diffraction", "msl_tacaw_dispersion", "msl_adf",
@@ -84,6 +84,7 @@ def load():
         "msl_tacaw": (C.c_int, [vp, vp, vp, i64, i32, i64]),
         "msl_download": (C.c_int, [vp, C.c_int, vp, C.c_size_t, i64, i64]),
         "msl_download_frame": (C.c_int, [vp, i32, vp, C.c_size_t]),
+        "msl_download_wavefunction_c128": (C.c_int, [vp, i32, vp, C.c_size_t]),
         "msl_upload_frame": (C.c_int, [vp, i32, vp, C.c_size_t]),
         "msl_buffer_bytes": (C.c_size_t, [vp, C.c_int]),
         "msl_device_ptr": (vp, [vp, C.c_int]),
@@ -389,6 +390,13 @@ class Engine:
     def wavefunction(self, first=0, count=0):
         n = count if count else self.n_probes
         return self.download(BUF_WAVEFUNCTION, np.complex64, (n, self.n_frames, self.wx, self.wy), first, count)
+
+    def wavefunction_c128(self, n_frames_used=0):
+        """(P, n_frames_used, wx, wy) complex128: the reference's result dtype, widened on the device (no host astype)"""
+        T = int(n_frames_used) if n_frames_used else self.n_frames
+        out = np.empty((self.n_probes, T, self.wx, self.wy), dtype=np.complex128)
+        self._chk(self._lib.msl_download_wavefunction_c128(self._h, T, _ptr(out), out.nbytes))
+        return out
 
     def frame(self, slot):
         out = np.empty((self.n_probes, self.wx, self.wy), dtype=np.complex64)

@@ -2548,6 +2548,36 @@ static int frame_copy(msl_handle* h, int32_t slot, void* host, size_t bytes, boo
     return MSL_OK;
 }
 
+int msl_download_wavefunction_c128(msl_handle* h, int32_t n_frames_used, void* dst, size_t bytes) {
+    if (!h || !dst) return fail(h, MSL_ERR_INVALID, "msl_download_wavefunction_c128: null argument");
+    const msl_config& c = h->cfg;
+    if (!h->wf) return fail(h, MSL_ERR_STATE, "msl_download_wavefunction_c128: no wavefunction buffer");
+    if (n_frames_used < 1 || n_frames_used > c.n_frames) return fail(h, MSL_ERR_INVALID, "msl_download_wavefunction_c128: %d of %d frames", n_frames_used, c.n_frames);
+    const size_t per_probe = (size_t)n_frames_used * h->wpix;
+    if (bytes != (size_t)c.n_probes * per_probe * sizeof(double2))
+        return fail(h, MSL_ERR_INVALID, "msl_download_wavefunction_c128: dst holds %zu bytes, the result has %zu", bytes, (size_t)c.n_probes * per_probe * sizeof(double2));
+    HIPCHK(h, hipSetDevice(c.device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    // chunks of at most 256 MB of complex128 through the scratch buffer, probe by probe (a probe's used frames are contiguous)
+    size_t chunk = std::min<size_t>(per_probe, (size_t)(256u << 20) / sizeof(double2));
+    if (const char* e = dbg_env("MSL_C128_CHUNK")) chunk = std::max<size_t>(1, std::min<size_t>(chunk, (size_t)atoll(e)));      // (tests: several chunks per probe)
+    int rc = ensure_scratch(h, chunk * sizeof(double2));
+    if (rc) return rc;
+    for (int p = 0; p < c.n_probes; ++p) {
+        const float2* src = h->wf + (size_t)p * c.n_frames * h->wpix;
+        double2* out = (double2*)dst + (size_t)p * per_probe;
+        for (size_t o = 0; o < per_probe; o += chunk) {
+            const size_t n = std::min(chunk, per_probe - o);
+            const int grid = (int)std::min<size_t>((n + 255) / 256, (size_t)h->n_cus * 8);
+            hipLaunchKernelGGL(widen_c64_kernel, dim3(grid), dim3(256), 0, h->stream, src + o, (double2*)h->scratch, (long long)n);
+            HIPCHK(h, hipGetLastError());
+            HIPCHK(h, hipMemcpyAsync(out + o, h->scratch, n * sizeof(double2), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+        }
+    }
+    return MSL_OK;
+}
+
 int msl_download_frame(msl_handle* h, int32_t slot, void* dst, size_t bytes) { return frame_copy(h, slot, dst, bytes, true); }
 int msl_upload_frame(msl_handle* h, int32_t slot, const void* src, size_t bytes) { return frame_copy(h, slot, const_cast<void*>(src), bytes, false); }
 

@@ -146,4 +146,12 @@ __global__ void __launch_bounds__(256) gather_k_kernel(const float* __restrict__
     out[t] = src[row * K + idx[i]];
 }
 
+// complex64 -> complex128 (msl_download_wavefunction_c128)
+__global__ void __launch_bounds__(256) widen_c64_kernel(const float2* __restrict__ src, double2* __restrict__ dst, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float2 v = src[i];
+        dst[i] = make_double2((double)v.x, (double)v.y);
+    }
+}
+
 }  // namespace msl

@@ -1336,6 +1336,29 @@ def test_tacaw_smooth_frame_counts_on_the_per_lane_kernel(ps, shape):
             assert rel_l2(got, cz) < 2e-5, T
 
 
+def test_result_download_as_complex128(ps):
+    """msl_download_wavefunction_c128: the (P, T, nx, ny) result in the reference's dtype, widened on the device -- equal, bit for
+    bit, to the complex64 download cast on the host; a prefix of the frame slots; several chunks per probe (debug chunk size)."""
+    from pyslice_amd import _native
+    rng = np.random.default_rng(11)
+    eng = _native.Engine(12, 10, 1, 0.1, 0.1, 0.5, 0.037, 1e-3, n_probes=3, n_frames=5)
+    frames = (rng.standard_normal((3, 5, 12, 10)) + 1j * rng.standard_normal((3, 5, 12, 10))).astype(np.complex64)
+    for t in range(5):
+        eng.upload_frame(t, frames[:, t])
+    full = eng.wavefunction_c128()
+    assert full.dtype == np.complex128 and np.array_equal(full, frames.astype(np.complex128))
+    os.environ["MSL_DEBUG"] = "1"
+    os.environ["MSL_C128_CHUNK"] = "77"
+    try:
+        part = eng.wavefunction_c128(4)
+    finally:
+        del os.environ["MSL_C128_CHUNK"], os.environ["MSL_DEBUG"]
+    assert part.shape == (3, 4, 12, 10) and np.array_equal(part, frames[:, :4].astype(np.complex128))
+    with pytest.raises(ValueError):                       # (MSL_ERR_INVALID: more frames than slots)
+        eng.wavefunction_c128(6)
+    eng.close()
+
+
 def test_result_release_returns_the_device_memory(ps, orc):
     """A WFData from run() keeps the engine (and every device buffer of the run) alive so that TACAWData can work on the resident
     spectra; release() drops that hold: the device memory comes back while the host arrays stay usable -- TACAWData then stages
