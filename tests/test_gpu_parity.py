@@ -1272,6 +1272,7 @@ def test_tacaw_many_tiles_per_workgroup(ps, T):
     big[:, :, ::3] = 0.0
     src = torch.view_as_complex((big + torch.randn((P, T, npix, 2), generator=g, device=dev) * 1e-2).contiguous())
     dst = torch.full((P, T, npix), -1.0, dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()                                           # (torch's stream filled src / dst; the library has its own)
     eng = _native.Engine(2, 2, 1, 1.0, 1.0, 1.0, 1.0, 0.0, n_probes=1, n_frames=0, device=0)
     eng.tacaw(src.data_ptr(), dst.data_ptr(), P, T, npix)
     eng.synchronize()
