@@ -554,14 +554,18 @@ def _tacaw_kernel_name(T, npix):
         while n % p == 0:
             n //= p
     smooth = n == 1
-    if T == 1024 and npix % 16 == 0 and npix >= 32 and 129 * npix * 8 >= 2 ** 32:
-        return "four-step time FFT (32 x 32 lanes x registers)"
     if smooth and 16 <= T <= 128:
         return "per-lane mixed-radix register FFT (time_direct_kernel)"
     if smooth and 128 < T <= 512 and 65 * npix * 8 < 2 ** 32 and any(T % L == 0 and T // L <= 128 and (L <= 4 or T // L <= 100) for L in (2, 3, 4, 5, 6)):
         return "mixed-radix register FFT split over the waves of a workgroup (time_split_kernel)"
-    if smooth and 512 < T <= 1024 and 129 * npix * 8 < 2 ** 32 and any(T % L == 0 and T // L <= 128 for L in (6, 8)):
-        return "mixed-radix register FFT split over the waves of a workgroup, two blocks per wave (time_split_kernel)"
+    if smooth and 512 < T <= 1024:
+        for L in (8, 6):
+            if T % L == 0 and T // L <= 128:
+                if (T // L + (T // L + 1) // 2) * npix * 8 < 2 ** 32:
+                    return "mixed-radix register FFT split over the waves of a workgroup, two blocks per wave (time_split_kernel)"
+                break
+    if T == 1024 and npix % 16 == 0 and npix >= 32:
+        return "four-step time FFT (32 x 32 lanes x registers)"
     return "chirp-z on the register FFTs" if T <= 512 else "generic LDS kernel"
 
 

@@ -2065,10 +2065,11 @@ int msl_tacaw(msl_handle* h, const void* d_src, void* d_dst, int64_t batch, int3
     if (T < 2) return fail(h, MSL_ERR_INVALID, "msl_tacaw: needs at least 2 frames (got %d)", T);
     if (batch < 1 || npix < 1) return fail(h, MSL_ERR_INVALID, "msl_tacaw: bad batch/npix");
     if (npix > 0x7fffffffLL) return fail(h, MSL_ERR_UNSUPPORTED, "msl_tacaw: npix too large");
-    // smooth counts up to 1024: the register network split over the waves of a workgroup (time_split_kernel); above 512 frames a
-    // wave holds two blocks and reaches the second through the 32-bit lane offset (pixel + TP rows), which bounds the image size
-    const bool split_t = c.fft_path == 0 && time_split_waves(T) > 0
-                         && (unsigned long long)(T > 512 ? TDIR_MAX + 1 : 65) * (unsigned long long)npix * 8ull < (1ull << 32)
+    // smooth counts up to 1024: the register network split over the waves of a workgroup (time_split_kernel)
+    // 32-bit offsets: the buffer unit adds the lane offset and the scalar row offset in 32 bits (measured: the sum wraps) --
+    // pixel + up to 64 rows with one block per wave, pixel + TP + (TP + 1) / 2 rows with two; time_split_launch falls back from the
+    // two-block shape to the one-block shape of the same L where there is one (L = 2, 4: up to 512 frames)
+    const bool split_t = c.fft_path == 0 && time_split_fits(T, npix)
                          && !dbg_env("MSL_TACAW_GENERIC") && !dbg_env("MSL_TACAW_CHIRPZ") && !(T == 1024 && dbg_env("MSL_TACAW_FOURSTEP"));
     // 1024 frames of images too large for that: the four-step column kernel (it served 256 and 1024 frames until the split kernel
     // overtook it: T = 256, 64 probes x 1024^2 40.2 -> 39.7 ms, 16 x 2048^2 44.7 -> 40.7 ms; T = 1024, 8 x 1024^2 33.7 -> 29.3 ms)

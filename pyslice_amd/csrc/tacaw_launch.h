@@ -10,6 +10,7 @@ namespace msl {
 // is there a kernel for T frames?
 bool time_direct_has(int T);                          // 2-3-5-smooth, TDIR_MIN <= T <= TDIR_MAX
 int time_split_waves(int T, int* hb = nullptr);       // L of the T = L x TP shape (and the blocks per wave), or 0
+bool time_split_fits(int T, long long npix);          // ... and do the 32-bit row offsets of one of its kernels cover an image of npix pixels?
 
 // launch on `stream`; false: no kernel for job.T (nothing launched).  Errors of the launch itself: hipGetLastError().
 bool time_direct_launch(const TimeJob& job, int n_cus, hipStream_t stream);

@@ -10,6 +10,9 @@ namespace msl {
 // T = 300 0.49 -> 0.62, T = 256 0.63 -> 0.69 in same-box A/Bs; L = 6 lost that way, 0.53 -> 0.42, and keeps a block per wave).
 // 513 .. 1024 as 8 x TP (else 6 x TP), two blocks per wave as well.
 #define MSL_TSPLIT_SHAPES(X) X(45, 3) X(75, 3) X(81, 3) X(45, 6) X(125, 3) X(81, 5) X(75, 6) X(81, 6)
+// one block per wave for the 2 x TP / 4 x TP shapes too: images beyond the two-block kernels' offset range (2048^2 ...)
+#define MSL_TSPLIT_BIG_SHAPES(X) X(72, 2) X(75, 2) X(80, 2) X(81, 2) X(90, 2) X(96, 2) X(100, 2) X(108, 2) X(120, 2) X(125, 2) X(128, 2) \
+    X(72, 4) X(75, 4) X(80, 4) X(81, 4) X(90, 4) X(96, 4) X(100, 4) X(108, 4) X(120, 4) X(125, 4) X(128, 4)
 
 int time_split_waves(int T, int* hb) {           // L (and the blocks per wave), or 0: no such kernel
     if (hb) *hb = 1;
@@ -25,11 +28,31 @@ int time_split_waves(int T, int* hb) {           // L (and the blocks per wave),
     return 0;
 }
 
+// The buffer unit adds the lane offset and the scalar row offset in 32 bits (the sum wraps: measured).  One block per wave: pixel
+// + up to 64 rows; two blocks: pixel + TP rows to the second block + up to (TP + 1) / 2 - 1 rows.
+static bool fits_one(long long npix) { return 65ull * (unsigned long long)npix * 8ull < (1ull << 32); }
+static bool fits_two(int TP, long long npix) { return (unsigned long long)(TP + (TP + 1) / 2) * (unsigned long long)npix * 8ull < (1ull << 32); }
+
+bool time_split_fits(int T, long long npix) {
+    int HB = 1;
+    const int L = time_split_waves(T, &HB);
+    if (!L) return false;
+    if (HB == 1) return fits_one(npix);
+    return fits_two(T / L, npix) || (T <= 512 && fits_one(npix));
+}
+
 bool time_split_launch(const TimeJob& j, int n_cus, size_t lds_limit, hipStream_t stream) {
     int HB = 1;
     const int T = j.T, L = time_split_waves(T, &HB);
     if (!L) return false;
-    if (HB == 2) return time_split2_launch(j, L, n_cus, lds_limit, stream);
+    if (HB == 2 && fits_two(T / L, j.npix)) return time_split2_launch(j, L, n_cus, lds_limit, stream);
+    if (!fits_one(j.npix)) return false;
+    if (HB == 2) {
+#define X(tp, l) if (T == (tp) * (l) && L == (l)) return launch_split_t<tp, l, 1>(j, n_cus, lds_limit, stream);
+        MSL_TSPLIT_BIG_SHAPES(X)
+#undef X
+        return false;
+    }
 #define X(tp, l) if (T == (tp) * (l) && L == (l)) return launch_split_t<tp, l, 1>(j, n_cus, lds_limit, stream);
     MSL_TSPLIT_SHAPES(X)
 #undef X

@@ -171,10 +171,10 @@ def test_m0_is_only_touched_by_the_addtid_exchange(tmp_path):
         vgpr = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1))
         assert scratch == 0, (name, scratch)
         assert vgpr <= (512 if name == "structure_factor_stream_kernel" else 256), (name, vgpr)     # (one wave per SIMD by design)
-    # the per-lane / wave-split time transforms (70 instantiations): one wave per SIMD where the line needs the 512-register file,
+    # the per-lane / wave-split time transforms (92 instantiations): one wave per SIMD where the line needs the 512-register file,
     # never private memory
     timek = re.findall(r"\.amdhsa_kernel (_ZN3msl\d+time_(?:direct|split)_kernel\S*)(.*?)\.end_amdhsa_kernel", text, re.S)
-    assert len(timek) == 70, len(timek)
+    assert len(timek) == 92, len(timek)
     for name, body in timek:
         assert int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1)) == 0, name
         assert int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1)) <= 512, name

@@ -1293,6 +1293,41 @@ def test_tacaw_many_tiles_per_workgroup(ps, T):
     assert err.max() < 5e-5, (T, err.max())
 
 
+@pytest.mark.parametrize("T,npix", [(100, 10_700_001), (375, 8_259_001), (500, 2_855_001), (500, 2_857_000), (500, 8_259_001),
+                                    (256, 2048 * 2048), (1000, 2_855_001), (1000, 2_857_000)])
+def test_tacaw_row_offsets_near_the_32_bit_limit(ps, T, npix):
+    """The mixed-radix time kernels address a row as descriptor base + 32-bit offsets; msl_tacaw hands them only images whose
+    offsets fit and everything else to the kernels with 64-bit addressing (the buffer unit adds lane offset and scalar offset in
+    32 bits: the first version of this test caught the sum wrapping).  One probe, pixel counts just below each limit
+    ((T + 1) / 2 rows for the per-lane kernel, 65 rows for one block per wave, TP + (TP + 1) / 2 rows for two blocks per wave) and
+    just above (T = 500: the one-block shape of the same L, again up to its own limit, as at 256 frames of a 2048^2 grid; T = 1000:
+    the generic LDS kernel): 3 000 random pixels -- the last ones of the image among them, where an overflow would wrap -- against
+    the float64 transform, and every element written."""
+    import torch
+    from pyslice_amd import _native
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(T + npix)
+    src = torch.randn((1, T, npix, 2), generator=g, device=dev) * 1e-2
+    src = torch.view_as_complex(src)
+    dst = torch.full((1, T, npix), -1.0, dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    eng = _native.Engine(2, 2, 1, 1.0, 1.0, 1.0, 1.0, 0.0, n_probes=1, n_frames=0, device=0)
+    eng.tacaw(src.data_ptr(), dst.data_ptr(), 1, T, npix)
+    eng.synchronize()
+    eng.close()
+    assert float(dst.min()) >= 0.0
+    pick = torch.from_numpy(np.random.default_rng(T).choice(npix, 3000, replace=False)).to(dev)
+    pick[:6] = torch.tensor([0, 1, 31, npix - 33, npix - 2, npix - 1], device=dev)
+    sub = src[:, :, pick].to(torch.complex128).cpu().numpy()
+    sub = sub - sub.mean(axis=1, keepdims=True)
+    want = np.abs(np.fft.fftshift(np.fft.fft(sub, axis=1), axes=1)) ** 2
+    got = dst[:, :, pick].cpu().numpy().astype(np.float64)
+    del src, dst
+    torch.cuda.empty_cache()
+    err = np.linalg.norm(got - want, axis=1) / np.linalg.norm(want, axis=1)
+    assert err.max() < 5e-5, (T, npix, err.max())
+
+
 TDIR_LENGTHS = [16, 18, 20, 24, 25, 27, 30, 32, 36, 40, 45, 48, 50, 54, 60, 64, 72, 75, 80, 81, 90, 96, 100, 108, 120, 125, 128]
 TSPLIT2_LENGTHS = [540, 576, 600, 640, 648, 720, 750, 768, 800, 864, 960, 1000, 1024]       # two blocks per wave
 TSPLIT_LENGTHS = [135, 144, 150, 160, 162, 180, 192, 200, 216, 225, 240, 243, 250, 256, 270, 288, 300, 320, 324, 360, 375, 384, 400, 405,
