@@ -301,7 +301,15 @@ __global__ void __launch_bounds__(1024) line_fft_kernel(LineJob job) {
     for (int e = tid; e < elems; e += nthreads) {
         int c, n;
         split(e, job.contiguous_lines, c, n);
-        tile[c * npad + n] = job.in[s_in[c] + (long long)n * job.in_es];
+        float2 x = job.in[s_in[c] + (long long)n * job.in_es];
+        if (job.store_mode == STORE_INTENSITY) {
+            // TACAW: any constant may be subtracted from a time line (only the DC bin sees it, and that bin is zeroed below); the
+            // line's first sample keeps the float32 transform at the size of the thermal part where the mean is orders of magnitude
+            // above it (the register kernels do the same: tacaw_time.h)
+            const float2 r = job.in[s_in[c]];
+            x.x -= r.x; x.y -= r.y;
+        }
+        tile[c * npad + n] = x;
     }
     __syncthreads();
     for (int st = 0; st < job.n_steps; ++st) {
