@@ -13,9 +13,11 @@
 // segments.  Index algebra is unit-tested on the host (tools/fft_regs_host.cpp).
 #pragma once
 #include <type_traits>
+#include <utility>
 #include <hip/hip_runtime.h>
 #include "fft_regs.h"
 #include "kernel_util.h"
+#include "rowt_pass.h"
 
 namespace msl {
 
@@ -113,44 +115,6 @@ __device__ __forceinline__ void fourstep_c64(float2 (&v)[R], float2* scratch, co
     fft_regs<R, INV>(v);
 }
 
-#ifdef MSL_STAMPS
-// The two halves of a four-step transform (diagnostic build of the transposing pass: phase timing per half):
-// head = first register FFT and the inter-FFT twiddles (no scratch access), tail = lane<->register transpose through the
-// scratch and the second register FFT.
-template <int R, bool INV, int CH = 8>
-__device__ __forceinline__ void fourstep_head(float2 (&v)[R], const float2* tw, int ln) {
-    fft_regs<R, INV>(v);
-    mul_table<R, 1, INV, R, CH>(v, tw, ln);
-}
-template <int R, bool INV, bool C64>
-__device__ __forceinline__ void fourstep_tail(float2 (&v)[R], float2* scratch2, int ln) {
-    static_assert(64 % R == 0, "an R-lane group must lie inside one wave: the scratch is ordered per wave only");
-    if constexpr (C64) {
-#pragma unroll
-        for (int k1 = 0; k1 < R; ++k1) scratch2[k1 * (R + 1) + ln] = v[k1];
-        wave_lds_fence();
-#pragma unroll
-        for (int n2 = 0; n2 < R; ++n2) v[n2] = scratch2[ln * (R + 1) + n2];
-        wave_lds_fence();
-    } else {
-        float* scratch = reinterpret_cast<float*>(scratch2);
-#pragma unroll
-        for (int k1 = 0; k1 < R; ++k1) scratch[k1 * (R + 1) + ln] = v[k1].x;
-        wave_lds_fence();
-#pragma unroll
-        for (int n2 = 0; n2 < R; ++n2) v[n2].x = scratch[ln * (R + 1) + n2];
-        wave_lds_fence();
-#pragma unroll
-        for (int k1 = 0; k1 < R; ++k1) scratch[k1 * (R + 1) + ln] = v[k1].y;
-        wave_lds_fence();
-#pragma unroll
-        for (int n2 = 0; n2 < R; ++n2) v[n2].y = scratch[ln * (R + 1) + n2];
-        wave_lds_fence();
-    }
-    fft_regs<R, INV>(v);
-}
-#endif  // MSL_STAMPS
-
 struct RowJob {
     float2* psi;            // (P, nx, pitch) working waves, rows contiguous
     const float2* trans;    // t_z (nx, ny) of this slice, or null
@@ -168,18 +132,6 @@ struct RowJob {
     unsigned t_magic;       // floor(2^32 / t_group) + 1
     long long t_stride;
 };
-
-// transmission stack of the frame that image p belongs to: job.trans + frame_off(job, p).  p is wave-uniform and the
-// frame number p / t_group is computed in scalar registers only -- a multiply-high by t_magic = floor(2^32 / t_group) + 1,
-// exact while p * t_group < 2^32 -- because these kernels run within a few VGPRs of the 256 that two waves per SIMD allow:
-// a vector temporary here pushed rowT2_pass_kernel<16> into the AGPRs and halved its occupancy (81 -> 117 us per pass).
-template <typename Job>
-__device__ __forceinline__ long long frame_off(const Job& job, int p) {
-    if (job.t_group <= 0) return 0;
-    const unsigned up = (unsigned)__builtin_amdgcn_readfirstlane(p);
-    const unsigned f = job.t_group == 1 ? up : __umulhi(up, job.t_magic);        // (the magic number of 1 does not fit 32 bits)
-    return (long long)f * job.t_stride;
-}
 
 // Row pass (two-pass loop, stand-alone FFTs), software-pipelined.  Workgroup = 256 threads = 256/R lines per iteration.
 // A work item is (x-group, chunk of `pchunk` probes): the t_z rows
@@ -450,7 +402,6 @@ __global__ void __launch_bounds__(COLS * R) col_pass_kernel(ColJob job) {
 // read + write of psi per slice instead of two: 16 B/pixel/slice-step.  Same arithmetic as the
 // reference up to fp32 rounding order.
 // =================================================================================================
-enum { P2_PRE_A = 1, P2_POST_A = 2, P2_POST_F = 4, P2_IN_PAIRED = 8, P2_OUT_PAIRED = 16 };
 
 struct Row2Job {
     float2* psi;
@@ -532,257 +483,6 @@ __global__ void __launch_bounds__(256, 2) row_pass2_kernel(Row2Job job) {
         for (int j = 0; j < R; ++j) cur_row[j * R + ln] = v[j];
         item = nitem; k = nk;
     }
-}
-
-// Transposing pass: lines of the input are contiguous (row-style, coalesced, prefetched in registers);
-// the result is written TRANSPOSED (out[pos][line]) through an LDS tile of 16 lines so that HBM sees
-// 128-byte segments.  The next pass then again reads contiguous lines -- of the other axis.  With this
-// kernel every slice is one pass  A_d . t_k . A_d  with t_k reused from registers across a chunk of probes.
-struct RowTJob {
-    const float2* in;       // (P, n_lines, in_pitch): lines along the transform axis
-    float2* out;            // (P, N, out_pitch): transposed
-    const float2* trans;    // t_k in the input orientation, (n_lines, N) unpadded
-    const float2* pl;       // (N) Fresnel factor along the line axis, 1/N folded in (split order for N = 2R^2)
-    const float2* tw;
-    const float2* tw2;      // N = 2R^2 only: W_N^m, m < R^2
-    long long in_image_stride, out_image_stride;
-    int in_pitch, out_pitch, n_lines, n_images, flags, pchunk;
-    int t_group;            // frame batching, see RowJob
-    unsigned t_magic;
-    long long t_stride;
-    // rowTB_pass_kernel (lines of any length N <= R^2/2 by Bluestein's chirp-z on the register FFTs of length M = R^2):
-    const float2* bf;       // (M/2 + 1) filter FFT_M(conj chirp, wrapped) / M -- an even sequence, first half stored
-    const float2* bw;       // (M/2) chirp w[n] = exp(-i pi n^2 / N), zero for n >= N
-    int n_line;             // N
-    int perm_shift;         // rowT_pass_kernel<.., OUT_P>: log2(R' / 8), R' = radix of the kernel that reads the output lines
-#ifdef MSL_STAMPS
-    unsigned* stamps;       // tools/rowt_timeline.hip: per wave, cycles spent in each of MSL_NSTAMP phases of the iteration
-#endif
-};
-
-// Phase timing for tools/rowt_timeline.hip (diagnostic build only: -DMSL_STAMPS; s_memtime costs an SMEM round trip and
-// drains the wave's LDS queue at every stamp, so the stamped kernel runs slower than the shipped one)
-#ifdef MSL_STAMPS
-#define MSL_NSTAMP 24
-#define MSL_STAMP(id) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
-                           acc_[id] += (unsigned)(now_ - last_); last_ = now_; __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define MSL_STAMP(id)
-#endif
-
-// IN_P / OUT_P: between two transposing passes the work buffer holds every line in the INTERLEAVED order
-//     position 2 R' (j >> 1) + 2 l + (j & 1)   <->   element R' j + l          (R' = radix of the kernel that reads the line)
-// i.e. the two elements a lane of the reading kernel keeps in registers 2 jp and 2 jp + 1 sit next to each other: the reader
-// fetches a line with R'/2 loads of 16 bytes per lane instead of R' loads of 8 (a wave's load covers 2 x 512 contiguous bytes) --
-// 8-byte accesses run at 0.54-0.70 of the 16-byte rate through the L1 / address path (MI355X_MICROARCH.md), and in the phase
-// timeline a wave spent 22 % of its time issuing the prefetch loads.  The writer keeps its 128-byte transposed segments: a tile
-// is then not 16 consecutive lines but 8 lines l0 .. l0 + 7 of block j = 2 jp and the same 8 of block 2 jp + 1 (tile row r =
-// line R' (2 jp + (r & 1)) + l0 + (r >> 1)), whose 16 output elements are exactly positions 2 R' jp + 2 l0 .. + 15: the store
-// addresses do not change at all, only which input lines (and t_k lines) form a tile.  job.perm_shift = log2(R' / 8).
-template <int R, int LINES, bool IN_P = false, bool OUT_P = false>
-__global__ void __launch_bounds__(LINES * R, (R == 16) ? 3 : 2) rowT_pass_kernel(RowTJob job) {
-    constexpr int N = R * R;
-#ifdef MSL_STAMPS
-    constexpr int TCH = 8;                              // the diagnostic build needs the registers for its counters
-#else
-    constexpr int TCH = (R == 32) ? 16 : 8;             // table-multiply chunk (see mul_table)
-#endif
-    constexpr int NT = LINES * R;
-    // tile line pitch in float2: the R^2 positions of a line (the wave's exchange scratch, R x 68 floats over 64 / R lines, is
-    // smaller); 2 mod 32: rows 16-byte aligned for the exchange's wide reads, conflict-free staging
-    constexpr int CS = (R * R + 33) / 32 * 32 + 2;
-    constexpr int TPS = LINES / 2;                    // threads (16 B = 2 lines each) per output segment of LINES*8 bytes
-    constexpr int POS_PER_IT = NT / TPS;
-    constexpr int NIT = N / POS_PER_IT;
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    static_assert(LINES == 16, "16 lines = 128-byte transposed segments (8 lines / 64 bytes measured 1.6x slower)");
-    float2* tw = reinterpret_cast<float2*>(smem_raw);
-    float2* pl = tw + N;
-    float2* tile = pl + N;                            // LINES * CS
-    const int tid = threadIdx.x;
-    for (int i = tid; i < N; i += NT) { tw[i] = job.tw[i]; pl[i] = job.pl[i]; }
-    __syncthreads();
-    const int grp = tid / R, ln = tid % R;
-    const int q = tid % TPS, r0 = tid / TPS;
-    float2* myrow = tile + grp * CS;
-    // add-tid exchange: the groups of a wave share the scratch that starts at the first of their tile rows
-    const float* wscr = reinterpret_cast<const float*>(tile + (grp - grp % (64 / R)) * CS);
-    const unsigned wscr_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(tile + (grp - grp % (64 / R)) * CS));
-    const int lblocks = job.n_lines / LINES;
-    const int PC = job.pchunk;
-    const int pchunks = (job.n_images + PC - 1) / PC;
-    const int n_items = lblocks * pchunks;
-    // work item = (line block lb, probe chunk pc), item = lb * pchunks + pc; the cursor (item, lb, pc, k) advances
-    // incrementally -- a division per iteration costs ~0.3 us of scalar work on the critical path
-    const int step_lb = (int)gridDim.x / pchunks, step_pc = (int)gridDim.x % pchunks;
-    // input line of this thread's tile row in line block lbb
-    auto line_of = [&](int lbb) {
-        if constexpr (OUT_P) {
-            const int sh = job.perm_shift;                              // blocks of 16 output elements per 2 R' chunk: R' / 8
-            return (((lbb >> sh) * 2 + (grp & 1)) << (sh + 3)) + 8 * (lbb & ((1 << sh) - 1)) + (grp >> 1);
-        } else {
-            return lbb * LINES + grp;
-        }
-    };
-    auto line_ptr = [&](int lbb, int pcc, int kk) {
-        return job.in + (long long)(pcc * PC + kk) * job.in_image_stride + (long long)line_of(lbb) * job.in_pitch;
-    };
-    // registers [LO, HI) of the next line: 8-byte loads of elements j R + ln, or (interleaved input) 16-byte loads of the pairs
-    auto load_regs = [&](float2 (&dst)[R], const float2* r, auto lo_c, auto hi_c) {
-        constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
-        if constexpr (IN_P) {
-            static_assert(LO % 2 == 0 && HI % 2 == 0, "register pairs");
-#pragma unroll
-            for (int jp = LO / 2; jp < HI / 2; ++jp) {
-                const msl_f4v t = __builtin_nontemporal_load(reinterpret_cast<const msl_f4v*>(r + (2 * R * jp + 2 * ln)));
-                dst[2 * jp] = make_float2(t.x, t.y); dst[2 * jp + 1] = make_float2(t.z, t.w);
-            }
-        } else {
-#pragma unroll
-            for (int j = LO; j < HI; ++j) dst[j] = ld_stream(r + (j * R + ln));
-        }
-    };
-    int item = blockIdx.x;
-    int lb = item / pchunks, pc = item - lb * pchunks, k = 0;
-    float2 vn[R];
-    if (item < n_items) load_regs(vn, line_ptr(lb, pc, 0), std::integral_constant<int, 0>{}, std::integral_constant<int, R>{});
-    float2 tv[R];
-#ifdef MSL_STAMPS
-    unsigned acc_[MSL_NSTAMP] = {0};
-    unsigned long long last_ = __builtin_amdgcn_s_memtime();
-#endif
-    while (item < n_items) {
-        MSL_STAMP(0);
-        float2 v[R];
-#pragma unroll
-        for (int j = 0; j < R; ++j) v[j] = vn[j];
-#ifdef MSL_STAMPS
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-        MSL_STAMP(1);
-        const int p = pc * PC + k;
-        const int cur_lb = lb;
-        if (k == 0) {
-            const float2* trow = job.trans + frame_off(job, pc * PC) + (long long)line_of(lb) * N;
-#pragma unroll
-            for (int j = 0; j < R; ++j) tv[j] = ld_stream(trow + j * R + ln);       // read once per launch too (+0.4 %)
-        }
-        int nitem = item, nlb = lb, npc = pc, nk = k + 1;
-        if (nk >= min(PC, job.n_images - pc * PC)) {
-            nk = 0; nitem = item + (int)gridDim.x; nlb = lb + step_lb; npc = pc + step_pc;
-            if (npc >= pchunks) { npc -= pchunks; ++nlb; }
-        }
-        // The prefetch of the next line is spread over the iteration, a quarter of the loads after each of the four
-        // transforms, instead of 32 loads at the top: right after the previous iteration's 16 stores the address unit is
-        // still busy with them and a burst of loads stalls the wave in issue (measured per 1024^2 pass: 322 us at the
-        // top, 306 us all after the third transform, 294 us half after the second and half after the third, 287 us in
-        // quarters).
-        auto prefetch_part = [&](auto lo_c, auto hi_c) {
-            // R = 32: quarters; R = 16 (256-point lines, three workgroups per CU): everything at the first call, measured faster
-            constexpr int LO = (R == 32) ? decltype(lo_c)::value : (decltype(lo_c)::value == 0 ? 0 : R);
-            constexpr int HI = (R == 32) ? decltype(hi_c)::value : R;
-            if constexpr (HI > LO) {
-                __builtin_amdgcn_sched_barrier(0);
-                if (nitem < n_items) load_regs(vn, line_ptr(nlb, npc, nk), std::integral_constant<int, LO>{}, std::integral_constant<int, HI>{});
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        };
-#define MSL_IC(x) std::integral_constant<int, (x)>{}              // quarter boundaries in 32nds of the line's registers
-        MSL_STAMP(2);                                                   // t_k load (k == 0) + cursor
-#ifdef MSL_STAMPS
-        // diagnostic build: the four transforms in halves (head = register FFT + twiddles, tail = transpose + register FFT);
-        // MSL_ABL bits remove parts of the work (wrong results, timing only): 1 = no prefetch loads, 2 = no stores,
-        // 4 = no LDS transposes, 8 = no LDS table reads (tables replaced by a register)
-#ifndef MSL_ABL
-#define MSL_ABL 0
-#endif
-        auto head = [&](auto inv_c) {
-            constexpr bool INV = decltype(inv_c)::value;
-            if constexpr (MSL_ABL & 8) { fft_regs<R, INV>(v);
-#pragma unroll
-                for (int j = 1; j < R; ++j) v[j] = cmulf(v[j], tv[j]);
-            } else fourstep_head<R, INV, TCH>(v, tw, ln);
-        };
-        auto tail = [&](auto inv_c) {
-            constexpr bool INV = decltype(inv_c)::value;
-            if constexpr (MSL_ABL & 4) fft_regs<R, INV>(v); else fourstep_tail<R, INV, false>(v, myrow, ln);
-        };
-        auto mulp = [&]() {
-            if constexpr (MSL_ABL & 8) {
-#pragma unroll
-                for (int j = 0; j < R; ++j) v[j] = cmulf(v[j], tv[R - 1 - j]);
-            } else mul_table<R, 0, false, R, TCH>(v, pl, ln);
-        };
-        auto pf = [&](auto lo, auto hi) { if constexpr (!(MSL_ABL & 1)) prefetch_part(lo, hi); };
-        head(std::false_type{}); MSL_STAMP(3);
-        tail(std::false_type{}); MSL_STAMP(4);
-        pf(MSL_IC(0), MSL_IC(8)); MSL_STAMP(5);
-        mulp(); MSL_STAMP(6);
-        head(std::true_type{}); MSL_STAMP(7);
-        tail(std::true_type{}); MSL_STAMP(8);
-        pf(MSL_IC(8), MSL_IC(16)); MSL_STAMP(9);
-#pragma unroll
-        for (int j = 0; j < R; ++j) v[j] = cmulf(v[j], tv[j]);
-        MSL_STAMP(10);
-        head(std::false_type{}); MSL_STAMP(11);
-        tail(std::false_type{}); MSL_STAMP(12);
-        pf(MSL_IC(16), MSL_IC(24)); MSL_STAMP(13);
-        mulp(); MSL_STAMP(14);
-        head(std::true_type{}); MSL_STAMP(15);
-        tail(std::true_type{}); MSL_STAMP(16);
-        pf(MSL_IC(24), MSL_IC(32)); MSL_STAMP(17);
-#else
-        if (job.flags & P2_PRE_A) {
-            fourstep_split_addtid<R, false, TCH>(v, wscr, wscr_lds, tw, ln, tid & 63);
-        }
-        prefetch_part(MSL_IC(0), MSL_IC(8));
-        if (job.flags & P2_PRE_A) {
-            mul_table<R, 0, false, R, TCH>(v, pl, ln);
-            fourstep_split_addtid<R, true, TCH>(v, wscr, wscr_lds, tw, ln, tid & 63);
-        }
-        prefetch_part(MSL_IC(8), MSL_IC(16));
-#pragma unroll
-        for (int j = 0; j < R; ++j) v[j] = cmulf(v[j], tv[j]);
-        if (job.flags & P2_POST_A) {
-            fourstep_split_addtid<R, false, TCH>(v, wscr, wscr_lds, tw, ln, tid & 63);
-        }
-        prefetch_part(MSL_IC(16), MSL_IC(24));
-        if (job.flags & P2_POST_A) {
-            mul_table<R, 0, false, R, TCH>(v, pl, ln);
-            fourstep_split_addtid<R, true, TCH>(v, wscr, wscr_lds, tw, ln, tid & 63);
-        }
-        prefetch_part(MSL_IC(24), MSL_IC(32));
-#endif
-        wave_lds_fence();
-#pragma unroll
-        for (int j = 0; j < R; ++j) myrow[j * R + ln] = v[j];
-        MSL_STAMP(18);
-        lds_barrier();
-        MSL_STAMP(19);
-        // uniform 64-bit base + per-thread 32-bit element offset, re-derived every iteration (the asm keeps the
-        // compiler from hoisting 16 loop-invariant 64-bit addresses into registers for the whole kernel)
-        float2* dst = job.out + (long long)p * job.out_image_stride + cur_lb * LINES;
-        int off0 = 2 * q + r0 * job.out_pitch;
-        asm volatile("" : "+v"(off0));
-        const int ostep = POS_PER_IT * job.out_pitch;
-#pragma unroll
-        for (int i = 0; i < NIT; ++i) {
-            const int pos = r0 + POS_PER_IT * i;
-            const float2 a = tile[(2 * q) * CS + pos], b = tile[(2 * q + 1) * CS + pos];
-#if defined(MSL_STAMPS) && (MSL_ABL & 2)
-            if (a.x == 1.2345e-30f)                 // never true: the LDS reads stay, the store goes
-#endif
-            st_stream(dst + (off0 + i * ostep), a.x, a.y, b.x, b.y);
-        }
-        MSL_STAMP(20);
-        lds_barrier();
-        MSL_STAMP(21);
-        item = nitem; lb = nlb; pc = npc; k = nk;
-    }
-#ifdef MSL_STAMPS
-    if ((tid & 63) == 0 && job.stamps)
-        for (int i = 0; i < MSL_NSTAMP; ++i) job.stamps[((size_t)blockIdx.x * (NT / 64) + tid / 64) * MSL_NSTAMP + i] = acc_[i];
-#endif
 }
 
 // ---- lines of ANY length N <= R^2/2: propagation as a zero-padded cyclic convolution on the register FFTs -------------------------

@@ -230,4 +230,207 @@ MSL_HD void fft_regs(cf (&v)[N]) {
     for (int i = 0; i < N; ++i) v[i] = t[i];
 }
 
+// ---- decimation in time with fused multiply-adds (power-of-two lengths; the slice-loop kernels of fft_pow2.h) -----------------
+// The decimation-in-frequency network above multiplies AFTER it adds, so a twiddle costs a full complex product (2 mul + 2 fma)
+// on top of the butterfly's four additions.  Decimation in time multiplies BEFORE it adds, and then the product folds into the
+// additions:  a + W b  is two chained FMAs per component, and  a - W b = 2 a - (a + W b)  one more -- 6 instructions per radix-2
+// butterfly with a general twiddle instead of 8 (32 points: 388 instead of ~430, the operation count of a split-radix transform).
+// Same for a pointwise product IN FRONT of a transform (inter-FFT twiddles, Fresnel factor, transmission function): the leaf level
+// has trivial twiddles, so  (wa a) +- (wb b)  is 10 instructions per butterfly instead of 4 + 4 + 4 -- the products of the slice
+// loop are passed to the leaf level as weights (dit_leaf_w) instead of being applied by a separate pass over the registers.
+// Radix plan: 4 while the length allows it and a radix-2 leaf otherwise (32 = 4.4.2 from the top, 16 = 4.4).  A top-level radix-4
+// butterfly with general twiddles applies W^k, W^2k, W^3k to its inputs directly (u0 = W^k a1 + W^3k a3 as product + two chained
+// FMAs) rather than as two radix-2 levels in sequence: the same 24 instructions, but every path from input to output crosses one
+// rounded twiddle constant per radix-4 level -- the constants' errors are systematic and add up linearly over the slices of a run.
+constexpr int dit_radix(int n) { return (n % 4 == 0) ? 4 : 2; }
+// position (in units of the stride) that holds frequency k after dit<N>: the sub-transform of the inputs r i + q leaves Y_q[k] at
+// r pos(k) + q, and the combining butterfly over q writes X[k + (N/r) p] to r pos(k) + p
+constexpr int dit_pos(int k, int n) {
+    if (n == 1) return 0;
+    const int r = dit_radix(n), m = n / r;
+    return r * dit_pos(k % m, m) + k / m;
+}
+constexpr int dit_freq(int i, int n) {             // inverse map: frequency held at position i
+    if (n == 1) return 0;
+    const int r = dit_radix(n), m = n / r;
+    return dit_freq(i / r, m) + m * (i % r);
+}
+
+MSL_HD float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+// (a, b) <- (a + W b, a - W b),  W = W_N^K = exp(-2 pi i K / N), conjugated when INV
+template <int N, int K, bool INV>
+MSL_HD void dit_bfly(cf& a, cf& b) {
+    constexpr int KK = ((K % N) + N) % N;
+    if constexpr (KK == 0) {
+        const cf t = mk(a.x + b.x, a.y + b.y); b = mk(a.x - b.x, a.y - b.y); a = t;
+    } else if constexpr (2 * KK == N) {            // W = -1
+        const cf t = mk(a.x - b.x, a.y - b.y); b = mk(a.x + b.x, a.y + b.y); a = t;
+    } else if constexpr ((4 * KK == N) != INV && (4 * KK == N || 4 * KK == 3 * N)) {      // W b = -i b = (b.y, -b.x)
+        const cf t = mk(a.x + b.y, a.y - b.x); b = mk(a.x - b.y, a.y + b.x); a = t;
+    } else if constexpr (4 * KK == N || 4 * KK == 3 * N) {                                // W b = +i b = (-b.y, b.x)
+        const cf t = mk(a.x - b.y, a.y + b.x); b = mk(a.x + b.y, a.y - b.x); a = t;
+    } else {
+        constexpr float c = (float)cx_cos2pi(KK, N);
+        constexpr float s = INV ? -(float)cx_sin2pi(KK, N) : (float)cx_sin2pi(KK, N);     // W = c - i s:  W b = (c b.x + s b.y, c b.y - s b.x)
+        const cf t = mk(fma_(s, b.y, fma_(c, b.x, a.x)), fma_(-s, b.x, fma_(c, b.y, a.y)));
+        b = mk(fma_(2.0f, a.x, -t.x), fma_(2.0f, a.y, -t.y));
+        a = t;
+    }
+}
+
+// radix-4 combination: inputs Y_q[k] in a_q, outputs X[k + (N/4) p] in a_p;  W_N^{qK} on input q
+template <int N, int K, bool INV>
+MSL_HD void dit_bfly4(cf& a0, cf& a1, cf& a2, cf& a3) {
+    if constexpr (K % N == 0 || (8 * K) % N == 0) {      // trivial and W_8-family twiddles: two radix-2 levels are cheaper (16 / 20)
+        dit_bfly<N, 2 * K, INV>(a0, a2);                 // t0, t1
+        dit_bfly<N, 2 * K, INV>(a1, a3);                 // d = a1 + W^2K a3, e = a1 - W^2K a3
+        dit_bfly<N, K, INV>(a0, a1);                     // y0, y2 = t0 +- W^K d
+        dit_bfly<N, K + N / 4, INV>(a2, a3);             // y1, y3 = t1 -+ i W^K e
+        const cf y2 = a1; a1 = a2; a2 = y2;
+    } else {
+        dit_bfly<N, 2 * K, INV>(a0, a2);                 // a0 = t0 = a0 + W^2K a2, a2 = t1
+        constexpr float c1 = (float)cx_cos2pi(K % N, N), c3 = (float)cx_cos2pi((3 * K) % N, N);
+        constexpr float s1 = INV ? -(float)cx_sin2pi(K % N, N) : (float)cx_sin2pi(K % N, N);
+        constexpr float s3 = INV ? -(float)cx_sin2pi((3 * K) % N, N) : (float)cx_sin2pi((3 * K) % N, N);
+        const cf p = mk(fma_(s1, a1.y, c1 * a1.x), fma_(-s1, a1.x, c1 * a1.y));                          // W^K a1
+        const cf u0 = mk(fma_(s3, a3.y, fma_(c3, a3.x, p.x)), fma_(-s3, a3.x, fma_(c3, a3.y, p.y)));     // + W^3K a3
+        const cf u1 = mk(fma_(2.0f, p.x, -u0.x), fma_(2.0f, p.y, -u0.y));                                // W^K a1 - W^3K a3
+        const cf t0 = a0, t1 = a2;
+        a0 = mk(t0.x + u0.x, t0.y + u0.y);
+        a2 = mk(t0.x - u0.x, t0.y - u0.y);
+        if constexpr (!INV) { a1 = mk(t1.x + u1.y, t1.y - u1.x); a3 = mk(t1.x - u1.y, t1.y + u1.x); }   // t1 -+ i u1
+        else                { a1 = mk(t1.x - u1.y, t1.y + u1.x); a3 = mk(t1.x + u1.y, t1.y - u1.x); }
+    }
+}
+
+// FENCE: a scheduling barrier after every FENCE-th butterfly (0: none), see fft_fence
+template <int N, int S, bool INV, bool SKIP_LEAF, int K, int FENCE = 0>
+MSL_HD void dit_combine(cf* v) {
+    constexpr int R = dit_radix(N), M = N / R;
+    if constexpr (K < M) {
+        constexpr int B = R * dit_pos(K, M);
+        if constexpr (R == 4) dit_bfly4<N, K, INV>(v[B * S], v[(B + 1) * S], v[(B + 2) * S], v[(B + 3) * S]);
+        else dit_bfly<N, K, INV>(v[B * S], v[(B + 1) * S]);
+        if constexpr (FENCE > 0) fft_fence<(K % FENCE) == FENCE - 1>();
+        dit_combine<N, S, INV, SKIP_LEAF, K + 1, FENCE>(v);
+    }
+}
+
+template <int N, int S, bool INV, bool SKIP_LEAF, int FENCE = 0>
+MSL_HD void dit(cf* v);
+
+template <int N, int S, bool INV, bool SKIP_LEAF, int Q, int FENCE = 0>
+MSL_HD void dit_subs(cf* v) {
+    constexpr int R = dit_radix(N);
+    if constexpr (Q < R) {
+        dit<N / R, S * R, INV, SKIP_LEAF, FENCE>(v + Q * S);
+        if constexpr (FENCE > 0) fft_fence<true>();
+        dit_subs<N, S, INV, SKIP_LEAF, Q + 1, FENCE>(v);
+    }
+}
+
+// decimation in time on v[0], v[S], ..., v[(N-1)S], natural order in; position i ends up holding frequency dit_freq(i, N).
+// SKIP_LEAF: the leaf level (the butterflies of the innermost radix, trivial twiddles) has been done by the caller (dit_leaf_*).
+template <int N, int S, bool INV, bool SKIP_LEAF, int FENCE>
+MSL_HD void dit(cf* v) {
+    if constexpr (N > 1) {
+        dit_subs<N, S, INV, SKIP_LEAF, 0, FENCE>(v);
+        if constexpr (!(SKIP_LEAF && N == dit_radix(N))) dit_combine<N, S, INV, SKIP_LEAF, 0, FENCE>(v);
+    }
+}
+
+constexpr int dit_leaf_radix(int n) { while (n > 4) n /= 4; return n; }            // 32 -> 2, 16 -> 4, 8 -> 2, 64 -> 4
+constexpr int dit_leaf_count(int n) { return n / dit_leaf_radix(n); }              // leaf butterflies; butterfly I takes the elements I + q count
+
+// leaf butterfly I of an N-point transform, out of place (in == out is fine), its inputs weighted:
+//   WMODE 0: no weights;  1: in[I + q C] * w[q];  2: in[I + q C] * conj(w[q])          (C = dit_leaf_count(N), w = the butterfly's r weights)
+template <int N, bool INV, int WMODE, int I>
+MSL_HD void dit_leaf(const cf* in, cf* out, const cf* w) {
+    constexpr int R = dit_leaf_radix(N), C = N / R;
+    // product with the weight, and  p + w b  as two chained FMAs per component
+    auto wmul = [](cf a, cf ww) {
+        if constexpr (WMODE == 2) return mk(fma_(a.x, ww.x, a.y * ww.y), fma_(a.y, ww.x, -(a.x * ww.y)));
+        else return mk(fma_(a.x, ww.x, -(a.y * ww.y)), fma_(a.y, ww.x, a.x * ww.y));
+    };
+    auto wfma = [](cf p, cf b, cf ww) {
+        if constexpr (WMODE == 2) return mk(fma_(b.y, ww.y, fma_(b.x, ww.x, p.x)), fma_(-b.x, ww.y, fma_(b.y, ww.x, p.y)));
+        else return mk(fma_(-b.y, ww.y, fma_(b.x, ww.x, p.x)), fma_(b.x, ww.y, fma_(b.y, ww.x, p.y)));
+    };
+    if constexpr (R == 2) {
+        cf a = in[I], b = in[I + C];
+        if constexpr (WMODE == 0) {
+            dit_bfly<2, 0, INV>(a, b);
+        } else {
+            const cf p = wmul(a, w[0]);
+            a = wfma(p, b, w[1]);
+            b = mk(fma_(2.0f, p.x, -a.x), fma_(2.0f, p.y, -a.y));
+        }
+        out[I] = a; out[I + C] = b;
+    } else {
+        cf a0 = in[I], a1 = in[I + C], a2 = in[I + 2 * C], a3 = in[I + 3 * C];
+        if constexpr (WMODE == 0) {
+            dit_bfly4<4, 0, INV>(a0, a1, a2, a3);
+        } else {
+            const cf p0 = wmul(a0, w[0]), p1 = wmul(a1, w[1]);
+            const cf t0 = wfma(p0, a2, w[2]), u0 = wfma(p1, a3, w[3]);
+            const cf t1 = mk(fma_(2.0f, p0.x, -t0.x), fma_(2.0f, p0.y, -t0.y));
+            const cf u1 = mk(fma_(2.0f, p1.x, -u0.x), fma_(2.0f, p1.y, -u0.y));
+            a0 = mk(t0.x + u0.x, t0.y + u0.y);
+            a2 = mk(t0.x - u0.x, t0.y - u0.y);
+            if constexpr (!INV) { a1 = mk(t1.x + u1.y, t1.y - u1.x); a3 = mk(t1.x - u1.y, t1.y + u1.x); }
+            else                { a1 = mk(t1.x - u1.y, t1.y + u1.x); a3 = mk(t1.x + u1.y, t1.y - u1.x); }
+        }
+        out[I] = a0; out[I + C] = a1; out[I + 2 * C] = a2; out[I + 3 * C] = a3;
+    }
+}
+
+template <int N, bool INV, int I>
+MSL_HD void dit_leaves_plain(const cf* in, cf* out) {
+    if constexpr (I < dit_leaf_count(N)) {
+        dit_leaf<N, INV, 0, I>(in, out, nullptr);
+        dit_leaves_plain<N, INV, I + 1>(in, out);
+    }
+}
+// all leaves with the weights in registers: w[n] on element n (conjugated for WMODE 2)
+template <int N, bool INV, int WMODE, int I>
+MSL_HD void dit_leaves_regs(const cf* in, cf* out, const cf* w) {
+    if constexpr (I < dit_leaf_count(N)) {
+        constexpr int R = dit_leaf_radix(N), C = N / R;
+        cf ww[4];
+        ww[0] = w[I]; ww[1] = w[I + C];
+        if constexpr (R == 4) { ww[2] = w[I + 2 * C]; ww[3] = w[I + 3 * C]; }
+        dit_leaf<N, INV, WMODE, I>(in, out, ww);
+        dit_leaves_regs<N, INV, WMODE, I + 1>(in, out, w);
+    }
+}
+
+template <int N, int I>
+MSL_HD void dit_unscramble(const cf* src, cf* dst) {
+    if constexpr (I < N) {
+        constexpr int F = dit_freq(I, N);
+        dst[F] = src[I];
+        dit_unscramble<N, I + 1>(src, dst);
+    }
+}
+
+// the levels above the leaves + the renaming to natural order
+template <int N, bool INV, int FENCE = 0>
+MSL_HD void dit_upper(cf (&v)[N]) {
+    dit<N, 1, INV, true, FENCE>(v);
+    cf t[N];
+    dit_unscramble<N, 0>(v, t);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = t[i];
+}
+
+// natural-order in (array `in`, may be v itself), natural-order out, unnormalised; WMODE / w: weights on the inputs, see dit_leaf
+template <int N, bool INV, int WMODE = 0, int FENCE = 0>
+MSL_HD void fft_regs_dit(const cf (&in)[N], cf (&v)[N], const cf* w = nullptr) {
+    if constexpr (WMODE == 0) dit_leaves_plain<N, INV, 0>(in, v);
+    else dit_leaves_regs<N, INV, WMODE, 0>(in, v, w);
+    fft_fence<(FENCE > 0)>();
+    dit_upper<N, INV, FENCE>(v);
+}
+
 }  // namespace msl

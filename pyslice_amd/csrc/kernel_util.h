@@ -49,6 +49,17 @@ __device__ __forceinline__ void st_stream(float2* p, float ax, float ay, float b
     __builtin_nontemporal_store(t, reinterpret_cast<msl_f4v*>(p));
 }
 
+// Pin values to this point of the program: an empty volatile asm that "modifies" them.  Volatile asm statements, scheduling barriers
+// and memory operations keep their program order, but plain arithmetic does not -- instruction selection is free to sink the
+// butterflies of one transform below the table reads of the next (the reads then wait in registers: +64 VGPRs and the kernel
+// spills).  Pinning a transform's results where it ends confines every value to its own phase; it emits no instruction.
+__device__ __forceinline__ void pin(float2& a) { asm volatile("" : "+v"(a.x), "+v"(a.y)); }
+template <int N>
+__device__ __forceinline__ void pin_all(float2 (&v)[N]) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) pin(v[j]);
+}
+
 // workgroup barrier that drains LDS traffic only (global loads/stores stay in flight across it)
 __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");

@@ -686,14 +686,12 @@ int transpose_odd_slices(msl_handle* h) {
     return MSL_OK;
 }
 
-// transposing pass on R^2-point lines (1024 / 256): add-tid exchange, 16-line tiles; IN_P / OUT_P: interleaved line order of the
-// work buffer on the input / output side (16-byte loads in the reading kernel, see rowT_pass_kernel)
-template <int R, bool IN_P, bool OUT_P>
-int launch_rowT_io(msl_handle* h, RowTJob job, int kind) {
-    constexpr int N = R * R, LINES = 16;
-    constexpr int CS = (R * R + 33) / 32 * 32 + 2;
-    const size_t lds = ((size_t)2 * N + (size_t)LINES * CS) * 8;
-    // R = 32: ~250 VGPRs, 152-156 KB -> one workgroup per CU; R = 16: 135 VGPRs, 39 KB -> three
+// transposing pass on R^2-point lines (1024 / 256), rowt_pass.h; the kernels live in slice_pass.hip
+template <int R>
+int launch_rowT_r(msl_handle* h, RowTJob job, int kind) {
+    constexpr int LINES = 16;
+    const size_t lds = rowT_lds_bytes(R);
+    // R = 32: ~235 VGPRs, 152 KB -> one workgroup per CU; R = 16: 138 VGPRs, 41 KB -> three
     const int cap = (R == 16) ? 3 : 2;
     const int per_cu = std::max(1, std::min(cap, (int)((size_t)h->lds_limit / lds)));
     const long long slots = (long long)h->n_cus * per_cu;
@@ -703,16 +701,9 @@ int launch_rowT_io(msl_handle* h, RowTJob job, int kind) {
     job.pchunk = pc;
     const long long items = lb * ((job.n_images + pc - 1) / pc);
     const int grid = (int)std::min<long long>(items, slots);
-    (void)hipFuncSetAttribute((const void*)rowT_pass_kernel<R, LINES, IN_P, OUT_P>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
-    hipLaunchKernelGGL((rowT_pass_kernel<R, LINES, IN_P, OUT_P>), dim3(grid), dim3(LINES * R), lds, h->stream, job);
+    if (!rowT_launch(R, job, grid, (size_t)h->lds_limit, h->stream)) return fail(h, MSL_ERR_STATE, "transposing pass: no kernel for flags %d", job.flags);
     HIPCHK(h, hipGetLastError());
     return mark_launch(h, kind);
-}
-template <int R>
-int launch_rowT_r(msl_handle* h, const RowTJob& job, int kind) {
-    const bool in_p = job.flags & P2_IN_PAIRED, out_p = job.flags & P2_OUT_PAIRED;
-    if (in_p) return out_p ? launch_rowT_io<R, true, true>(h, job, kind) : launch_rowT_io<R, true, false>(h, job, kind);
-    return out_p ? launch_rowT_io<R, false, true>(h, job, kind) : launch_rowT_io<R, false, false>(h, job, kind);
 }
 
 // lines of 2 R^2 = 512 points
@@ -877,7 +868,7 @@ int slice_loop_onepass_b(msl_handle* h, int fused_slot, int groups, int first_gr
             j.flags |= (k > 0 ? P2_IN_PAIRED : 0) | (k < nz - 1 ? P2_OUT_PAIRED : 0);
         // 512-point lines next to 512 / 256 / 1024-point ones: interleaved line order between two passes (16-byte loads)
         auto il_kernel = [](const msl_handle::OpDir& o) { return o.R && !o.generic && !o.breg && !o.breg2 && !o.breg4 && !o.wave2k; };
-        if (il_kernel(h->opx) && il_kernel(h->opy) && !dbg_env("MSL_NO_INTERLEAVE")) {
+        if (il_kernel(h->opx) && il_kernel(h->opy) && !dbg_env("MSL_NO_INTERLEAVE") && h->debug_flags_mask < 0) {
             j.flags |= (k > 0 ? P2_IN_PAIRED : 0) | (k < nz - 1 ? P2_OUT_PAIRED : 0);
             j.perm_shift = (((k & 1) ? h->opy : h->opx).R == 32) ? 2 : 1;       // radix of the kernel that reads this pass's output
         }
@@ -967,7 +958,7 @@ int slice_loop_onepass(msl_handle* h, int fused_slot, int groups, int first_grou
         RowTJob j{};
         // between two transposing passes the work buffer is in the interleaved line order (16-byte loads in the reader): the first
         // pass reads the probes, the last transposing pass (k = nz - 2) writes for the in-place pass, both in natural order
-        if (!dbg_env("MSL_NO_INTERLEAVE")) flags |= (k > 0 ? P2_IN_PAIRED : 0) | (k < nz - 2 ? P2_OUT_PAIRED : 0);
+        if (!dbg_env("MSL_NO_INTERLEAVE") && h->debug_flags_mask < 0) flags |= (k > 0 ? P2_IN_PAIRED : 0) | (k < nz - 2 ? P2_OUT_PAIRED : 0);
         j.flags = flags; j.n_images = P;
         j.perm_shift = ((along_y ? h->Rx : h->Ry) == 32) ? 2 : 1;             // radix of the kernel that reads this pass's output: log2(R' / 8)
         if (groups > 1) { j.t_group = c.n_probes; j.t_magic = (unsigned)((1ull << 32) / (unsigned)c.n_probes + 1); j.t_stride = (long long)c.nz * npix; }
@@ -1247,6 +1238,11 @@ int msl_create(const msl_config* cfg, msl_handle** out) {
     (void)hipFuncSetAttribute((const void*)line_fft_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
     (void)hipFuncSetAttribute((const void*)line_fft_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit);
     int rc;
+    {   // the lane <-> register exchange of every register kernel rests on inline asm the compiler cannot check: test it once per process
+        static int exchange_ok = -1;
+        if (exchange_ok < 0) exchange_ok = rowT_selftest(h->stream);
+        if (exchange_ok != 0) return bail(fail(h, MSL_ERR_HIP, "msl_create: the add-tid LDS exchange self-test failed on this device / toolchain (%d values wrong)", exchange_ok));
+    }
     if ((rc = make_plan(h, h->plan_x, cfg->nx))) return bail(rc);
     if ((rc = make_plan(h, h->plan_y, cfg->ny))) return bail(rc);
     {
