@@ -66,6 +66,8 @@ def parse():
     ap.add_argument("--tacaw-frames", type=int, default=TACAW_T,
                     help="frame slots of the TACAW leg (default 256 = BASELINE C3; 100 = the reference notebook's run)")
     ap.add_argument("--no-exchange", action="store_true", help="skip the end-of-run exchange timing (N>1)")
+    ap.add_argument("--no-c3-full", action="store_true",
+                    help="N=1: do not fill the remaining frame slots with REAL frames after the timed region (c3_full block)")
     ap.add_argument("--stream", action="store_true",
                     help="streaming TACAW (the only representable form of BASELINE C5): every frame goes through a ring of --stream-tile "
                          "frame slots (k-window --k-window, detector bin --k-bin) and is folded into the time->frequency transform "
@@ -240,6 +242,11 @@ def run(a):
             slots, tacaw_T = want, want
         else:
             tacaw_T = n_local
+    # BASELINE C3 as configured: after the timed region the remaining slots are filled with REAL frames of the same trajectory
+    # (the synthetic trajectory does not depend on its length: frame f is frame f) and the time FFT runs on them
+    c3_full = (world == 1 and not a.no_c3_full and not a.stream and not strong and tacaw_T is not None and tacaw_T == slots and tacaw_T > n_local)
+    if c3_full:
+        tr = synthetic_trajectory(n, nz, tacaw_T, seed=0)
     from pyslice_amd.calculators import default_frame_batch
     fb = a.frame_batch if a.frame_batch > 0 else default_frame_batch(P, nz, n, n)      # the calculator's own default
     fb = max(1, min(fb, a.steps))
@@ -331,8 +338,10 @@ def run(a):
             dist.barrier()
         torch.cuda.synchronize()
 
+    tw0 = time.perf_counter()
     steps(0, a.warmup)
     fence()
+    dt_warm = time.perf_counter() - tw0
     eng.reset_counters()
     t0 = time.perf_counter()
     steps(a.warmup, a.warmup + a.steps)
@@ -376,20 +385,77 @@ def run(a):
     wf_view = torch.as_tensor(_native.DeviceArray(eng.device_ptr(_native.BUF_WAVEFUNCTION), (P, slots, eng.wx * eng.wy), "<c8", owner=eng),
                               device=dev)
 
-    # ---- TACAW leg (N=1): time FFT over the resident frame slots; slots beyond the computed frames are filled with copies
+    # ---- BASELINE C3 as configured (N=1, after the timed region): every frame slot holds a REAL frame, the time FFT runs on them
+    c3 = None
+    if c3_full:
+        todo = list(range(n_local, tacaw_T))
+        tx0 = time.perf_counter()
+        for i in range(0, len(todo), eng.frame_batch):
+            chunk = todo[i:i + eng.frame_batch]
+            if eng.frame_batch > 1:
+                eng.build_potentials(tr.positions[chunk[0]:chunk[-1] + 1], Z, 2)
+                eng.propagate_frames(chunk[0], len(chunk))
+            else:
+                eng.build_potential(tr.positions[chunk[0]], Z, 2)
+                eng.propagate_frame(chunk[0])
+        fence()
+        dt_extra = time.perf_counter() - tx0
+        c3 = {"frames": tacaw_T, "probes": P, "grid": n, "slices": nz,
+              "frames_in_warmup_and_timed_region": n_local, "frames_after_timed_region": len(todo),
+              "seconds_warmup": round(dt_warm, 3), "seconds_timed_region": round(dt, 3), "seconds_remaining_frames": round(dt_extra, 3),
+              "seconds_propagate": round(dt_warm + dt + dt_extra, 3)}
+
+    # ---- TACAW leg (N=1): time FFT over the resident frame slots; without c3_full the slots beyond the computed frames hold copies
     tacaw = None
     if tacaw_T is not None:
-        for j in range(n_local, tacaw_T):
-            wf_view[:, j].copy_(wf_view[:, j % n_local])
+        if not c3_full:
+            for j in range(n_local, tacaw_T):
+                wf_view[:, j].copy_(wf_view[:, j % n_local])
         torch.cuda.synchronize()
-        eng.tacaw()                                  # warm-up: first touch of the freshly allocated intensity buffer, tables
+        before = eng.counters()["ms_tacaw"]
+        eng.tacaw()                                  # first call: first touch of the freshly allocated intensity buffer, tables
+        ms_first = eng.counters()["ms_tacaw"] - before
         before = eng.counters()["ms_tacaw"]
         eng.tacaw()
         ms = eng.counters()["ms_tacaw"] - before
         tacaw = {"ms": round(ms, 3), "GBps": round(12.0 * P * tacaw_T * npix / (ms * 1e-3) / 1e9, 1), "frames": tacaw_T,
                  "probes": P, "kernel": _tacaw_kernel_name(tacaw_T, npix),
                  "algorithmic_bytes": 12.0 * P * tacaw_T * npix, "frac_of_hbm_peak": round(12.0 * P * tacaw_T * npix / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                 "note": f"{n_local} computed frames, remaining slots filled with copies (timing is data-independent)"}
+                 "first_call_ms": round(ms_first, 3),
+                 "note": ("all slots hold real frames (c3_full)" if c3_full else
+                          f"{n_local} computed frames, remaining slots filled with copies (timing is data-independent)")}
+        if c3_full:
+            # Parseval over the frequency axis, per probe: sum_w I[p,w,k] = T sum_t |Psi|^2 - |sum_t Psi|^2 (the mean subtraction of
+            # tacaw_data.py:94 removes exactly the u = 0 bin); float64 sums over the resident arrays, one probe at a time
+            inten = torch.as_tensor(_native.DeviceArray(eng.device_ptr(_native.BUF_INTENSITY), (P, tacaw_T, npix), "<f4", owner=eng), device=dev)
+            worst = 0.0
+            for pi in range(P):
+                w = wf_view[pi]
+                s2, s1 = 0.0, torch.zeros(npix, dtype=torch.complex128, device=dev)
+                for t0_ in range(0, tacaw_T, 32):
+                    blk = w[t0_:t0_ + 32]
+                    s2 += float((blk.real.double() ** 2).sum() + (blk.imag.double() ** 2).sum())
+                    s1 += blk.sum(dim=0, dtype=torch.complex128)
+                rhs = tacaw_T * s2 - float((s1.real ** 2 + s1.imag ** 2).sum())
+                lhs = float(sum(inten[pi, t0_:t0_ + 32].sum(dtype=torch.float64) for t0_ in range(0, tacaw_T, 32)))
+                worst = max(worst, abs(lhs - rhs) / abs(rhs))
+                del s1
+            # known answer: the synthetic trajectory's atoms oscillate at 10, 25 and 40 THz (pyslice_amd/synthetic.py)
+            spec = np.asarray(eng.tacaw_spectrum()).reshape(P, tacaw_T).sum(axis=0)
+            freqs = np.fft.fftshift(np.fft.fftfreq(tacaw_T, tr.timestep))
+            pos = freqs > 0
+            fpos, spos = freqs[pos], spec[pos]
+            loc = [i for i in range(1, len(spos) - 1) if spos[i] > spos[i - 1] and spos[i] >= spos[i + 1]]
+            loc.sort(key=lambda i: -spos[i])
+            c3.update({"tacaw_ms": round(ms, 3), "tacaw_first_call_ms": round(ms_first, 3),
+                       "seconds_total": round(c3["seconds_propagate"] + ms_first * 1e-3, 3),
+                       "parseval_rel": float(worst),
+                       "spectrum_peak_THz": [round(float(fpos[i]), 2) for i in sorted(loc[:3])],
+                       "frequency_resolution_THz": round(1.0 / (tacaw_T * tr.timestep), 4),
+                       "expected_peaks_THz": [10.0, 25.0, 40.0],
+                       "resident_GB": round((8.0 + 4.0) * P * tacaw_T * npix / 1e9, 1),
+                       "baseline_md_target_seconds": 27.5})
+            del inten
 
     # ---- end-of-run exchanges of the sharded path (N>1), on the frames just computed (run AFTER the bench line is assembled,
     # under a watchdog: see below)
@@ -490,6 +556,8 @@ def run(a):
         }
         if tacaw is not None:
             out["tacaw"] = tacaw
+        if c3 is not None:
+            out["c3_full"] = c3
         if stream_ms is not None:
             out["stream_ms"] = stream_ms
             out["config"]["streaming_tacaw"] = {"ring": slots, "k_window": kw, "k_bin": a.k_bin, "frames_folded": world * n_local}
