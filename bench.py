@@ -357,6 +357,28 @@ def run(a):
 
     dev = torch.device("cuda", local_rank)
     stream_ms = None
+    stream_done = None
+    if stream and world > 1:
+        # the end-of-stream collectives below run over a backend this build could not exercise on multi-GPU hardware: if they
+        # stall, the measurement (already complete) is printed with the failure in place of their timings and the rank exits 3
+        import threading
+        stream_done = threading.Event()
+
+        def stream_watchdog():
+            if not stream_done.wait(a.exchange_timeout):
+                if rank == 0:
+                    line = {"metric": "slice-steps/sec (probes x frames x slices / s), potential + slice loop + exit FFT",
+                            "value": round(frames_timed * P * nz / dt, 1), "unit": "slice-steps/s", "n_gpus": world, "steps": a.steps,
+                            "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": a.scaling,
+                            "vs_baseline": None, "dtype": "complex64 (f32)", "data": "synthetic",
+                            "config": {"workload": f"{P}-probe STEM grid, {n}x{n} grid, {nz} slices, streaming TACAW", "grid": n, "slices": nz,
+                                       "probes": P, "frames_timed": frames_timed, "parallelism": f"frames x{world}"},
+                            "stream_ms": {"error": f"end-of-stream reduce / gather did not finish within {a.exchange_timeout} s"}}
+                    print(json.dumps(line), flush=True)
+                else:
+                    time.sleep(2.0)
+                os._exit(EXIT_EXCHANGE_STALLED)
+        threading.Thread(target=stream_watchdog, daemon=True).start()
     if stream:
         # end of the stream (after the timed region): sum of the ranks' partial sums (reduce-scatter over probes), |.|^2 of this
         # rank's probes, gather of the intensities on rank 0
@@ -382,6 +404,8 @@ def run(a):
                      "accumulator_bytes_per_rank": 8.0 * P * F * K,
                      "intensity_sum": float(full.double().sum()) if full is not None else None}
         del mine, full
+        if stream_done is not None:
+            stream_done.set()
     wf_view = torch.as_tensor(_native.DeviceArray(eng.device_ptr(_native.BUF_WAVEFUNCTION), (P, slots, eng.wx * eng.wy), "<c8", owner=eng),
                               device=dev)
 

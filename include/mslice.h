@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MSL_ABI_VERSION 1
+#define MSL_ABI_VERSION 2   /* 2: reduction / streaming entry points and enum values added in rounds 2-3 */
 
 typedef struct msl_handle msl_handle;
 

@@ -221,6 +221,25 @@ class MultisliceCalculator:
             wx, wy = self._k_window if self._k_window is not None else (nx, ny)
             if wx % self._k_bin[0] or wy % self._k_bin[1]:
                 raise ValueError(f"the stored spectrum {wx} x {wy} is not a multiple of k_bin {self._k_bin}")
+        # Headroom for what is allocated AFTER the engine exists: the phase tables of a frame group (up to 6 GB), the TACAW
+        # intensity array (4 B per stored complex value), the streaming accumulators.  A default batch that passes msl_create
+        # could otherwise run out of memory in the middle of a run (an explicit frame_batch is honoured as is).
+        if self._frame_batch is None and batch > 1 and TORCH_AVAILABLE and torch.cuda.is_available():
+            try:
+                free_b = float(torch.cuda.mem_get_info(_device_index(dev))[0])
+            except Exception:                              # pragma: no cover  (no device visible to torch: msl_create decides)
+                free_b = None
+            if free_b is not None:
+                wx, wy = self._k_window if self._k_window is not None else (nx, ny)
+                bx, by = self._k_bin if self._k_bin is not None else (1, 1)
+                stored = float(self.n_probes) * slots * (wx // bx) * (wy // by)
+                n_atoms = len(trajectory.atom_types)
+                tables = min(6e9, batch * n_atoms * (nx // 2 + ny // 2 + 2) * 8.0)
+                later = tables + 4.0 * stored + (24.0 * stored / slots if self._stream_tile is not None else 0.0)
+                fixed = 8.0 * stored + later + 2e9
+                per_frame = 16.0 * n_slices * nx * ny + 24.0 * nx * ny * self.n_probes
+                while batch > 1 and fixed + batch * per_frame > 0.95 * free_b:
+                    batch = max(1, batch // 2)
         # The frame batch costs batch x (two orientations of the transmission stack + three work buffers): when the device cannot
         # hold it next to the (P, T_local, wx, wy) result -- a result near capacity, a shared or smaller GPU -- halve it down to one
         # frame per launch sequence instead of failing a run that fits without batching (an explicit frame_batch is honoured as is)
@@ -436,7 +455,10 @@ class MultisliceCalculator:
         tot = torch.from_numpy(total).to(dev)
         tac.probe_range = (p0, p1)
         if self._gather == "none":
+            # this rank keeps ITS probes only: the TACAWData's probe list is the shard's (its methods index probes by
+            # len(probe_positions)); probe_range holds the shard's place in the run's probe list
             full, tot_full = mine, tot
+            tac.probe_positions = list(tac.probe_positions)[p0:p1]
         else:
             dst = None if self._gather == "all" else 0
             full = distributed.gather_probes(mine, P, dst=dst)

@@ -429,6 +429,12 @@ LineArgs col_args(const msl_handle* h, const float2* in, float2* out, int images
     return a;
 }
 
+// timing events of one call, destroyed on every exit path
+struct EventPair {
+    hipEvent_t a = nullptr, b = nullptr;
+    ~EventPair() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+};
+
 // Probes per work item of the chunked kernels (a work item = 16 lines x a chunk of probes that share the t_k lines in
 // registers; the grid is `slots` persistent workgroups).  The time of a launch is (rounds of work items over the slots) x
 // (iterations per item): take the chunk that minimises it, the larger one on ties (fewer t_k loads).  Halving until every slot
@@ -1637,7 +1643,7 @@ static int build_potentials(msl_handle* h, const double* pos, const int32_t* Z, 
     int rc;
     // with launch timing off the call only queues work: no event, no host wait (the frames of a run pipeline on the stream)
     const bool timed = h->cfg.launch_timing != 0;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
+    EventPair evp_; hipEvent_t &e0 = evp_.a, &e1 = evp_.b;
     if (timed) {
         HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
         HIPCHK(h, hipEventRecord(e0, h->stream));
@@ -1739,6 +1745,7 @@ static int build_potentials(msl_handle* h, const double* pos, const int32_t* Z, 
             const int* n_sorted = h->d_start + nkeys;
             recip_written = true;
             const long long rows_pad = rows + (long long)(SF_ALIGN - 1) * nkeys;          // sorted rows at most: every bin padded to SF_ALIGN
+            if (rows_pad > 0x7fffffffLL) return fail(h, MSL_ERR_INVALID, "msl_build_potentials: %lld padded table rows in one group exceed 2^31", rows_pad);
             const long long tx = rows_pad * cx, ty = rows_pad * cy;
             hipLaunchKernelGGL(phase_table_kernel, dim3((unsigned)((tx + 255) / 256)), dim3(256), 0, h->stream, h->d_ex, h->d_u1,
                                h->d_order, n_sorted, c.nx, cx, cx);
@@ -1932,7 +1939,6 @@ static int build_potentials(msl_handle* h, const double* pos, const int32_t* Z, 
         float ms = 0.f;
         HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
         h->ctr.ms_potential += ms;
-        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     }
     h->have_potential = true;
     return MSL_OK;
@@ -1992,7 +1998,7 @@ static int run_loop(msl_handle* h, int slot, int groups = 1) {
     if (!h->have_potential) return fail(h, MSL_ERR_STATE, "propagate: no potential (msl_build_potential / msl_upload_potential)");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     if (!h->cfg.launch_timing) return slice_loop(h, slot, groups, first_group);         // queued; msl_synchronize / msl_download wait for it
-    hipEvent_t e0, e1;
+    EventPair evp_; hipEvent_t &e0 = evp_.a, &e1 = evp_.b;
     HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
     HIPCHK(h, hipEventRecord(e0, h->stream));
     int rc = slice_loop(h, slot, groups, first_group);
@@ -2002,7 +2008,6 @@ static int run_loop(msl_handle* h, int slot, int groups = 1) {
     float ms = 0.f;
     HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
     h->ctr.ms_propagate += ms;
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return MSL_OK;
 }
 
@@ -2105,7 +2110,7 @@ int msl_tacaw(msl_handle* h, const void* d_src, void* d_dst, int64_t batch, int3
     } else if ((rc = make_plan(h, h->plan_t, T))) {
         return rc;
     }
-    hipEvent_t e0, e1;
+    EventPair evp_; hipEvent_t &e0 = evp_.a, &e1 = evp_.b;
     HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
     HIPCHK(h, hipEventRecord(e0, h->stream));
     h->cur = nullptr;
@@ -2166,7 +2171,6 @@ int msl_tacaw(msl_handle* h, const void* d_src, void* d_dst, int64_t batch, int3
     float ms = 0.f;
     HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
     h->ctr.ms_tacaw += ms;
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     if (tw4_t) (void)hipFree(tw4_t);
     return MSL_OK;
 }

@@ -32,7 +32,7 @@ how tests/test_distributed.py covers it without a GPU.  No ring all-reduce is us
 """
 from __future__ import annotations
 
-from typing import List, Optional
+from typing import List, NamedTuple, Optional
 
 try:
     import torch
@@ -95,19 +95,97 @@ def _chunk(t):
 MAX_GROUP_OPS = 1024      # point-to-point operations per grouped launch (RCCL bounds the operations of one group)
 
 
-def _exchange(sends, recvs, world):
-    """sends / recvs: [(tensor, peer, ordinal)].  Grouped launches (every pair of GPUs on its own link at once) of at most
-    MAX_GROUP_OPS operations: round k carries the ordinals [k*B, (k+1)*B) -- the ordinal is the probe's position in the
-    sender-to-receiver stream, the same number on both sides, so every rank cuts the rounds at the same places."""
-    per = max(1, MAX_GROUP_OPS // (2 * max(1, world - 1)))
-    top = max([j for _, _, j in sends] + [j for _, _, j in recvs] + [-1])
-    # every rank must run the same number of rounds only if it takes part in them: a round with no operation is skipped locally
-    for lo in range(0, top + 1, per):
-        ops = [dist.P2POp(dist.irecv, t, peer) for t, peer, j in recvs if lo <= j < lo + per and t.numel()]
-        ops += [dist.P2POp(dist.isend, t, peer) for t, peer, j in sends if lo <= j < lo + per and t.numel()]
-        if not ops:
+class Op(NamedTuple):
+    """One point-to-point operation of an exchange plan.  `ordinal` is the operation's position in the stream between its two
+    ranks (the same number on both sides), `round` the grouped launch it belongs to, `where` names the tensor slice."""
+    kind: str          # "send" | "recv"
+    peer: int
+    ordinal: int
+    numel: int         # elements moved (0-element operations are dropped from a plan: on both sides, the sizes agree)
+    round: int
+    where: tuple
+
+
+def _group_size(world: int) -> int:
+    """ordinals per grouped launch: every rank exchanges with at most world - 1 peers in both directions"""
+    return max(1, MAX_GROUP_OPS // (2 * max(1, world - 1)))
+
+
+# ---- plans: pure functions of (rank, world, sizes) -- tests/test_distributed.py builds them for every rank of a world of 8 and
+# checks that every send has its receive in the same round with the same ordinal and size (a mismatched grouped launch on RCCL is a
+# hang, not an error) ----------------------------------------------------------------------------------------------------------
+
+def plan_gather_frames(rank: int, world: int, n_probes: int, n_frames: int, inner: int, dst: Optional[int] = 0) -> List[Op]:
+    """(P, T_r, inner) frame shards -> (P, T, inner) on `dst` (None: everywhere): per probe one contiguous run of T_r frames"""
+    per = _group_size(world)
+    bounds = [shard_bounds(n_frames, world, r) for r in range(world)]
+    receivers = range(world) if dst is None else [dst]
+    ops: List[Op] = []
+    if rank in receivers:
+        for r in range(world):
+            if r != rank:
+                lo, hi = bounds[r]
+                ops += [Op("recv", r, p, (hi - lo) * inner, p // per, ("full", p, lo, hi)) for p in range(n_probes)]
+    lo, hi = bounds[rank]
+    for d in receivers:
+        if d != rank:
+            ops += [Op("send", d, p, (hi - lo) * inner, p // per, ("local", p)) for p in range(n_probes)]
+    return [o for o in ops if o.numel]
+
+
+def plan_frames_to_probes(rank: int, world: int, n_probes: int, n_frames: int, inner: int) -> List[Op]:
+    """all-to-all (P, T_r, inner) -> (P_r, T, inner): my probes' frames of rank r in, rank r's probes' frames of mine out"""
+    per = _group_size(world)
+    tb = [shard_bounds(n_frames, world, r) for r in range(world)]
+    pb = [shard_bounds(n_probes, world, r) for r in range(world)]
+    p0, p1 = pb[rank]
+    mylo, myhi = tb[rank]
+    ops: List[Op] = []
+    for r in range(world):
+        if r == rank:
             continue
-        for req in dist.batch_isend_irecv(ops):
+        lo, hi = tb[r]
+        ops += [Op("recv", r, p - p0, (hi - lo) * inner, (p - p0) // per, ("mine", p - p0, lo, hi)) for p in range(p0, p1)]
+        ops += [Op("send", r, p - pb[r][0], (myhi - mylo) * inner, (p - pb[r][0]) // per, ("local", p)) for p in range(pb[r][0], pb[r][1])]
+    return [o for o in ops if o.numel]
+
+
+def plan_gather_probes(rank: int, world: int, n_probes: int, inner: int, dst: Optional[int] = 0) -> List[Op]:
+    """(P_r, inner) probe shards -> (P, inner) on `dst` (None: everywhere): one operation per pair"""
+    pb = [shard_bounds(n_probes, world, r) for r in range(world)]
+    receivers = range(world) if dst is None else [dst]
+    ops: List[Op] = []
+    if rank in receivers:
+        ops += [Op("recv", r, 0, (pb[r][1] - pb[r][0]) * inner, 0, ("full", pb[r][0], pb[r][1])) for r in range(world) if r != rank]
+    ops += [Op("send", d, 0, (pb[rank][1] - pb[rank][0]) * inner, 0, ("local",)) for d in receivers if d != rank]
+    return [o for o in ops if o.numel]
+
+
+def plan_reduce_probes(rank: int, world: int, n_probes: int, inner: int, itemsize: int, temp_bytes: float = 32e9):
+    """sum-reduce-scatter over probes as a direct exchange: shift s sends the slice of rank (rank + s) % world and receives this
+    rank's slice from rank (rank - s) % world; `per_round` shifts share one grouped launch and one set of receive buffers (sized
+    for the LARGEST probe shard, so every rank cuts the rounds at the same shifts).  Returns (ops, per_round)."""
+    pb = [shard_bounds(n_probes, world, r) for r in range(world)]
+    p0, p1 = pb[rank]
+    biggest = max(b - a for a, b in pb) * inner * itemsize
+    per_round = int(max(1, min(world - 1, temp_bytes // max(1, biggest))))
+    ops: List[Op] = []
+    for s in range(1, world):
+        rnd, slot = (s - 1) // per_round, (s - 1) % per_round
+        to, frm = (rank + s) % world, (rank - s) % world
+        a, b = pb[to]
+        ops.append(Op("send", to, 0, (b - a) * inner, rnd, ("acc", a, b)))
+        ops.append(Op("recv", frm, 0, (p1 - p0) * inner, rnd, ("temp", slot)))
+    return [o for o in ops if o.numel], per_round
+
+
+def _run(ops: List[Op], resolve):
+    """the grouped launches of a plan, round by round (a round without operations is skipped locally); resolve(where) -> tensor"""
+    for rnd in sorted({o.round for o in ops}):
+        batch = [o for o in ops if o.round == rnd]
+        p2p = [dist.P2POp(dist.irecv, resolve(o.where), o.peer) for o in batch if o.kind == "recv"]
+        p2p += [dist.P2POp(dist.isend, resolve(o.where), o.peer) for o in batch if o.kind == "send"]
+        for req in dist.batch_isend_irecv(p2p):
             req.wait()
 
 
@@ -118,22 +196,16 @@ def gather_frames(local, n_frames: int, dst: Optional[int] = 0):
         return local
     local, cplx, dev = _as_real(local)
     P = local.shape[0]
-    bounds = [shard_bounds(n_frames, world, r) for r in range(world)]
-    receivers = range(world) if dst is None else [dst]
+    inner = 1
+    for d in local.shape[2:]:
+        inner *= int(d)
     full = None
-    sends, recvs = [], []
-    if rank in receivers:
+    if dst is None or rank == dst:
         full = _alloc((P, n_frames) + tuple(local.shape[2:]), local.dtype, local.device)
-        lo, hi = bounds[rank]
+        lo, hi = shard_bounds(n_frames, world, rank)
         full[:, lo:hi].copy_(local)
-        for r in range(world):
-            if r != rank:
-                lo, hi = bounds[r]
-                recvs += [(full[p, lo:hi], r, p) for p in range(P)]
-    for d in receivers:
-        if d != rank:
-            sends += [(_chunk(local[p]), d, p) for p in range(P)]
-    _exchange(sends, recvs, world)
+    _run(plan_gather_frames(rank, world, P, n_frames, inner, dst),
+         lambda w: full[w[1], w[2]:w[3]] if w[0] == "full" else _chunk(local[w[1]]))
     return _restore(full, cplx, dev)
 
 
@@ -144,20 +216,15 @@ def frames_to_probes(local, n_frames: int):
         return local
     local, cplx, dev = _as_real(local)
     P = local.shape[0]
-    tb = [shard_bounds(n_frames, world, r) for r in range(world)]
-    pb = [shard_bounds(P, world, r) for r in range(world)]
-    p0, p1 = pb[rank]
+    inner = 1
+    for d in local.shape[2:]:
+        inner *= int(d)
+    p0, p1 = shard_bounds(P, world, rank)
     mine = _alloc((p1 - p0, n_frames) + tuple(local.shape[2:]), local.dtype, local.device)
-    lo, hi = tb[rank]
+    lo, hi = shard_bounds(n_frames, world, rank)
     mine[:, lo:hi].copy_(local[p0:p1])
-    sends, recvs = [], []
-    for r in range(world):
-        if r == rank:
-            continue
-        lo, hi = tb[r]
-        recvs += [(mine[p - p0, lo:hi], r, p - p0) for p in range(p0, p1)]                      # my probes, rank r's frames
-        sends += [(_chunk(local[p]), r, p - pb[r][0]) for p in range(pb[r][0], pb[r][1])]       # rank r's probes, my frames
-    _exchange(sends, recvs, world)
+    _run(plan_frames_to_probes(rank, world, P, n_frames, inner),
+         lambda w: mine[w[1], w[2]:w[3]] if w[0] == "mine" else _chunk(local[w[1]]))
     return _restore(mine, cplx, dev)
 
 
@@ -167,16 +234,16 @@ def gather_probes(local, n_probes: int, dst: Optional[int] = 0):
     if world == 1:
         return local
     local, cplx, dev = _as_real(local)
-    pb = [shard_bounds(n_probes, world, r) for r in range(world)]
-    receivers = range(world) if dst is None else [dst]
+    inner = 1
+    for d in local.shape[1:]:
+        inner *= int(d)
     full = None
-    sends, recvs = [], []
-    if rank in receivers:
+    if dst is None or rank == dst:
         full = _alloc((n_probes,) + tuple(local.shape[1:]), local.dtype, local.device)
-        full[pb[rank][0]:pb[rank][1]].copy_(local)
-        recvs = [(full[pb[r][0]:pb[r][1]], r, 0) for r in range(world) if r != rank]
-    sends = [(_chunk(local), d, 0) for d in receivers if d != rank]
-    _exchange(sends, recvs, world)
+        a, b = shard_bounds(n_probes, world, rank)
+        full[a:b].copy_(local)
+    _run(plan_gather_probes(rank, world, n_probes, inner, dst),
+         lambda w: full[w[1]:w[2]] if w[0] == "full" else _chunk(local))
     return _restore(full, cplx, dev)
 
 
@@ -197,37 +264,43 @@ def reduce_probes(acc, n_probes: int, temp_bytes: float = 32e9):
     On return acc[p0:p1] holds the sum over ALL ranks for this rank's probe range [p0, p1) = shard_bounds(P, world, rank);
     the rest of acc is unchanged (stale partial sums).  Returns (p0, p1).
 
-    Direct exchange: in round s every rank sends the slice of rank (rank + s) % world and receives its own slice from rank
-    (rank - s) % world -- as many rounds at once as `temp_bytes` of receive buffers allow (all world-1 of them when they fit:
-    one grouped launch, every pair of GPUs on its own link), then adds what it received.  Per link: one probe shard of the
-    accumulator; C5 (256 probes x 1024 bins x 128^2 stored pixels on 8 GPUs): 4.3 GB per pair, 30 GB of receive buffers."""
+    Direct exchange (plan_reduce_probes): in shift s every rank sends the slice of rank (rank + s) % world and receives its own
+    slice from rank (rank - s) % world -- as many shifts at once as `temp_bytes` of receive buffers allow (all world-1 of them
+    when they fit: one grouped launch, every pair of GPUs on its own link), then adds what it received.  Per link: one probe shard
+    of the accumulator; C5 (256 probes x 1024 bins x 128^2 stored pixels on 8 GPUs): 4.3 GB per pair, 30 GB of receive buffers.
+    A device that cannot hold the receive buffers halves `temp_bytes` -- on EVERY rank, by agreement (an all-reduce of one flag),
+    because the rounds must be cut at the same shifts everywhere."""
     rank, world = rank_world()
-    pb = [shard_bounds(n_probes, world, r) for r in range(world)]
-    p0, p1 = pb[rank]
+    p0, p1 = shard_bounds(n_probes, world, rank)
     if world == 1:
         return p0, p1
     real, cplx, dev = _as_real(acc)          # under gloo with device data: a host copy (rehearsal path)
     mine = real[p0:p1]
-    shard_bytes = max(1, mine.numel() * mine.element_size())
-    # the same number of shifts per round on every rank: sized for the LARGEST probe shard
-    biggest = max(b - a for a, b in pb) * (real[0].numel() if real.shape[0] else 0) * real.element_size()
-    per_round = int(max(1, min(world - 1, temp_bytes // max(1, biggest))))
-    for s0 in range(1, world, per_round):
-        shifts = range(s0, min(world, s0 + per_round))
-        temp = _alloc((len(shifts),) + tuple(mine.shape), mine.dtype, mine.device)
-        sends, recvs = [], []
-        for i, s in enumerate(shifts):
-            to, frm = (rank + s) % world, (rank - s) % world
-            a, b = pb[to]
-            if b > a:
-                sends.append((_chunk(real[a:b]), to, 0))
-            if p1 > p0:
-                recvs.append((temp[i], frm, 0))
-        _exchange(sends, recvs, world)
-        if p1 > p0:
-            for i in range(len(shifts)):         # fixed order: deterministic sums; in place: no allocation beyond the receive buffers
-                mine.add_(temp[i])
+    inner = 1
+    for d in real.shape[1:]:
+        inner *= int(d)
+    while True:
+        ops, per_round = plan_reduce_probes(rank, world, n_probes, inner, real.element_size(), temp_bytes)
+        temp, ok = None, 1
+        try:
+            temp = _alloc((per_round,) + tuple(mine.shape), mine.dtype, mine.device)
+        except RuntimeError:                 # out of memory (torch.cuda.OutOfMemoryError is a RuntimeError)
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=real.device if dist.get_backend() != "gloo" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            break
         del temp
+        if per_round == 1:
+            raise MemoryError("reduce_probes: no room for one probe shard of receive buffer")
+        temp_bytes = max(1.0, temp_bytes / 2)
+    for rnd in sorted({o.round for o in ops}):
+        batch = [o for o in ops if o.round == rnd]
+        _run(batch, lambda w: temp[w[1]] if w[0] == "temp" else _chunk(real[w[1]:w[2]]))
+        if p1 > p0:
+            for o in sorted((o for o in batch if o.kind == "recv"), key=lambda o: o.where[1]):
+                mine.add_(temp[o.where[1]])  # fixed order (the shifts of the round): deterministic sums, no further allocation
+    del temp
     if dev is not None and p1 > p0:          # gloo rehearsal with device data: write the reduced slice back
         target = torch.view_as_real(acc) if cplx else acc
         target[p0:p1].copy_(mine)

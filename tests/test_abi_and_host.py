@@ -25,7 +25,7 @@ def test_header_symbols_exported(lib):
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in mslice.h but not exported"
     assert declared == set(_native.EXPORTS)
-    assert lib.msl_abi_version() == 1
+    assert lib.msl_abi_version() == 2
 
 
 def test_struct_layouts_match_header(lib):
@@ -155,7 +155,7 @@ def test_m0_is_only_touched_by_the_addtid_exchange(tmp_path):
     # no register kernel of the library spills or falls below two waves per SIMD (the generic LDS line kernels, the fallback for
     # lengths no register kernel serves, are the only ones allowed private memory)
     text = "\n".join(lines)
-    shipped = ["rowT_pass_kernelILi32ELi16E", "rowT_pass_kernelILi16ELi16E", "rowT2_pass_kernelILi16E", "rowTW_pass_kernelILb1ELb1E",
+    shipped = ["rowT2_pass_kernelILi16E", "rowTW_pass_kernelILb1ELb1E",
                "rowTB_pass_kernelILi32E", "rowTB_pass_kernelILi16E", "rowTB2_pass_kernelILb0ELb0E", "rowTC2_pass_kernel",
                "ifftTB_kernelILi32ELb0E", "ifftTB_kernelILi32ELb1E", "ifftTB_kernelILi16ELb0E", "ifftTB_two_kernel", "ifftTB2_kernel", "ifftTW_kernel",
                "ifftT2_kernelILi16ELb0E", "ifftT2_kernelILi16ELb1E",
@@ -171,6 +171,22 @@ def test_m0_is_only_touched_by_the_addtid_exchange(tmp_path):
         vgpr = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1))
         assert scratch == 0, (name, scratch)
         assert vgpr <= (512 if name == "structure_factor_stream_kernel" else 256), (name, vgpr)     # (one wave per SIMD by design)
+    # the transposing pass of 256 / 1024-point lines (rowt_pass.h): every instantiation with compile-time pass flags fits the registers
+    # of two (three) waves per SIMD without private memory; the run-time-flag form (first / last pass of natural-order stacks) spills
+    # the t_k line by design and nothing else
+    rowt = re.findall(r"\.amdhsa_kernel (_ZN3msl16rowT_pass_kernelILi(\d+)ELi16ELb([01])ELb([01])ELi(n?\d+)EEEvNS_7RowTJobE)(.*?)\.end_amdhsa_kernel", text, re.S)
+    assert len(rowt) == 12, [r[0] for r in rowt]
+    for name, R, ip, op, fl, body in rowt:
+        scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1))
+        vgpr = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1))
+        assert vgpr <= (256 if R == "32" else 168), (name, vgpr)
+        assert (scratch == 0) if fl != "n1" else (scratch <= 400), (name, scratch)
+    # ... and waits for its prefetched line with the iteration's 16 stores still in flight: the first run of eight descending vmcnt
+    # waits (the leaf level consuming the eight 16-byte loads of a half line) ends at vmcnt(16) or above, not at vmcnt(0)
+    hot = re.search(r"\n(_ZN3msl16rowT_pass_kernelILi32ELi16ELb1ELb1ELi3EEEvNS_7RowTJobE:.*?)s_endpgm", "\n".join(lines), re.S).group(1)
+    waits = [int(x) for x in re.findall(r"s_waitcnt vmcnt\((\d+)\)", hot)]
+    runs = [waits[i:i + 8] for i in range(len(waits) - 7) if all(waits[i + j] == waits[i] - j for j in range(8))]
+    assert runs and runs[0][-1] >= 16, (waits[:40], runs[:1])
     # the per-lane / wave-split time transforms (92 instantiations): one wave per SIMD where the line needs the 512-register file,
     # never private memory
     timek = re.findall(r"\.amdhsa_kernel (_ZN3msl\d+time_(?:direct|split)_kernel\S*)(.*?)\.end_amdhsa_kernel", text, re.S)

@@ -164,3 +164,82 @@ def test_bench_starts_its_own_ranks_and_relays_a_failure():
                         "--probes", "1", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
     assert '"metric"' not in r.stdout
+
+
+def _check_pairing(plans, world, max_group):
+    """every send of rank s to rank r has exactly one receive on r from s: same round, ordinal and element count, in the same
+    order (a pair's operations are matched by order); no rank enters a round with a peer that the peer skips; no grouped launch
+    holds more than the bound"""
+    for s in range(world):
+        for r in range(world):
+            if s == r:
+                continue
+            sends = [(o.round, o.ordinal, o.numel) for o in plans[s] if o.kind == "send" and o.peer == r]
+            recvs = [(o.round, o.ordinal, o.numel) for o in plans[r] if o.kind == "recv" and o.peer == s]
+            assert sends == recvs, (s, r, sends[:3], recvs[:3])
+            assert sends == sorted(sends), (s, r)                       # rounds ascend along a pair's stream
+            assert all(n > 0 for _, _, n in sends)
+    for rank in range(world):
+        rounds = {}
+        for o in plans[rank]:
+            rounds[o.round] = rounds.get(o.round, 0) + 1
+        assert all(n <= max_group for n in rounds.values()), (rank, max(rounds.values()))
+
+
+@pytest.mark.parametrize("world", [2, 3, 4, 8])
+def test_exchange_plans_pair_up_world8(world):
+    """The exchanges are grouped point-to-point launches; on RCCL a send without its receive in the matching group is a hang, not
+    an error, and no multi-GPU hardware has run them.  The plans are pure functions of (rank, world, sizes): build them for every
+    rank -- BASELINE C4's and C5's shapes and uneven shards (fewer probes than ranks, frame counts that do not divide, receive
+    budgets that force several rounds) -- and check that they pair up, stay inside the group bound, and move the bytes DESIGN.md
+    section 5 states."""
+    from pyslice_amd import distributed as D
+    npix = 1024 * 1024
+    cases = [(64, 256, 2 * npix), (3, 11, 10), (1, 5, 7), (17, 9, 3), (256, 2000, 4)]
+    for P, T, inner in cases:
+        for dst in (0, None, world - 1):
+            plans = [D.plan_gather_frames(r, world, P, T, inner, dst) for r in range(world)]
+            _check_pairing(plans, world, D.MAX_GROUP_OPS)
+            # what the destination receives is everything but its own shard
+            for d in (range(world) if dst is None else [dst]):
+                lo, hi = D.shard_bounds(T, world, d)
+                assert sum(o.numel for o in plans[d] if o.kind == "recv") == P * (T - (hi - lo)) * inner
+        plans = [D.plan_frames_to_probes(r, world, P, T, inner) for r in range(world)]
+        _check_pairing(plans, world, D.MAX_GROUP_OPS)
+        for r in range(world):
+            p0, p1 = D.shard_bounds(P, world, r)
+            lo, hi = D.shard_bounds(T, world, r)
+            assert sum(o.numel for o in plans[r] if o.kind == "recv") == (p1 - p0) * (T - (hi - lo)) * inner
+            assert sum(o.numel for o in plans[r] if o.kind == "send") == (P - (p1 - p0)) * (hi - lo) * inner
+        for dst in (0, None):
+            _check_pairing([D.plan_gather_probes(r, world, P, T * inner, dst) for r in range(world)], world, D.MAX_GROUP_OPS)
+        for temp_bytes in (32e9, 1.0, 3.5 * ((P + world - 1) // world) * inner * 8):
+            both = [D.plan_reduce_probes(r, world, P, inner, 8, temp_bytes) for r in range(world)]
+            assert len({pr for _, pr in both}) == 1                      # every rank cuts the rounds at the same shifts
+            _check_pairing([ops for ops, _ in both], world, D.MAX_GROUP_OPS)
+            per_round = both[0][1]
+            for r, (ops, _) in enumerate(both):
+                p0, p1 = D.shard_bounds(P, world, r)
+                assert sum(o.numel for o in ops if o.kind == "recv") == (world - 1) * (p1 - p0) * inner
+                assert all(o.where[1] < per_round for o in ops if o.kind == "recv")          # receive slots inside the buffer
+    # a small group bound forces several grouped launches per exchange (the probe ordinals cut the rounds)
+    old = D.MAX_GROUP_OPS
+    try:
+        D.MAX_GROUP_OPS = 4 * (world - 1)
+        plans = [D.plan_frames_to_probes(r, world, 19, 13, 3) for r in range(world)]
+        _check_pairing(plans, world, D.MAX_GROUP_OPS)
+        assert max(o.round for ops in plans for o in ops) >= 1
+    finally:
+        D.MAX_GROUP_OPS = old
+    if world == 8:
+        # DESIGN.md section 5, BASELINE C4 (64 probes x 256 frames x 1024^2 complex64 on 8 GPUs)
+        gf = D.plan_gather_frames(0, 8, 64, 256, 2 * npix, 0)
+        assert len(gf) == 64 * 7 and sum(o.numel for o in gf) * 4 == 64 * 224 * npix * 8          # 120.3 GB into rank 0, one group
+        assert {o.round for o in gf} == {0}
+        assert all(o.numel * 4 == 32 * npix * 8 for o in gf)                                       # 268 MB per transfer
+        fp = D.plan_frames_to_probes(3, 8, 64, 256, 2 * npix)
+        assert sum(o.numel for o in fp if o.kind == "send") * 4 == 56 * 32 * npix * 8             # 15.0 GB leave every rank
+        # C5: 256 probes x 1024 bins x 128^2 stored pixels, complex64 accumulators
+        ops, per_round = D.plan_reduce_probes(5, 8, 256, 1024 * 128 * 128 * 2, 4, 32e9)
+        assert per_round == 7 and {o.round for o in ops} == {0}
+        assert all(o.numel * 4 == 32 * 1024 * 128 * 128 * 8 for o in ops)                          # 4.3 GB per link

@@ -135,7 +135,14 @@ def _stream_worker(rank, world, port, q):
         calc = ps.MultisliceCalculator(device=0, progress=False, stream_tile=3, gather="none")
         calc.setup(tr, aperture=30.0, voltage_eV=100e3, probe_positions=pp)
         tac = calc.run_streaming_tacaw()
-        out["shard"] = (tac.probe_range, tac.intensity.cpu().numpy())
+        # the shard's TACAWData indexes ITS probes: spectrum of every local probe, spectrum image, probe-mean diffraction
+        n_loc = tac.probe_range[1] - tac.probe_range[0]
+        assert len(tac.probe_positions) == n_loc
+        out["shard"] = (tac.probe_range, tac.intensity.cpu().numpy(),
+                        [tac.spectrum(b) for b in range(n_loc)], tac.diffraction(None) if n_loc else None)
+        if n_loc:
+            with pytest.raises(ValueError):
+                tac.spectrum(n_loc)                       # one past the shard
         q.put((rank, out))
     finally:
         dist.destroy_process_group()
@@ -188,10 +195,13 @@ def test_ranks_frame_sharded_streaming_tacaw(world):
     assert rel_l2(w["intensity"], iw[:, sel]) < 2e-4
     assert rel_l2(w["total"], iw.sum(axis=1)) < 2e-4
     for r in range(world):
-        (p0, p1), shard = res[r]["shard"]
+        (p0, p1), shard, spectra, diff = res[r]["shard"]
         assert (p0, p1) == shard_bounds(3, world, r)
         if p1 > p0:
             assert rel_l2(shard, inten[p0:p1]) < 2e-4
+            for b, sp in enumerate(spectra):
+                assert rel_l2(sp, inten[p0 + b].sum(axis=(1, 2))) < 2e-4
+            assert rel_l2(diff, inten[p0:p1].sum(axis=1).mean(axis=0)) < 2e-4
 
 
 def test_bench_two_ranks_gloo_rehearsal(tmp_path):
