@@ -44,8 +44,13 @@ __device__ __forceinline__ void mul_table(float2 (&v)[R], TabPtr tab, int ln) {
 template <int R, bool INV, int CH = 8>
 __device__ __forceinline__ void fourstep_split(float2 (&v)[R], float* scratch, const float2* tw, int ln) {
     static_assert(64 % R == 0, "an R-lane group must lie inside one wave: the scratch is ordered per wave only");
-    fft_regs<R, INV>(v);
-    mul_table<R, 1, INV, R, CH>(v, tw, ln);
+    // decimation in time with the twiddles folded into the second transform's leaves (see fourstep_split_addtid) for 16 registers;
+    // with 32 the kernels that use this form (row_pass_pf_kernel, col_pass_kernel: work buffers next to the line) spill on it and
+    // keep the decimation-in-frequency network with its separate twiddle pass
+    constexpr bool DIT = R <= 16;
+    constexpr int LCH = (CH / 2 < dit_leaf_count(R)) ? (CH / 2 > 0 ? CH / 2 : 1) : dit_leaf_count(R);
+    if constexpr (DIT) { fft_regs_dit<R, INV, 0, 1>(v, v); pin_all(v); }
+    else { fft_regs<R, INV>(v); mul_table<R, 1, INV, R, CH>(v, tw, ln); }
 #pragma unroll
     for (int k1 = 0; k1 < R; ++k1) scratch[k1 * (R + 1) + ln] = v[k1].x;
     wave_lds_fence();
@@ -58,7 +63,13 @@ __device__ __forceinline__ void fourstep_split(float2 (&v)[R], float* scratch, c
 #pragma unroll
     for (int n2 = 0; n2 < R; ++n2) v[n2].y = scratch[ln * (R + 1) + n2];
     wave_lds_fence();
-    fft_regs<R, INV>(v);
+    if constexpr (DIT) {
+        dit_leaf_chunks<R, INV, INV ? 2 : 1, R, LCH, 0>(v, v, tw, ln);
+        dit_upper<R, INV, 1>(v);
+        pin_all(v);
+    } else {
+        fft_regs<R, INV>(v);
+    }
 }
 
 // Exchange with ds_write_addtid_b32 stores and 16-byte reads: the store address is M0 + offset + 4 * lane, so it needs no address
@@ -71,48 +82,39 @@ __device__ __forceinline__ void fourstep_split(float2 (&v)[R], float* scratch, c
 // its own s_mov, cost 0.7 % at 1024^2 and 1.8 % at 512^2 -- so the statements stay as they are.
 template <int R, bool INV, int CH = 8>
 __device__ __forceinline__ void fourstep_split_addtid(float2 (&v)[R], const float* scratch_base, unsigned wave_scratch, const float2* tw, int ln, int lane64) {
-    static_assert(64 % R == 0 && R % 4 == 0, "R-lane groups inside one wave; rows are read four floats at a time");
-    constexpr int PW = 68;
-    fft_regs<R, INV>(v);
-    mul_table<R, 1, INV, R, CH>(v, tw, ln);
-    const float* rd = scratch_base + ln * PW + (lane64 / R) * R;
-    // (an s_mov to M0 needs a wait state before an add-tid LDS instruction; the hazard recogniser does not see into inline asm)
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 1" :: "s"(wave_scratch) : "memory");
-#pragma unroll
-    for (int k1 = 0; k1 < R; ++k1) asm volatile("ds_write_addtid_b32 %0 offset:%1" :: "v"(v[k1].x), "n"(k1 * PW * 4) : "memory");
-    wave_lds_fence();
-#pragma unroll
-    for (int g = 0; g < R / 4; ++g) {
-        const float4 q = *reinterpret_cast<const float4*>(rd + 4 * g);
-        v[4 * g].x = q.x; v[4 * g + 1].x = q.y; v[4 * g + 2].x = q.z; v[4 * g + 3].x = q.w;
-    }
-    wave_lds_fence();
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 1" :: "s"(wave_scratch) : "memory");
-#pragma unroll
-    for (int k1 = 0; k1 < R; ++k1) asm volatile("ds_write_addtid_b32 %0 offset:%1" :: "v"(v[k1].y), "n"(k1 * PW * 4) : "memory");
-    wave_lds_fence();
-#pragma unroll
-    for (int g = 0; g < R / 4; ++g) {
-        const float4 q = *reinterpret_cast<const float4*>(rd + 4 * g);
-        v[4 * g].y = q.x; v[4 * g + 1].y = q.y; v[4 * g + 2].y = q.z; v[4 * g + 3].y = q.w;
-    }
-    wave_lds_fence();
-    fft_regs<R, INV>(v);
+    // decimation-in-time form (round 4, see rowt_pass.h): register FFT, exchange, and the twiddles as weights of the second
+    // register FFT's leaf level -- the table is symmetric, the weight of element n2 in lane k1 is T[n2 R + k1] -- 388 + 484
+    // instructions per 32 registers where the decimation-in-frequency network with a separate twiddle pass took 2 x 430 + 128
+    constexpr int LCH = (CH / 2 < dit_leaf_count(R)) ? (CH / 2 > 0 ? CH / 2 : 1) : dit_leaf_count(R);
+    fft_regs_dit<R, INV, 0, 1>(v, v);
+    pin_all(v);
+    exchange_addtid<R>(v, scratch_base, wave_scratch, ln, lane64);
+    dit_leaf_chunks<R, INV, INV ? 2 : 1, R, LCH, 0>(v, v, tw, ln);
+    dit_upper<R, INV, 1>(v);
+    pin_all(v);
 }
 
 // same with a complex scratch of R*(R+1) float2 (column pass: the tile is in LDS anyway)
 template <int R, bool INV, int CH = 8>
 __device__ __forceinline__ void fourstep_c64(float2 (&v)[R], float2* scratch, const float2* tw, int ln) {
     static_assert(64 % R == 0, "an R-lane group must lie inside one wave: the scratch is ordered per wave only");
-    fft_regs<R, INV>(v);
-    mul_table<R, 1, INV, R, CH>(v, tw, ln);
+    constexpr bool DIT = R <= 16;                       // see fourstep_split
+    constexpr int LCH = (CH / 2 < dit_leaf_count(R)) ? (CH / 2 > 0 ? CH / 2 : 1) : dit_leaf_count(R);
+    if constexpr (DIT) { fft_regs_dit<R, INV, 0, 1>(v, v); pin_all(v); }
+    else { fft_regs<R, INV>(v); mul_table<R, 1, INV, R, CH>(v, tw, ln); }
 #pragma unroll
     for (int k1 = 0; k1 < R; ++k1) scratch[k1 * (R + 1) + ln] = v[k1];
     wave_lds_fence();
 #pragma unroll
     for (int n2 = 0; n2 < R; ++n2) v[n2] = scratch[ln * (R + 1) + n2];
     wave_lds_fence();
-    fft_regs<R, INV>(v);
+    if constexpr (DIT) {
+        dit_leaf_chunks<R, INV, INV ? 2 : 1, R, LCH, 0>(v, v, tw, ln);
+        dit_upper<R, INV, 1>(v);
+        pin_all(v);
+    } else {
+        fft_regs<R, INV>(v);
+    }
 }
 
 struct RowJob {
@@ -643,29 +645,38 @@ constexpr int W2K_PITCH = 97;               // floats per k1 row of the transpos
 
 // tw: LDS table T[k1 * 64 + n2] = exp(-2 pi i k1 n2 / 2048) stored at lds_pos64 (lane L reads tw[k1 * 64 + L]); w64: LDS table [h * 32 + m] = (h ? exp(-2 pi i m / 64) : 1);
 // scr: this wave's scratch of 32 * W2K_PITCH floats; L = lane, la = lam64(L), sgn = (L & 1) ? -1 : +1
-template <bool INV, int CH = 8>
-__device__ __forceinline__ void fft2048_wave(float2 (&v)[32], float* scr, const float2* tw, const float2* w64, int L, int la, float sgn) {
+struct NoMid { __device__ __forceinline__ void operator()() const {} };
+// mid(): called between the two halves of the transform (behind the exchange going forward, in front of it going back) -- the
+// transposing pass puts a prefetch slot there
+template <bool INV, int CH = 8, typename Mid = NoMid, bool DIT = true>
+__device__ __forceinline__ void fft2048_wave(float2 (&v)[32], float* scr, const float2* tw, const float2* w64, int L, int la, float sgn, Mid mid = Mid()) {
     constexpr int R = 32;
     const int col = (la & 31) + 48 * (la >> 5);                     // this lane's column n2 = la in a k1 row
     const int rowbase = (L >> 1) * W2K_PITCH + 48 * (L & 1);        // lane (k1, h): row k1, columns m + 32 h
+    // radix-2 step across the lane pair (L, L ^ 1) through DPP; going back the odd lane's W_64^m comes first, going forward it is
+    // left to the leaf level of the register FFT that follows (weights w64: ones on the even lane)
     auto pair_step = [&](bool twiddle_first) {
 #pragma unroll
         for (int c = 0; c < R; c += CH) {
             float2 w[CH];
+            if (twiddle_first) {
 #pragma unroll
-            for (int j = 0; j < CH; ++j) w[j] = w64[(L & 1) * R + c + j];
+                for (int j = 0; j < CH; ++j) w[j] = w64[(L & 1) * R + c + j];
+            }
 #pragma unroll
             for (int j = 0; j < CH; ++j) {
                 float2 x = v[c + j];
                 if (twiddle_first) x = cmulf_conj(x, w[j]);                    // inverse: d' = d~ conj(W_64^m) on the odd lane
-                const float2 r = make_float2(fmaf(sgn, x.x, dpp_swap_pair(x.x)), fmaf(sgn, x.y, dpp_swap_pair(x.y)));
-                v[c + j] = twiddle_first ? r : cmulf(r, w[j]);                 // forward: d = (..) W_64^m on the odd lane
+                v[c + j] = make_float2(fmaf(sgn, x.x, dpp_swap_pair(x.x)), fmaf(sgn, x.y, dpp_swap_pair(x.y)));
+                if constexpr (!DIT) if (!twiddle_first) v[c + j] = cmulf(v[c + j], w64[(L & 1) * R + c + j]);     // (.. ) W_64^m, forward
             }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
+    constexpr int LCH = CH / 2 > 0 ? CH / 2 : 1;                   // leaf butterflies per chunk of table reads
     if constexpr (!INV) {
-        fft_regs<R, false>(v);
+        if constexpr (DIT) { fft_regs_dit<R, false, 0, 1>(v, v); pin_all(v); }
+        else fft_regs<R, false>(v);
         mul_table<R, 1, false, 64, CH>(v, tw, L);
 #pragma unroll
         for (int k1 = 0; k1 < R; ++k1) scr[k1 * W2K_PITCH + col] = v[k1].x;
@@ -679,11 +690,20 @@ __device__ __forceinline__ void fft2048_wave(float2 (&v)[32], float* scr, const 
 #pragma unroll
         for (int m = 0; m < R; ++m) v[m].y = scr[rowbase + m];
         wave_lds_fence();
+        mid();
         pair_step(false);
-        fft_regs<R, false>(v);
+        if constexpr (DIT) {
+            dit_leaf_chunks<R, false, 1, 1, LCH, 0>(v, v, w64, (L & 1) * R);    // (..) W_64^m on the odd lane, folded into the leaves
+            dit_upper<R, false, 1>(v);
+            pin_all(v);
+        } else {
+            fft_regs<R, false>(v);
+        }
     } else {
-        fft_regs<R, true>(v);
+        if constexpr (DIT) { fft_regs_dit<R, true, 0, 1>(v, v); pin_all(v); }
+        else fft_regs<R, true>(v);
         pair_step(true);
+        mid();
 #pragma unroll
         for (int m = 0; m < R; ++m) scr[rowbase + m] = v[m].x;
         wave_lds_fence();
@@ -696,8 +716,14 @@ __device__ __forceinline__ void fft2048_wave(float2 (&v)[32], float* scr, const 
 #pragma unroll
         for (int k1 = 0; k1 < R; ++k1) v[k1].y = scr[k1 * W2K_PITCH + col];
         wave_lds_fence();
-        mul_table<R, 1, true, 64, CH>(v, tw, L);
-        fft_regs<R, true>(v);
+        if constexpr (DIT) {
+            dit_leaf_chunks<R, true, 2, 64, LCH, 0>(v, v, tw, L);               // conj W_2048^{k1 n2}, folded into the leaves
+            dit_upper<R, true, 1>(v);
+            pin_all(v);
+        } else {
+            mul_table<R, 1, true, 64, CH>(v, tw, L);
+            fft_regs<R, true>(v);
+        }
     }
 }
 
@@ -904,7 +930,7 @@ __global__ void __launch_bounds__(512, 2) rowTC2_pass_kernel(RowTJob job) {
         // this wave's branch of the cyclic convolution; afterwards role 0 holds y (outputs 0 .. N-1, the rest zero)
         auto conv = [&]() __attribute__((always_inline)) {
             if (role) mul_wq(std::false_type{});
-            fft2048_wave<false, TCH>(v, scr, tw, w64, L, la, sgn);
+            fft2048_wave<false, TCH, NoMid, false>(v, scr, tw, w64, L, la, sgn);       // (the fused-multiply-add network spills in this kernel)
 #pragma unroll
             for (int c = 0; c < R; c += TCH) {
                 float2 w[TCH];
@@ -914,7 +940,7 @@ __global__ void __launch_bounds__(512, 2) rowTC2_pass_kernel(RowTJob job) {
                 for (int j = 0; j < TCH; ++j) v[c + j] = cmulf(v[c + j], w[j]);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            fft2048_wave<true, TCH>(v, scr, tw, w64, L, la, sgn);
+            fft2048_wave<true, TCH, NoMid, false>(v, scr, tw, w64, L, la, sgn);
             if (role) mul_wq(std::true_type{});
             lds_barrier();                                  // every wave has left its transform: the rows are free
             if (role) {
@@ -1048,8 +1074,11 @@ __global__ void __launch_bounds__(512, 2) rowTW_pass_kernel(RowTJob job) {
     int lb = item / pchunks, pc = item - lb * pchunks, k = 0;
     float2 vn[R];
     if (item < n_items) load_regs(vn, line_ptr(lb, pc, 0), MSL_IC(0), MSL_IC(R));
+    __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): nothing in flight at the loop entry, see rowT_pass_kernel
     float2 tv[R];
     while (item < n_items) {
+        if constexpr (MSL_STAGGER > 0)                  // waves on different SIMDs start an iteration apart, see rowT_pass_kernel
+            for (int i = __builtin_amdgcn_readfirstlane(tid >> 6) & 3; i > 0; --i) __builtin_amdgcn_s_sleep(MSL_STAGGER);
         float2 v[R];
 #pragma unroll
         for (int j = 0; j < R; ++j) v[j] = vn[j];
@@ -1065,10 +1094,13 @@ __global__ void __launch_bounds__(512, 2) rowTW_pass_kernel(RowTJob job) {
             nk = 0; nitem = item + (int)gridDim.x; nlb = lb + step_lb; npc = pc + step_pc;
             if (npc >= pchunks) { npc -= pchunks; ++nlb; }
         }
+        // unconditional prefetch (past the last item: the current line again), one address per iteration
+        const bool more = nitem < n_items;
+        const float2* nptr = line_ptr(more ? nlb : lb, more ? npc : pc, more ? nk : k);
         auto prefetch_part = [&](auto lo_c, auto hi_c) {
             constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
             __builtin_amdgcn_sched_barrier(0);
-            if (nitem < n_items) load_regs(vn, line_ptr(nlb, npc, nk), MSL_IC(LO), MSL_IC(HI));
+            load_regs(vn, nptr, MSL_IC(LO), MSL_IC(HI));
             __builtin_amdgcn_sched_barrier(0);
         };
         if (job.flags & P2_PRE_A) fft2048_wave<false, TCH>(v, scr, tw, w64, L, la, sgn);
