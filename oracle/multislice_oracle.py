@@ -224,9 +224,24 @@ def diffraction(exit_waves: np.ndarray, workers=None) -> np.ndarray:
     return np.fft.fftshift(_fft_pair(workers)[0](exit_waves), axes=(-2, -1))
 
 
+def usable_cores():
+    """CPU cores this process may use (cgroup quota, affinity): the `workers` of the threaded FFT path"""
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def run_frames(box_matrix, positions_t, atomic_numbers, aperture, eV, probe_positions=None,
-               sampling=0.1, slice_thickness=0.5, slice_axis=2, frames=None):
+               sampling=0.1, slice_thickness=0.5, slice_axis=2, frames=None, workers=None):
     """Calculator-level oracle; reference: calculators.py:144-161, 172-186, 256-290.
+    workers: threads of the FFTs (scipy.fft: the same pocketfft transforms as numpy.fft, tests/test_oracle.py checks both paths agree);
+    the long GPU parity tests pass usable_cores().
 
     Returns dict(wavefunction_data (P,T,nx,ny,1) c128, xs, ys, zs, probe_positions).
     """
@@ -240,8 +255,8 @@ def run_frames(box_matrix, positions_t, atomic_numbers, aperture, eV, probe_posi
     pr = batched_probes(base, xs, ys, probe_positions)
     for ti, t in enumerate(frames):
         V = potential(xs, ys, zs, positions_t[t], atomic_numbers, slice_axis)
-        ex = propagate(pr, V, xs, ys, zs, eV)
-        out[:, ti, :, :, 0] = diffraction(ex)
+        ex = propagate(pr, V, xs, ys, zs, eV, workers=workers)
+        out[:, ti, :, :, 0] = diffraction(ex, workers=workers)
     return dict(wavefunction_data=out, xs=xs, ys=ys, zs=zs, probe_positions=probe_positions)
 
 

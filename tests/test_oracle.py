@@ -170,3 +170,15 @@ def test_k1_vacuum_plane_wave():
     assert abs(d[16, 16] - 32 * 32) < 1e-9
     d[16, 16] = 0
     assert np.abs(d).max() < 1e-9
+
+
+def test_threaded_fft_path_of_the_oracle_equals_the_numpy_path():
+    """The long GPU parity tests run the oracle's slice loop with scipy.fft(workers=cores): the same pocketfft transforms as the
+    numpy.fft path that the reference fixtures pin, batched and threaded -- the two must agree to rounding."""
+    from pyslice_amd.synthetic import synthetic_trajectory
+    tr = synthetic_trajectory(96, 5, 2, density=0.1, seed=9)
+    pp = [(3.0, 4.0), (1.5, 7.25)]
+    a = orc.run_frames(tr.box_matrix, tr.positions, tr.atom_types, 30.0, 100e3, pp)["wavefunction_data"]
+    b = orc.run_frames(tr.box_matrix, tr.positions, tr.atom_types, 30.0, 100e3, pp, workers=2)["wavefunction_data"]
+    assert np.linalg.norm(a - b) / np.linalg.norm(a) < 1e-13
+    assert orc.usable_cores() >= 1

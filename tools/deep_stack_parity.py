@@ -32,7 +32,7 @@ def case(n, nz, seed=0, distinct=None):
     eng.close()
     t0 = time.time()
     probes = orc.batched_probes(orc.probe_array(xs, xs, 30.0, 100e3), xs, xs, [(xs[-1] / 2, xs[-1] / 2)])
-    want = orc.propagate(probes, V.astype(np.float64), xs, xs, zs, 100e3)
+    want = orc.propagate(probes, V.astype(np.float64), xs, xs, zs, 100e3, workers=orc.usable_cores())
     err = np.linalg.norm(got - want) / np.linalg.norm(want)
     print(f"{n}x{n} x {nz} slices: exit-wave rel-L2 {err:.2e}   (max |V| {V.max():.0f} V.A, oracle {time.time() - t0:.0f} s)", flush=True)
     return err
