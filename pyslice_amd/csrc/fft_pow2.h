@@ -727,6 +727,85 @@ __device__ __forceinline__ void fft2048_wave(float2 (&v)[32], float* scr, const 
     }
 }
 
+// The same transform with the cheap exchange of the R^2 kernels (round 4; the transposing pass of 2048-point lines).  The line comes in
+// the IDENTITY layout -- element 64 j + L in register j of lane L -- and leaves in the lambda layout above (frequency 64 q + lam64(L)
+// in register q); the inverse takes the lambda layout back to the identity.  With the identity on the writing side a register of
+// all 64 lanes is one row of 64 consecutive floats (ds_write_addtid_b32, no address register, twice the rate of ds_write_b32), and
+// lane (k1, h) reads its 32 values m + 32 h of row k1 as eight ds_read_b128; going back it writes them as eight ds_write_b128 and
+// lane n2 gathers column n2 (32 ds_read_b32).  160 LDS instructions per forward + inverse pair instead of 256; rows of 68 floats
+// (16-byte aligned, conflict-free both ways).  tw: T[k1 * 64 + n2] in natural order; scr_lds: LDS byte address of scr (wave-uniform).
+template <bool INV, int CH = 8>
+__device__ __forceinline__ void fft2048_wave_io(float2 (&v)[32], float* scr, unsigned scr_lds, const float2* tw, const float2* w64, int L, float sgn) {
+    constexpr int R = 32, PW = 68;
+    constexpr int LCH = CH / 2 > 0 ? CH / 2 : 1;
+    float* mine = scr + (L >> 1) * PW + 32 * (L & 1);                // lane (k1, h): row k1, floats [32 h, 32 h + 32)
+    auto pair_step = [&](bool twiddle_first) {
+#pragma unroll
+        for (int c = 0; c < R; c += CH) {
+            float2 w[CH];
+            if (twiddle_first) {
+#pragma unroll
+                for (int j = 0; j < CH; ++j) w[j] = w64[(L & 1) * R + c + j];
+            }
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                float2 x = v[c + j];
+                if (twiddle_first) x = cmulf_conj(x, w[j]);
+                v[c + j] = make_float2(fmaf(sgn, x.x, dpp_swap_pair(x.x)), fmaf(sgn, x.y, dpp_swap_pair(x.y)));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    if constexpr (!INV) {
+        fft_regs_dit<R, false, 0, 1>(v, v);
+        pin_all(v);
+        mul_table<R, 1, false, 64, CH>(v, tw, L);
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 1" :: "s"(scr_lds) : "memory");
+#pragma unroll
+        for (int k1 = 0; k1 < R; ++k1) asm volatile("ds_write_addtid_b32 %0 offset:%1" :: "v"(v[k1].x), "n"(k1 * PW * 4) : "memory");
+        wave_lds_fence();
+#pragma unroll
+        for (int g = 0; g < R / 4; ++g) {
+            const float4 q = *reinterpret_cast<const float4*>(mine + 4 * g);
+            v[4 * g].x = q.x; v[4 * g + 1].x = q.y; v[4 * g + 2].x = q.z; v[4 * g + 3].x = q.w;
+        }
+        wave_lds_fence();
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 1" :: "s"(scr_lds) : "memory");
+#pragma unroll
+        for (int k1 = 0; k1 < R; ++k1) asm volatile("ds_write_addtid_b32 %0 offset:%1" :: "v"(v[k1].y), "n"(k1 * PW * 4) : "memory");
+        wave_lds_fence();
+#pragma unroll
+        for (int g = 0; g < R / 4; ++g) {
+            const float4 q = *reinterpret_cast<const float4*>(mine + 4 * g);
+            v[4 * g].y = q.x; v[4 * g + 1].y = q.y; v[4 * g + 2].y = q.z; v[4 * g + 3].y = q.w;
+        }
+        wave_lds_fence();
+        pair_step(false);
+        dit_leaf_chunks<R, false, 1, 1, LCH, 0>(v, v, w64, (L & 1) * R);        // (..) W_64^m on the odd lane, folded into the leaves
+        dit_upper<R, false, 1>(v);
+        pin_all(v);
+    } else {
+        fft_regs_dit<R, true, 0, 1>(v, v);
+        pin_all(v);
+        pair_step(true);
+#pragma unroll
+        for (int g = 0; g < R / 4; ++g) *reinterpret_cast<float4*>(mine + 4 * g) = make_float4(v[4 * g].x, v[4 * g + 1].x, v[4 * g + 2].x, v[4 * g + 3].x);
+        wave_lds_fence();
+#pragma unroll
+        for (int k1 = 0; k1 < R; ++k1) v[k1].x = scr[k1 * PW + L];
+        wave_lds_fence();
+#pragma unroll
+        for (int g = 0; g < R / 4; ++g) *reinterpret_cast<float4*>(mine + 4 * g) = make_float4(v[4 * g].y, v[4 * g + 1].y, v[4 * g + 2].y, v[4 * g + 3].y);
+        wave_lds_fence();
+#pragma unroll
+        for (int k1 = 0; k1 < R; ++k1) v[k1].y = scr[k1 * PW + L];
+        wave_lds_fence();
+        dit_leaf_chunks<R, true, 2, 64, LCH, 0>(v, v, tw, L);                   // conj W_2048^{k1 n2}, folded into the leaves
+        dit_upper<R, true, 1>(v);
+        pin_all(v);
+    }
+}
+
 // Transposing pass A . t_k . A for lines of any length 513 <= N <= 1024: rowTB_pass_kernel's convolution scheme on fft2048_wave (M = 2048).
 // One wave per line, 8 lines per workgroup.  IN_P / OUT_P: the PAIRED-LINES layout of a work buffer between two such passes --
 // element e of line L at (L/2) * (2 * pitch) + 2 * e + (L & 1) [float2 units], the two lines of a pair interleaved element by
@@ -1015,14 +1094,15 @@ __global__ void __launch_bounds__(512, 2) rowTW_pass_kernel(RowTJob job) {
     float2* plh = w64 + 64;                                   // N/2 + 2: symmetric Fresnel table, first half
     float2* tile = plh + NHT;                                 // LINES * RS
     const int tid = threadIdx.x;
-    for (int i = tid; i < N; i += NT) tw[lds_pos64(i)] = job.tw[i];
+    for (int i = tid; i < N; i += NT) tw[i] = job.tw[i];          // natural order: fft2048_wave_io
     if (tid < 64) w64[tid] = job.tw2[tid];
     for (int i = tid; i <= N / 2; i += NT) plh[lds_pos64(i)] = job.pl[i];
     __syncthreads();
     const int wv = tid >> 6, L = tid & 63, la = lam64(L);
     const float sgn = (L & 1) ? -1.f : 1.f;
     float2* myrow = tile + wv * RS;
-    float* scr = reinterpret_cast<float*>(myrow);
+    float* scr = reinterpret_cast<float*>(myrow + (wv & 1));      // the exchange scratch (32 rows x 68 floats) on a 16-byte boundary: RS is odd
+    const unsigned scr_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)scr);
     const float2* pa = plh + L;                               // P[64 j + lam(L)]
     const float2* pb = plh + lds_mirror64(L);                 // pb[64 r] = P[64 r - lam(L)]
     auto mul_p = [&](float2 (&vv)[R]) {
@@ -1054,7 +1134,7 @@ __global__ void __launch_bounds__(512, 2) rowTW_pass_kernel(RowTJob job) {
     };
     auto line_ptr = [&](int lbb, int pcc, int kk) {
         const int Ln = line_of(lbb);
-        const long long off = IN_P ? (long long)(Ln >> 1) * (2 * job.in_pitch) + (2 * la + (Ln & 1)) * 2 : (long long)Ln * job.in_pitch + la;
+        const long long off = IN_P ? (long long)(Ln >> 1) * (2 * job.in_pitch) + (2 * L + (Ln & 1)) * 2 : (long long)Ln * job.in_pitch + L;     // identity layout: element 64 j + L
         return job.in + (long long)(pcc * PC + kk) * job.in_image_stride + off;
     };
     auto load_regs = [&](float2 (&dst)[R], const float2* r, auto lo_c, auto hi_c) {
@@ -1085,7 +1165,7 @@ __global__ void __launch_bounds__(512, 2) rowTW_pass_kernel(RowTJob job) {
         const int p = pc * PC + k;
         const int cur_lb = lb;
         if (k == 0) {
-            const float2* trow = job.trans + frame_off(job, pc * PC) + (long long)line_of(lb) * N + la;
+            const float2* trow = job.trans + frame_off(job, pc * PC) + (long long)line_of(lb) * N + L;
 #pragma unroll
             for (int j = 0; j < R; ++j) tv[j] = trow[j * 64];
         }
@@ -1103,25 +1183,25 @@ __global__ void __launch_bounds__(512, 2) rowTW_pass_kernel(RowTJob job) {
             load_regs(vn, nptr, MSL_IC(LO), MSL_IC(HI));
             __builtin_amdgcn_sched_barrier(0);
         };
-        if (job.flags & P2_PRE_A) fft2048_wave<false, TCH>(v, scr, tw, w64, L, la, sgn);
+        if (job.flags & P2_PRE_A) fft2048_wave_io<false, TCH>(v, scr, scr_lds, tw, w64, L, sgn);
         prefetch_part(MSL_IC(0), MSL_IC(8));
         if (job.flags & P2_PRE_A) {
             mul_p(v);
-            fft2048_wave<true, TCH>(v, scr, tw, w64, L, la, sgn);
+            fft2048_wave_io<true, TCH>(v, scr, scr_lds, tw, w64, L, sgn);
         }
         prefetch_part(MSL_IC(8), MSL_IC(16));
 #pragma unroll
         for (int j = 0; j < R; ++j) v[j] = cmulf(v[j], tv[j]);
-        if (job.flags & P2_POST_A) fft2048_wave<false, TCH>(v, scr, tw, w64, L, la, sgn);
+        if (job.flags & P2_POST_A) fft2048_wave_io<false, TCH>(v, scr, scr_lds, tw, w64, L, sgn);
         prefetch_part(MSL_IC(16), MSL_IC(24));
         if (job.flags & P2_POST_A) {
             mul_p(v);
-            fft2048_wave<true, TCH>(v, scr, tw, w64, L, la, sgn);
+            fft2048_wave_io<true, TCH>(v, scr, scr_lds, tw, w64, L, sgn);
         }
         prefetch_part(MSL_IC(24), MSL_IC(32));
         wave_lds_fence();
 #pragma unroll
-        for (int j = 0; j < R; ++j) myrow[j * 64 + L] = v[j];          // element 64 j + lam(L) at lds_pos64
+        for (int j = 0; j < R; ++j) myrow[j * 64 + lam64_inv(L)] = v[j];          // element 64 j + L at lds_pos64
         lds_barrier();
         if constexpr (OUT_P) {
             // one 16-byte store = position 2 mm + c of the tile rows 2 i and 2 i + 1 (blocks 2 jp / 2 jp + 1 of the output line pair
