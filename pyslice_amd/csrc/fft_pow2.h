@@ -760,6 +760,7 @@ __device__ __forceinline__ void fft2048_wave_io(float2 (&v)[32], float* scr, uns
         fft_regs_dit<R, false, 0, 1>(v, v);
         pin_all(v);
         mul_table<R, 1, false, 64, CH>(v, tw, L);
+        if constexpr (!(MSL_ABL2 & 4)) {
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 1" :: "s"(scr_lds) : "memory");
 #pragma unroll
         for (int k1 = 0; k1 < R; ++k1) asm volatile("ds_write_addtid_b32 %0 offset:%1" :: "v"(v[k1].x), "n"(k1 * PW * 4) : "memory");
@@ -780,6 +781,7 @@ __device__ __forceinline__ void fft2048_wave_io(float2 (&v)[32], float* scr, uns
             v[4 * g].y = q.x; v[4 * g + 1].y = q.y; v[4 * g + 2].y = q.z; v[4 * g + 3].y = q.w;
         }
         wave_lds_fence();
+        }
         pair_step(false);
         dit_leaf_chunks<R, false, 1, 1, LCH, 0>(v, v, w64, (L & 1) * R);        // (..) W_64^m on the odd lane, folded into the leaves
         dit_upper<R, false, 1>(v);
@@ -788,6 +790,7 @@ __device__ __forceinline__ void fft2048_wave_io(float2 (&v)[32], float* scr, uns
         fft_regs_dit<R, true, 0, 1>(v, v);
         pin_all(v);
         pair_step(true);
+        if constexpr (!(MSL_ABL2 & 4)) {
 #pragma unroll
         for (int g = 0; g < R / 4; ++g) *reinterpret_cast<float4*>(mine + 4 * g) = make_float4(v[4 * g].x, v[4 * g + 1].x, v[4 * g + 2].x, v[4 * g + 3].x);
         wave_lds_fence();
@@ -800,6 +803,7 @@ __device__ __forceinline__ void fft2048_wave_io(float2 (&v)[32], float* scr, uns
 #pragma unroll
         for (int k1 = 0; k1 < R; ++k1) v[k1].y = scr[k1 * PW + L];
         wave_lds_fence();
+        }
         dit_leaf_chunks<R, true, 2, 64, LCH, 0>(v, v, tw, L);                   // conj W_2048^{k1 n2}, folded into the leaves
         dit_upper<R, true, 1>(v);
         pin_all(v);
@@ -1156,9 +1160,21 @@ __global__ void __launch_bounds__(512, 2) rowTW_pass_kernel(RowTJob job) {
     if (item < n_items) load_regs(vn, line_ptr(lb, pc, 0), MSL_IC(0), MSL_IC(R));
     __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): nothing in flight at the loop entry, see rowT_pass_kernel
     float2 tv[R];
+#ifdef MSL_CLOCK
+    const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
     while (item < n_items) {
-        if constexpr (MSL_STAGGER > 0)                  // waves on different SIMDs start an iteration apart, see rowT_pass_kernel
-            for (int i = __builtin_amdgcn_readfirstlane(tid >> 6) & 3; i > 0; --i) __builtin_amdgcn_s_sleep(MSL_STAGGER);
+        // (No stagger of the waves here.  This pass is not at the power limit -- 1 210-1 280 W, 2.29 GHz -- but its eight waves run in
+        // lockstep between the two barriers of an iteration and meet at every exchange: without the tile, the barriers and the store
+        // phase an iteration takes 28.9 k cycles, with the two barriers alone 40.0 k, complete 44.5 k (tools/rowtw_bench.hip,
+        // profiles/r04_k2048_cycles.txt).  Delaying waves by SIMD (0 / 256 / 512 / 768 cycles) costs 2 %, delaying waves 4-7 by 1-6 k
+        // cycles 3 %: MSL_STAGGER_W / MSL_STAGGER_HALF rebuild those experiments.)
+#ifdef MSL_STAGGER_W
+        for (int i = __builtin_amdgcn_readfirstlane(tid >> 6) & 3; i > 0; --i) __builtin_amdgcn_s_sleep(MSL_STAGGER_W);
+#endif
+#ifdef MSL_STAGGER_HALF
+        if (__builtin_amdgcn_readfirstlane(tid >> 8)) __builtin_amdgcn_s_sleep(MSL_STAGGER_HALF);
+#endif
         float2 v[R];
 #pragma unroll
         for (int j = 0; j < R; ++j) v[j] = vn[j];
@@ -1180,9 +1196,10 @@ __global__ void __launch_bounds__(512, 2) rowTW_pass_kernel(RowTJob job) {
         auto prefetch_part = [&](auto lo_c, auto hi_c) {
             constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
             __builtin_amdgcn_sched_barrier(0);
-            load_regs(vn, nptr, MSL_IC(LO), MSL_IC(HI));
+            if constexpr (!(MSL_ABL2 & 1)) load_regs(vn, nptr, MSL_IC(LO), MSL_IC(HI));
             __builtin_amdgcn_sched_barrier(0);
         };
+        if constexpr (MSL_ABL2 & 8) job.flags = 0;
         if (job.flags & P2_PRE_A) fft2048_wave_io<false, TCH>(v, scr, scr_lds, tw, w64, L, sgn);
         prefetch_part(MSL_IC(0), MSL_IC(8));
         if (job.flags & P2_PRE_A) {
@@ -1199,11 +1216,22 @@ __global__ void __launch_bounds__(512, 2) rowTW_pass_kernel(RowTJob job) {
             fft2048_wave_io<true, TCH>(v, scr, scr_lds, tw, w64, L, sgn);
         }
         prefetch_part(MSL_IC(24), MSL_IC(32));
+        if constexpr (MSL_ABL2 & 32) {
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < R; ++j) acc += v[j].x + v[j].y;
+            if (acc == 1.2345e-30f) job.out[tid] = make_float2(acc, acc);
+            item = nitem; lb = nlb; pc = npc; k = nk;
+            continue;
+        }
         wave_lds_fence();
+        if constexpr (!(MSL_ABL2 & 128)) {
 #pragma unroll
         for (int j = 0; j < R; ++j) myrow[j * 64 + lam64_inv(L)] = v[j];          // element 64 j + L at lds_pos64
+        }
         lds_barrier();
-        if constexpr (OUT_P) {
+        if constexpr (MSL_ABL2 & 64) {
+        } else if constexpr (OUT_P) {
             // one 16-byte store = position 2 mm + c of the tile rows 2 i and 2 i + 1 (blocks 2 jp / 2 jp + 1 of the output line pair
             // mm); eight lanes (i, c) make a 128-byte run; the four octets of a half-wave take pairs 8 positions apart (LDS banks)
             const int i8 = tid & 7, i = i8 >> 1, c = i8 & 1, oct = tid >> 3, q = oct & 3, hh = oct >> 2;
@@ -1216,6 +1244,9 @@ __global__ void __launch_bounds__(512, 2) rowTW_pass_kernel(RowTJob job) {
 #pragma unroll
             for (int it = 0; it < N / 2 / 64; ++it) {
                 const float2 a = src[it * 128], b = src[RS + it * 128];
+#if MSL_ABL2 & 2
+                if (a.x == 1.2345e-30f)
+#endif
                 st_stream(dst + (off0 + it * ostep), a.x, a.y, b.x, b.y);
             }
         } else {
@@ -1234,6 +1265,12 @@ __global__ void __launch_bounds__(512, 2) rowTW_pass_kernel(RowTJob job) {
         lds_barrier();
         item = nitem; lb = nlb; pc = npc; k = nk;
     }
+#ifdef MSL_CLOCK
+    if (tid == 0 && job.clk) {
+        job.clk[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - clk0;
+        job.clk[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - rt0;
+    }
+#endif
 }
 
 // ---- lines of N = 2 R^2 points (512 = 2*16^2) ---------------------------------------------------------------

@@ -273,3 +273,28 @@ def test_bench_line_survives_a_stalled_exchange():
     assert len(line) == 1, r.stdout
     j = json.loads(line[0])
     assert j["n_gpus"] == 2 and j["value"] > 0 and "did not finish" in j["exchange_ms"]["error"]
+
+
+def test_bench_single_gpu_line_and_c3_full_block():
+    """`python bench.py` at N = 1 in small: one JSON line with the roofline and cpu_baseline objects, and the c3_full block --
+    after the timed region the remaining frame slots are filled with REAL frames, the time FFT runs on them, Parseval over the
+    frequency axis holds, sampled time series agree with a float64 FFT and the trajectory's phonon peaks are found (timestep
+    0.005 ps, 64 frames: 3.1 THz per bin)."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--grid", "256", "--slices", "8", "--probes", "4", "--steps", "8",
+                        "--warmup", "4", "--tacaw-frames", "64", "--cpu-slices", "4"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1, r.stdout
+    j = json.loads(line[0])
+    assert j["n_gpus"] == 1 and j["value"] > 0 and j["roofline"]["bound"] == "hbm" and 0 < j["roofline"]["frac"] < 1
+    assert j["cpu_baseline"]["value"] > 0 and j["cpu_baseline"]["cores"] == 1
+    c3 = j["c3_full"]
+    assert c3["frames"] == 64 and c3["frames_in_warmup_and_timed_region"] == 12 and c3["frames_after_timed_region"] == 52
+    assert c3["parseval_rel"] < 1e-4 and c3["time_fft_worst_series_rel_l2"] < 2e-4
+    assert j["tacaw"]["frames"] == 64 and "real frames" in j["tacaw"]["note"]
+    assert len(c3["spectrum_peak_THz"]) == 3 and min(abs(p - 25.0) for p in c3["spectrum_peak_THz"]) <= c3["frequency_resolution_THz"]
