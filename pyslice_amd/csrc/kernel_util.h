@@ -60,6 +60,21 @@ __device__ __forceinline__ void pin_all(float2 (&v)[N]) {
     for (int j = 0; j < N; ++j) pin(v[j]);
 }
 
+// Raw buffer loads: a descriptor in 4 SGPRs, a byte offset in one more (SALU arithmetic) and ONE 32-bit lane offset register -- no
+// 64-bit address pair per load in flight, no vector address arithmetic.  aux 2 = "nt" (the non-temporal hint of ld_stream).
+// num_bytes: the buffer unit returns zero for offsets past it (-1: no bound; offsets are 32-bit either way).
+typedef int msl_i4v __attribute__((ext_vector_type(4)));
+__device__ msl_f2v msl_raw_buffer_load_f2(msl_i4v rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v2f32");
+__device__ __forceinline__ msl_i4v make_raw_rsrc(const void* base, unsigned num_bytes = 0xffffffffu) {          // stride 0
+    const unsigned long long a = (unsigned long long)base;
+    msl_i4v r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r.y = __builtin_amdgcn_readfirstlane((int)((a >> 32) & 0xffffu));
+    r.z = __builtin_amdgcn_readfirstlane((int)num_bytes);
+    r.w = 0x00020000;
+    return r;
+}
+
 // workgroup barrier that drains LDS traffic only (global loads/stores stay in flight across it)
 __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");

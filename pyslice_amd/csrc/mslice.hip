@@ -1761,11 +1761,15 @@ static int build_potentials(msl_handle* h, const double* pos, const int32_t* Z, 
             if (sf_stream) {
                 // persistent form, one wave per SIMD: one workgroup per CU, a multiple of 8 (XCD-local slices)
                 const int n_pers = std::max(8, h->n_cus / 8 * 8);
-                hipLaunchKernelGGL(structure_factor_stream_kernel, dim3((unsigned)n_pers), dim3(256), 0, h->stream, TR, h->d_ex, h->d_ey, h->d_ff,
-                                   h->d_start, nsp, c.nx, c.ny, tiles_y, n_tiles, (int)rows_pad, half_rows ? 0 : 1, cx, cy, n_slices);
+                if (dbg_env("MSL_SF_F32"))                   // the exact-f32 matrix instruction (A/B against the split-bf16 form)
+                    hipLaunchKernelGGL(structure_factor_stream_kernel, dim3((unsigned)n_pers), dim3(256), 0, h->stream, TR, h->d_ex, h->d_ey, h->d_ff,
+                                       h->d_start, nsp, c.nx, c.ny, tiles_y, n_tiles, (int)rows_pad, half_rows ? 0 : 1, cx, cy, n_slices);
+                else
+                    hipLaunchKernelGGL(structure_factor_stream_bf16_kernel, dim3((unsigned)n_pers), dim3(256), 0, h->stream, TR, h->d_ex, h->d_ey, h->d_ff,
+                                       h->d_start, nsp, c.nx, c.ny, tiles_y, n_tiles, (int)rows_pad, half_rows ? 0 : 1, cx, cy, n_slices);
             } else
-            hipLaunchKernelGGL(structure_factor_quad_kernel, dim3((unsigned)n_wg), dim3(256), 0, h->stream, TR, h->d_ex, h->d_ey, h->d_ff,
-                               h->d_start, nsp, c.nx, c.ny, tiles_y, n_tiles, (int)rows_pad, half_rows ? 0 : 1, cx, cy, n_slices, wg_per_slice);
+                hipLaunchKernelGGL(structure_factor_quad_kernel, dim3((unsigned)n_wg), dim3(256), 0, h->stream, TR, h->d_ex, h->d_ey, h->d_ff,
+                                   h->d_start, nsp, c.nx, c.ny, tiles_y, n_tiles, (int)rows_pad, half_rows ? 0 : 1, cx, cy, n_slices, wg_per_slice);
             if (edge_x || edge_y) {
                 const int bins = (edge_x ? cy : 0) + (edge_y ? (edge_x ? cx - 1 : cx) : 0);
                 for (int s0 = 0; s0 < n_slices; s0 += 65535) {

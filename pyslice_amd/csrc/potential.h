@@ -9,6 +9,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "kernel_util.h"
 
 namespace msl {
 
@@ -75,7 +76,7 @@ __global__ void atom_prep_kernel(const double* __restrict__ pos, const int* __re
 // every thread a contiguous share, the shares' totals scanned through the LDS.  `align` (1 or SF_ALIGN = 8): every bin is rounded up
 // to a multiple of that many rows -- the phase tables get zero rows there (order = -1) -- for structure_factor_stream_kernel, which
 // walks whole half-trips of 8 atoms without masks.  start[nkeys] = rows of the sorted tables, padding included.
-#define SF_ALIGN 8
+#define SF_ALIGN 16         // rows per trip of structure_factor_stream_bf16_kernel (the f32 kernel walks half-trips of 8)
 __global__ void __launch_bounds__(1024) bin_scan_kernel(const int* __restrict__ counts, int* __restrict__ start, int nkeys, int align) {
     __shared__ int part[1024];
     const int t = threadIdx.x;
@@ -366,6 +367,140 @@ __global__ void __launch_bounds__(256, 1) structure_factor_stream_kernel(float2*
         }
     }
 }
+
+// The streaming kernel on the bf16 matrix instruction at fp32 accuracy (round 4).  The exact-f32 MFMA runs at the vector rate (64
+// cycles per 32x32x2 step and SIMD) and the kernel above is bound by it (its waves are issue-stalled on the matrix pipe 65 % of their
+// cycles, profiles/r04_c3_summary.json).  v_mfma_f32_32x32x16_bf16 does eight times the multiply-adds in half the cycles; a float
+// is split in registers into three bf16 pieces, x = h + m + l (|m| <= 2^-8 |h|, |l| <= 2^-16 |h|), and a product keeps the six terms
+// down to 2^-16: hh + hm + mh + hl + lh + mm -- relative error ~2^-24 per product, accumulation in f32 inside the matrix unit as
+// before.  6 x 4 = 24 instructions of 32 cycles per 16 atoms instead of 32 of 64 cycles, plus ~180 vector instructions for the
+// splits, which issue while the matrix pipe works.  A trip is 16 rows (atoms): lane (i, kk) holds rows 8 kk .. 8 kk + 7 of frequency i
+// as the matrix operand; bins are padded to SF_ALIGN = 16 rows.  Everything else -- persistent waves, species flush with the weights
+// f_Z, quadrant store -- is the kernel above.
+typedef unsigned sf_u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 sf_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float sf_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned sf_pk_bf16(float a, float b) {
+    const sf_f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, sf_bf16x2));          // v_cvt_pk_bf16_f32 (round to nearest even)
+}
+// (a, b) -> packed bf16 pairs of the three pieces
+__device__ __forceinline__ void sf_split3(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+    h = sf_pk_bf16(a, b);
+    const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
+    m = sf_pk_bf16(ra, rb);
+    l = sf_pk_bf16(ra - __uint_as_float(m << 16), rb - __uint_as_float(m & 0xffff0000u));
+}
+__global__ void __launch_bounds__(256, 1) structure_factor_stream_bf16_kernel(float2* __restrict__ recip, const float2* __restrict__ ex,
+                                                                           const float2* __restrict__ ey, const float* __restrict__ ff,
+                                                                           const int* __restrict__ start, int n_species, int nx, int ny,
+                                                                           int tiles_y, int n_tiles, int n_rows, int write_mx, int px_pitch,
+                                                                           int py_pitch, int n_slices) {
+    const int xcd = blockIdx.x & 7, jw = blockIdx.x >> 3, wg_x = gridDim.x >> 3;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hx = nx / 2, hy = ny / 2;
+    const int i = lane & 31, kk = lane >> 5;
+    const int G = (n_tiles + 3) / 4, Mx = (n_slices + 7) / 8;
+    for (int q = jw; q < Mx * G; q += wg_x) {
+        const int m = q / G, g = q - m * G;
+        const int s = xcd + 8 * m, tile = 4 * g + wave;
+        if (s >= n_slices || tile >= n_tiles) continue;
+        const int kx0 = (tile / tiles_y) * 32, ky0 = (tile % tiles_y) * 32;
+        const int lx = min(kx0 + i, hx), ly = min(ky0 + i, hy);
+        const int* st = start + s * n_species;
+        const int S0 = __builtin_amdgcn_readfirstlane(st[0]), S1 = __builtin_amdgcn_readfirstlane(st[n_species]);
+        const int H = (S1 - S0) >> 4;                   // whole trips of 16 rows: every bin is padded to a multiple of 16
+        // the slice's rows of the two phase tables as raw buffers (zero past the table's end: no row clamp, no vector address
+        // arithmetic); lane (i, kk) reads rows 8 kk + u of a trip at frequency lx / ly: one lane offset per table, row offsets scalar
+        const unsigned rows_left = (unsigned)(n_rows - S0);
+        const msl_i4v rx = make_raw_rsrc(ex + (size_t)S0 * px_pitch, (unsigned)((unsigned long long)rows_left * px_pitch * 8ull < 0xfffffff0ull ? (unsigned long long)rows_left * px_pitch * 8ull : 0xfffffff0ull));
+        const msl_i4v ry = make_raw_rsrc(ey + (size_t)S0 * py_pitch, (unsigned)((unsigned long long)rows_left * py_pitch * 8ull < 0xfffffff0ull ? (unsigned long long)rows_left * py_pitch * 8ull : 0xfffffff0ull));
+        const int vox = (8 * kk * px_pitch + lx) * 8, voy = (8 * kk * py_pitch + ly) * 8;
+        f32x16 tA = {0}, tB = {0}, tC = {0}, tD = {0};
+        f32x16 A = {0}, B = {0}, C = {0}, D = {0};
+        int sp = -1, seg1 = S0, spn = -1, segn1 = S0;
+        auto next_of = [&](int& k, int& e) { const int from = e; do { ++k; if (k >= n_species) return; e = st[k + 1]; } while (e <= from); };
+        float wc[16], wn[16];
+        auto load_w = [&](int spc, float (&w)[16]) {
+            const float* f = ff + (size_t)spc * nx * ny;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) w[r] = f[(size_t)min(kx0 + (r & 3) + 8 * (r >> 2) + 4 * kk, hx) * ny + ly];
+        };
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { wc[r] = 0.f; wn[r] = 0.f; }
+        next_of(sp, seg1);
+        spn = sp; segn1 = seg1;
+        if (sp < n_species) { load_w(sp, wc); next_of(spn, segn1); if (spn < n_species) load_w(spn, wn); }
+        auto flush = [&]() {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                tA[r] = fmaf(wc[r], A[r], tA[r]); tB[r] = fmaf(wc[r], B[r], tB[r]);
+                tC[r] = fmaf(wc[r], C[r], tC[r]); tD[r] = fmaf(wc[r], D[r], tD[r]);
+                A[r] = 0.f; B[r] = 0.f; C[r] = 0.f; D[r] = 0.f;
+                wc[r] = wn[r];
+            }
+            sp = spn; seg1 = segn1;
+            if (sp < n_species) { next_of(spn, segn1); if (spn < n_species) load_w(spn, wn); }
+        };
+        auto load16 = [&](int h, float2 (&x)[8], float2 (&y)[8]) {
+            const int r0 = __builtin_amdgcn_readfirstlane(16 * h);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const msl_f2v a = msl_raw_buffer_load_f2(rx, vox, (r0 + u) * px_pitch * 8, 0);
+                const msl_f2v b = msl_raw_buffer_load_f2(ry, voy, (r0 + u) * py_pitch * 8, 0);
+                x[u] = make_float2(a.x, a.y); y[u] = make_float2(b.x, b.y);
+            }
+        };
+        auto mma = [&](f32x16& acc, const sf_u32x4& a, const sf_u32x4& b) { asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b)); };
+        auto mma6 = [&](f32x16& acc, const sf_u32x4 (&p)[3], const sf_u32x4 (&q)[3]) {      // all six kept terms of one real product sum
+            mma(acc, p[0], q[0]); mma(acc, p[0], q[1]); mma(acc, p[1], q[0]);
+            mma(acc, p[0], q[2]); mma(acc, p[2], q[0]); mma(acc, p[1], q[1]);
+        };
+        // one plane (cos or sin along one axis) of a raw trip -> its three bf16 pieces, 8 rows packed in pairs: 44 vector instructions
+        auto conv = [&](sf_u32x4 (&o)[3], const float2 (&v)[8], bool imag) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                unsigned p0, p1, p2;
+                sf_split3(imag ? v[2 * u].y : v[2 * u].x, imag ? v[2 * u + 1].y : v[2 * u + 1].x, p0, p1, p2);
+                o[0][u] = p0; o[1][u] = p1; o[2][u] = p2;
+            }
+        };
+        // ONE set of split operands (48 registers) and two raw sets (64): a plane is converted for the next trip as soon as the last
+        // matrix instruction that reads its current contents has issued -- cx after A and C, cy after D, sx and sy after B -- so the
+        // 176 vector instructions of a trip's splits issue between its matrix instructions (the matrix pipe works meanwhile):
+        //     A(cx,cy)  [sy, sx of THIS trip]   C(cx,sy)  [cx of the next]   D(sx,cy)  [cy of the next]   B(sx,sy)
+        sf_u32x4 cx[3], sx[3], cy[3], sy[3];
+        // (x, y): the raw set of this trip -- its sin planes are converted first, then it is free and takes the loads of trip h + 2,
+        // one trip ahead of their first use; (xn, yn): the raw set of the next trip, whose cos planes are converted here
+        auto trip = [&](int h, float2 (&x)[8], float2 (&y)[8], const float2 (&xn)[8], const float2 (&yn)[8]) {
+            if (S0 + 16 * h == seg1) flush();               // the species ended with the previous trip
+            mma6(A, cx, cy); conv(sy, y, true); conv(sx, x, true); __builtin_amdgcn_sched_barrier(0);
+            load16(h + 2, x, y); __builtin_amdgcn_sched_barrier(0);
+            mma6(C, cx, sy); conv(cx, xn, false); __builtin_amdgcn_sched_barrier(0);
+            mma6(D, sx, cy); conv(cy, yn, false); __builtin_amdgcn_sched_barrier(0);
+            mma6(B, sx, sy); __builtin_amdgcn_sched_barrier(0);
+        };
+        float2 x0[8], y0[8], x1[8], y1[8];
+        if (H > 0) { load16(0, x0, y0); load16(1, x1, y1); conv(cx, x0, false); conv(cy, y0, false); }
+        for (int h = 0; h < H; h += 2) {
+            trip(h, x0, y0, x1, y1);
+            if (h + 1 < H) trip(h + 1, x1, y1, x0, y0);
+        }
+        if (H > 0) flush();
+        float2* out = recip + (size_t)s * nx * ny;
+        const int my = ky0 + i;
+        if (my > hy) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int mx = kx0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+            if (mx > hx) continue;
+            store_quad_bin(out, nx, ny, mx, my, tA[r], tB[r], tC[r], tD[r], write_mx);
+        }
+    }
+}
+
+// (The tiled kernel for few atoms per bin keeps the exact-f32 instruction: with 4-5 trips per bin the splits are not hidden and trips of
+// 16 rows waste a fifth of them -- a split-bf16 form of it measured 7 % slower on 512^2 / 501^2 / 256^2 single-probe runs.)
 
 // The Nyquist row mx = nx/2 (edge_x) and / or column my = ny/2 (edge_y) of a slice by direct summation -- (nx/2 + ny/2 + 1) bins
 // x the slice's atoms: along the row every thread shares the atom's x phase and reads consecutive y phases, along the column the

@@ -38,17 +38,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 // (SALU arithmetic) and ONE 32-bit lane offset register for all rows.  Written as plain pointer arithmetic the same loads come
 // out with a 64-bit address pair per row, advanced by VALU adds: two registers per load in flight, which this kernel cannot
 // spare.  (LLVM intrinsic declared here; aux 2 = "nt", the non-temporal hint of ld_stream.)
-typedef int msl_i4v __attribute__((ext_vector_type(4)));
-__device__ msl_f2v msl_raw_buffer_load_f2(msl_i4v rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v2f32");
-__device__ __forceinline__ msl_i4v make_raw_rsrc(const void* base) {          // stride 0, no bound (offsets are 32-bit)
-    const unsigned long long a = (unsigned long long)base;
-    msl_i4v r;
-    r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
-    r.y = __builtin_amdgcn_readfirstlane((int)((a >> 32) & 0xffffu));
-    r.z = -1;
-    r.w = 0x00020000;
-    return r;
-}
+// (msl_raw_buffer_load_f2 / make_raw_rsrc: kernel_util.h)
 
 __host__ __device__ constexpr int tdir_prefetch(int T) { return T < 216 - T ? T : 216 - T; }
 constexpr int TDIR_MIN = 16, TDIR_MAX = 128;
