@@ -590,7 +590,9 @@ def test_randomised_potential_sweep(ps, orc):
 
 @pytest.mark.parametrize("nx,ny,nz,n_atoms,batch", [(96, 80, 3, 1500, 1), (128, 128, 2, 2100, 3), (64, 250, 1, 400, 1), (256, 256, 4, 1100, 2)])
 def test_structure_factor_stream_kernel_dense_slices(ps, orc, nx, ny, nz, n_atoms, batch):
-    """From 128 atoms per (slice, species) on the potential takes structure_factor_stream_kernel (persistent, the rows of every bin
+    """From 128 atoms per (slice, species) on the potential takes structure_factor_stream_bf16_kernel (three-way bf16 split of
+    every factor on the matrix instruction, f32 accumulation; measured 1.1e-7 .. 1.3e-7 of max|V|, the same as the f32 kernel;
+    persistent, the rows of every bin
     padded to whole half-trips of 8, species flushed at half-trip boundaries): three species of which one is missing from a
     slice and one slice holds a single species, bin sizes that are and are not multiples of 8, several frames per build, odd grid
     lengths; and just below the threshold the tiled kernel on the same kind of input.  Transmission functions against the

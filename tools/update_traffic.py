@@ -4,8 +4,10 @@ collection of tools/collect_kernel_profile.sh, and tie it to the kernel sources 
     python tools/update_traffic.py <tag> <profiles/summary-name.json>
 
 copies gpurun_out/<tag>/summary.json to the given tracked name and records the dominant slice-loop kernel, its traffic per
-launch and sha256 over pyslice_amd/csrc/*.  bench.py recomputes the hash at run time and reports traffic = null when the
-sources have changed since the counters were taken (a stale constant must not ride along with a new kernel).
+launch and sha256 over the sources the slice-loop passes are compiled from (LOOP_SOURCES: the pass kernels, the register FFTs, their
+launchers; not the potential / TACAW / reduction kernels or the host code, which cannot change a pass's traffic).  bench.py recomputes
+the hash at run time and reports traffic = null when those sources have changed since the counters were taken (a stale constant
+must not ride along with a new kernel).
 """
 import hashlib
 import json
@@ -16,13 +18,15 @@ import sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+LOOP_SOURCES = ("fft_pow2.h", "fft_regs.h", "kernel_util.h", "rowt_pass.h", "slice_pass.hip")
+
+
 def csrc_sha256():
     h = hashlib.sha256()
     d = os.path.join(REPO, "pyslice_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".h", ".hip")):
-            h.update(f.encode())
-            h.update(open(os.path.join(d, f), "rb").read())
+    for f in LOOP_SOURCES:
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()
 
 
