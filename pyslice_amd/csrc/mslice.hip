@@ -14,6 +14,7 @@
 #include "../../include/mslice.h"
 #include "fft_generic.h"
 #include "fft_pow2.h"
+#include "rowtm_pass.h"
 #include "potential.h"
 #include "reduce.h"
 #include "stream.h"
@@ -77,7 +78,8 @@ struct msl_handle {
     // one-pass kernel per direction: R^2 register kernel, 2 R^2 (two) register kernel with its tables, or the generic LDS kernel
     // (breg: any length <= R^2/2 by Bluestein's chirp-z on the R^2 register FFTs, with its filter bf and chirp bw)
     // (breg2: lengths 513..1024 by the same scheme on the wave-per-line 2048-point FFT; tw = T[k1*64+n2], tw2 = W_64 table)
-    struct OpDir { int R = 0; bool two = false; bool generic = false; bool breg = false; bool breg2 = false; bool breg4 = false; bool wave2k = false; float2* tw = nullptr; float2* tw2 = nullptr; float2* qf = nullptr;
+    struct OpDir { int R = 0; bool two = false; bool generic = false; bool mixed = false; float2* mtw = nullptr;   // mixed: smooth length A * B on rowTM_pass_kernel, mtw = its two twiddle tables
+         bool breg = false; bool breg2 = false; bool breg4 = false; bool wave2k = false; float2* tw = nullptr; float2* tw2 = nullptr; float2* qf = nullptr;
         // chirp-z tables of an axis whose slice-loop kernel is not a chirp / convolution kernel (a power of two next to another length):
         // only the potential's inverse transform uses them (ifftTB_kernel / ifftTB2_kernel).  cz_R: 16 / 32 (M = R^2) or 64 (the 2048-point wave FFT)
         int cz_R = 0; float2* cz_tw = nullptr; float2* cz_tw2 = nullptr; float2* cz_bf = nullptr; float2* cz_bw = nullptr;
@@ -796,9 +798,31 @@ int launch_rowTW(msl_handle* h, const RowTJob& job, int kind) {
     return out_p ? launch_rowTW_io<false, true>(h, job, kind) : launch_rowTW_io<false, false>(h, job, kind);
 }
 
+// lines of a smooth length A * B (A, B <= 32): direct mixed-radix transform (rowtm_pass.h)
+int launch_rowTM(msl_handle* h, const msl_handle::OpDir& o, RowTJob job, int kind) {
+    const int n = (&o == &h->opx) ? h->cfg.nx : h->cfg.ny;
+    int A = 0, B = 0, G = 0;
+    if (!rowTM_factors(n, &A, &B, &G)) return fail(h, MSL_ERR_STATE, "mixed-radix pass: no kernel for %d points", n);
+    const size_t lds = rowTM_lds_bytes(A, B);
+    // ~230 VGPRs: two waves per SIMD, i.e. one workgroup of 512 threads or two of 256 per CU
+    const int per_cu = std::max(1, std::min(G == 16 ? 2 : 1, (int)((size_t)h->lds_limit / lds)));
+    const long long slots = (long long)h->n_cus * per_cu;
+    const long long lb = (job.n_lines + 15) / 16;
+    int pc = choose_pchunk(lb, job.n_images, slots, job.t_group);
+    if (h->row_pchunk > 0) { pc = std::min(h->row_pchunk, job.n_images); if (job.t_group > 0) while (job.t_group % pc) --pc; }
+    job.pchunk = pc;
+    job.tw = o.mtw; job.flags &= ~(P2_IN_PAIRED | P2_OUT_PAIRED);
+    const long long items = lb * ((job.n_images + pc - 1) / pc);
+    const int grid = (int)std::min<long long>(items, slots);
+    if (!rowTM_launch(n, job, grid, (size_t)h->lds_limit, h->stream)) return fail(h, MSL_ERR_STATE, "mixed-radix pass: no kernel for %d points", n);
+    HIPCHK(h, hipGetLastError());
+    return mark_launch(h, kind);
+}
+
 // one transposing pass along direction `o`: register kernels for R^2 and 2 R^2 points, else the generic LDS kernel
 // running the same program (fft, x P, ifft, x t, fft, x P, ifft) with a transposing store
 int launch_rowT_dir(msl_handle* h, const msl_handle::OpDir& o, RowTJob job, int kind) {
+    if (o.mixed) return launch_rowTM(h, o, job, kind);
     if (o.generic) {
         const FftPlan& pl = (&o == &h->opx) ? h->plan_x : h->plan_y;
         LineArgs a;
@@ -1304,6 +1328,25 @@ int msl_create(const msl_config* cfg, msl_handle** out) {
                     return fail(h, MSL_ERR_HIP, "twiddle upload failed");
                 return MSL_OK;
             }
+            // smooth lengths A * B (A, B <= 32) with a compiled kernel: direct mixed-radix passes in the slice loop (600^2: 163 k ->
+            // 330 k slice-steps/s).  The tables of the convolution / generic branches below are made all the same: the potential's
+            // inverse transform, the probes and the exit FFT of such a grid still run on those kernels.
+            {
+                int mA = 0, mB = 0, mG = 0;
+                if (!two_ok && want && rowTM_factors(n, &mA, &mB, &mG) && !dbg_env("MSL_NO_MIXED")) {
+                    std::vector<float2> T(2 * (size_t)n);
+                    for (int k2 = 0; k2 < mB; ++k2)
+                        for (int n1 = 0; n1 < mA; ++n1) {
+                            const double a = -2.0 * M_PI * (double)((k2 * n1) % n) / (double)n;
+                            T[k2 * mA + n1] = T[n + n1 * mB + k2] = make_float2((float)cos(a), (float)sin(a));
+                        }
+                    int r;
+                    if ((r = dalloc(h, &o.mtw, (size_t)2 * n))) return r;
+                    if (hipMemcpy(o.mtw, T.data(), T.size() * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess)
+                        return fail(h, MSL_ERR_HIP, "twiddle upload failed");
+                    o.mixed = true;
+                }
+            }
             // zero-padded cyclic convolution (or, MSL_CHIRPZ=1, chirp-z) on the register FFTs of length M = R^2 >= 2n - 1.  A line
             // costs the same whatever n is, so against the generic Stockham kernel (cost ~ n log n) it wins for n <= 128 (M = 256)
             // and from n ~ 190 up (M = 1024; 64 probes x 50 slices: 160^2 1.83 M vs 1.72 M slice-steps/s, 200^2 1.23 vs 1.31 M,
@@ -1487,7 +1530,7 @@ int msl_destroy(msl_handle* h) {
                     h->d_z2s, h->d_species, h->d_ff, h->d_xy, h->plan_x.tw, h->plan_y.tw, h->plan_t.tw, h->tw4_x, h->tw4_y,
                     h->scratch, h->psiT, h->psi0T, h->transT, h->bin_stage, h->st_acc, h->st_s1, h->st_s2, h->st_tw, h->st_bins, h->st_ref, h->opx.tw2, h->opx.ptab, h->opy.tw2, h->opy.ptab,
                     ((h->opx.two || h->opx.breg || h->opx.breg2 || h->opx.breg4 || h->opx.wave2k) ? h->opx.tw : nullptr), ((h->opy.two || h->opy.breg || h->opy.breg2 || h->opy.breg4 || h->opy.wave2k) ? h->opy.tw : nullptr),
-                    h->opx.bf, h->opx.bw, h->opy.bf, h->opy.bw, h->opx.qf, h->opy.qf, h->opx.cz_tw, h->opx.cz_tw2, h->opx.cz_bf, h->opx.cz_bw,
+                    h->opx.bf, h->opx.bw, h->opy.bf, h->opy.bw, h->opx.qf, h->opy.qf, h->opx.mtw, h->opy.mtw, h->opx.cz_tw, h->opx.cz_tw2, h->opx.cz_bf, h->opx.cz_bw,
                     h->opy.cz_tw, h->opy.cz_tw2, h->opy.cz_bf, h->opy.cz_bw, h->opt.cz_tw, h->opt.cz_tw2, h->opt.cz_bf, h->opt.cz_bw, h->tsplit_tw, h->plan_x.chirp, h->plan_x.bfilt, h->plan_y.chirp, h->plan_y.bfilt, h->plan_t.chirp, h->plan_t.bfilt};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->stream) (void)hipStreamDestroy(h->stream);

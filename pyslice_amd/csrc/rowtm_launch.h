@@ -1,0 +1,28 @@
+// Instantiation lists of the mixed-radix transposing pass (rowtm_pass.h), split over two translation units (slice_mixed_a.hip:
+// lengths below 500, slice_mixed_b.hip: from 500) so that the library builds in parallel.  Every entry is (A, B, G): line length
+// A * B in groups of G lanes.  Balanced factors keep most lanes busy in both layouts; A >= B: the prefetched line and the t_k line
+// are B registers each; G = 16 where both factors allow it.
+#pragma once
+#include "rowtm_pass.h"
+
+#define MSL_ROWTM_LIST_A(X) \
+    X(12, 12, 16) X(15, 10, 16) X(16, 10, 16) X(15, 12, 16) X(16, 12, 16) X(20, 10, 32) X(18, 12, 32) X(15, 15, 16) X(16, 15, 16) \
+    X(25, 10, 32) X(18, 15, 32) X(18, 16, 32) X(20, 15, 32) X(20, 16, 32) X(18, 18, 32) X(20, 18, 32) X(25, 15, 32) X(24, 16, 32) \
+    X(20, 20, 32) X(27, 15, 32) X(24, 18, 32) X(25, 18, 32) X(24, 20, 32) X(27, 18, 32)
+#define MSL_ROWTM_LIST_B(X) \
+    X(25, 20, 32) X(27, 20, 32) X(24, 24, 32) X(25, 24, 32) X(25, 25, 32) X(32, 20, 32) X(27, 24, 32) X(27, 25, 32) X(30, 24, 32) \
+    X(27, 27, 32) X(30, 25, 32) X(32, 24, 32) X(32, 25, 32) X(30, 27, 32) X(32, 27, 32) X(30, 30, 32) X(32, 30, 32)
+
+namespace msl {
+
+template <int A, int B, int G>
+static bool rowTM_launch_one(const RowTJob& job, int grid, size_t lds_limit, hipStream_t stream) {
+    (void)hipFuncSetAttribute((const void*)rowTM_pass_kernel<A, B, G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit);
+    hipLaunchKernelGGL((rowTM_pass_kernel<A, B, G>), dim3(grid), dim3(16 * G), rowTM_lds_bytes(A, B), stream, job);
+    return true;
+}
+
+bool rowTM_launch_a(int n, const RowTJob& job, int grid, size_t lds_limit, hipStream_t stream);
+bool rowTM_launch_b(int n, const RowTJob& job, int grid, size_t lds_limit, hipStream_t stream);
+
+}  // namespace msl

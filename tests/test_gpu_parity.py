@@ -810,6 +810,25 @@ def test_lengths_513_to_1024_on_the_2048_point_wave_fft(ps, orc, nx, ny, nz, P):
     assert ref_residual(got, want) < RESID_TOL
 
 
+@pytest.mark.parametrize("nx,ny,nz,P", [(600, 600, 4, 3), (360, 480, 3, 2), (144, 225, 3, 2), (960, 320, 2, 1), (900, 729, 3, 1),
+                                        (500, 1024, 3, 2), (250, 810, 2, 2), (648, 405, 3, 1), (768, 150, 2, 2), (625, 997, 2, 1)])
+def test_smooth_lengths_on_the_mixed_radix_pass(ps, orc, nx, ny, nz, P):
+    """Lines of a smooth length A * B (A, B <= 32) run on rowTM_pass_kernel, the direct mixed-radix four-step transform
+    (rowtm_pass.h): balanced and lopsided factorisations, radix 3 / 5 / 4 / 2 register transforms, groups of 16 and of 32 lanes, the
+    kernels that spill a few registers (900, 729, 960), line counts that are not multiples of 16, odd and even depths, and mixes
+    with a power-of-two axis (1024), a convolution axis (997) and the small-group kernels (150, 144)."""
+    from pyslice_amd.synthetic import synthetic_trajectory
+    tr = synthetic_trajectory(nx, nz, 1, ny=ny, density=0.02, seed=nx + 3 * ny)
+    lx, ly = tr.box_matrix[0, 0], tr.box_matrix[1, 1]
+    pp = [tuple(v) for v in np.random.default_rng(12).random((P, 2)) * [lx, ly]]
+    calc = ps.MultisliceCalculator(progress=False, dtype="complex64")
+    calc.setup(tr, aperture=30.0, voltage_eV=100e3, probe_positions=pp)
+    got = npy(calc.run().wavefunction_data)
+    want = orc.run_frames(tr.box_matrix, tr.positions, tr.atom_types, 30.0, 100e3, pp)["wavefunction_data"]
+    assert rel_l2(got, want) < WAVE_TOL
+    assert ref_residual(got, want) < RESID_TOL
+
+
 @pytest.mark.parametrize("nz", [3, 2])
 def test_transmission_functions_2048_grid(ps, orc, nz):
     """exp(i sigma V) on the C5 grid straight against the oracle: quadrant structure factor, half-spectrum inverse transform on the
