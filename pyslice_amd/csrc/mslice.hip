@@ -798,16 +798,19 @@ int launch_rowTW(msl_handle* h, const RowTJob& job, int kind) {
     return out_p ? launch_rowTW_io<false, true>(h, job, kind) : launch_rowTW_io<false, false>(h, job, kind);
 }
 
-// lines of a smooth length A * B (A, B <= 32): direct mixed-radix transform (rowtm_pass.h)
+// lines of a smooth length A * B (A, B <= 32; G = 16 / 32 lanes per line) or 2 A * B (G = 64: one wave per line, tiles of 8 lines):
+// direct mixed-radix transform (rowtm_pass.h)
 int launch_rowTM(msl_handle* h, const msl_handle::OpDir& o, RowTJob job, int kind) {
     const int n = (&o == &h->opx) ? h->cfg.nx : h->cfg.ny;
     int A = 0, B = 0, G = 0;
     if (!rowTM_factors(n, &A, &B, &G)) return fail(h, MSL_ERR_STATE, "mixed-radix pass: no kernel for %d points", n);
-    const size_t lds = rowTM_lds_bytes(A, B);
+    const size_t lds = G == 64 ? rowTM2_lds_bytes(A, B) : rowTM_lds_bytes(A, B);
+    if (lds > (size_t)h->lds_limit) return fail(h, MSL_ERR_STATE, "mixed-radix pass: %zu bytes of LDS for %d points", lds, n);
     // ~230 VGPRs: two waves per SIMD, i.e. one workgroup of 512 threads or two of 256 per CU
     const int per_cu = std::max(1, std::min(G == 16 ? 2 : 1, (int)((size_t)h->lds_limit / lds)));
     const long long slots = (long long)h->n_cus * per_cu;
-    const long long lb = (job.n_lines + 15) / 16;
+    const int lines = G == 64 ? 8 : 16;
+    const long long lb = (job.n_lines + lines - 1) / lines;
     int pc = choose_pchunk(lb, job.n_images, slots, job.t_group);
     if (h->row_pchunk > 0) { pc = std::min(h->row_pchunk, job.n_images); if (job.t_group > 0) while (job.t_group % pc) --pc; }
     job.pchunk = pc;
@@ -1328,20 +1331,31 @@ int msl_create(const msl_config* cfg, msl_handle** out) {
                     return fail(h, MSL_ERR_HIP, "twiddle upload failed");
                 return MSL_OK;
             }
-            // smooth lengths A * B (A, B <= 32) with a compiled kernel: direct mixed-radix passes in the slice loop (600^2: 163 k ->
-            // 330 k slice-steps/s).  The tables of the convolution / generic branches below are made all the same: the potential's
+            // smooth lengths A * B (A, B <= 32) or 2 A * B (up to 1728) with a compiled kernel: direct mixed-radix passes in the slice
+            // loop (600^2: 163 k -> 330 k slice-steps/s, 1500^2: 18 k -> 55 k).  The tables of the convolution / generic branches below are made all the same: the potential's
             // inverse transform, the probes and the exit FFT of such a grid still run on those kernels.
             {
                 int mA = 0, mB = 0, mG = 0;
-                if (!two_ok && want && rowTM_factors(n, &mA, &mB, &mG) && !dbg_env("MSL_NO_MIXED")) {
-                    std::vector<float2> T(2 * (size_t)n);
+                if (!two_ok && want && rowTM_factors(n, &mA, &mB, &mG) && !dbg_env("MSL_NO_MIXED") &&
+                    (mG == 64 ? rowTM2_lds_bytes(mA, mB) : rowTM_lds_bytes(mA, mB)) <= (size_t)h->lds_limit) {
+                    const int lanes1 = mG == 64 ? 2 * mA : mA;           // lanes of layout 1 (rowtm_pass.h)
+                    std::vector<float2> T(2 * (size_t)n + (mG == 64 ? 2 * mA : 0));
                     for (int k2 = 0; k2 < mB; ++k2)
-                        for (int n1 = 0; n1 < mA; ++n1) {
+                        for (int n1 = 0; n1 < lanes1; ++n1) {
                             const double a = -2.0 * M_PI * (double)((k2 * n1) % n) / (double)n;
-                            T[k2 * mA + n1] = T[n + n1 * mB + k2] = make_float2((float)cos(a), (float)sin(a));
+                            const float2 w = make_float2((float)cos(a), (float)sin(a));
+                            T[k2 * lanes1 + n1] = w;
+                            if (mG == 64) T[n + (n1 % mA) * 2 * mB + 2 * k2 + n1 / mA] = w;      // lane order of layout 2: [m 2B + 2 k2 + h], n1 = m + A h
+                            else T[n + n1 * mB + k2] = w;
+                        }
+                    if (mG == 64)
+                        for (int m = 0; m < mA; ++m) {
+                            const double a = -2.0 * M_PI * (double)m / (double)(2 * mA);
+                            T[2 * n + m] = make_float2(1.f, 0.f);
+                            T[2 * n + mA + m] = make_float2((float)cos(a), (float)sin(a));
                         }
                     int r;
-                    if ((r = dalloc(h, &o.mtw, (size_t)2 * n))) return r;
+                    if ((r = dalloc(h, &o.mtw, T.size()))) return r;
                     if (hipMemcpy(o.mtw, T.data(), T.size() * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess)
                         return fail(h, MSL_ERR_HIP, "twiddle upload failed");
                     o.mixed = true;

@@ -1,5 +1,6 @@
-// Instantiation lists of the mixed-radix transposing pass (rowtm_pass.h), split over two translation units (slice_mixed_a.hip:
-// lengths below 500, slice_mixed_b.hip: from 500) so that the library builds in parallel.  Every entry is (A, B, G): line length
+// Instantiation lists of the mixed-radix transposing passes (rowtm_pass.h), split over three translation units (slice_mixed_a.hip:
+// lengths A * B below 500, slice_mixed_b.hip: from 500, slice_mixed_c.hip: lengths 2 A * B on one wave per line, G = 64) so that
+// the library builds in parallel.  Every entry is (A, B, G): line length
 // A * B in groups of G lanes.  Balanced factors keep most lanes busy in both layouts; A >= B: the prefetched line and the t_k line
 // are B registers each; G = 16 where both factors allow it.
 #pragma once
@@ -12,6 +13,9 @@
 #define MSL_ROWTM_LIST_B(X) \
     X(25, 20, 32) X(27, 20, 32) X(24, 24, 32) X(25, 24, 32) X(25, 25, 32) X(32, 20, 32) X(27, 24, 32) X(27, 25, 32) X(30, 24, 32) \
     X(27, 27, 32) X(30, 25, 32) X(32, 24, 32) X(32, 25, 32) X(30, 27, 32) X(32, 27, 32) X(30, 30, 32) X(32, 30, 32)
+#define MSL_ROWTM_LIST_C(X) \
+    X(27, 18, 64) X(25, 20, 64) X(27, 20, 64) X(24, 24, 64) X(25, 24, 64) X(25, 25, 64) X(32, 20, 64) X(27, 24, 64) X(27, 25, 64) \
+    X(30, 24, 64) X(27, 27, 64) X(30, 25, 64) X(32, 24, 64) X(32, 25, 64) X(30, 27, 64) X(32, 27, 64)
 
 namespace msl {
 
@@ -24,5 +28,6 @@ static bool rowTM_launch_one(const RowTJob& job, int grid, size_t lds_limit, hip
 
 bool rowTM_launch_a(int n, const RowTJob& job, int grid, size_t lds_limit, hipStream_t stream);
 bool rowTM_launch_b(int n, const RowTJob& job, int grid, size_t lds_limit, hipStream_t stream);
+bool rowTM_launch_c(int n, const RowTJob& job, int grid, size_t lds_limit, hipStream_t stream);
 
 }  // namespace msl

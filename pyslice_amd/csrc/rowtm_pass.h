@@ -172,6 +172,183 @@ __global__ void __launch_bounds__(16 * G, 2) rowTM_pass_kernel(RowTJob job) {
     }
 }
 
+// ---- N = 2 A B on one wave per line (lengths up to 1728) --------------------------------------------------------------------------
+// The same transform with 2 A in the place of A, and the 2 A-point register transform of layout 2 split over a PAIR of lanes (the
+// scheme of fft2048_wave in fft_pow2.h): a radix-2 step across the pair through DPP and an A-point transform in each lane.
+//     layout 1:  lane n1 < 2 A holds x[r 2A + n1] in register r < B
+//     layout 2:  lane L = 2 k2 + h (k2 < B, h < 2) holds X[(2 q + h) B + k2] in register q < A
+// forward:  B-point FFT over r -> k2 | x W_N^{n1 k2} | exchange: lane (k2, h) gets n1 = m + A h in register m | pair step
+//           (h = 0: a = x[m] + x[m + A]; h = 1: d = (x[m] - x[m + A]) W_2A^m, the partner's value by DPP) | A-point FFT over m -> q
+// inverse:  A-point inverse over q -> m | pair step (the odd lane's conj W_2A^m first) | x conj W_N^{n1 k2} | exchange back | B-point inverse
+// Tables in LDS: tw1[k2 2A + n1] = W_N^{n1 k2}; tw2[m 2B + L] = W_N^{(m + A h) k2} and the Fresnel factor pl[q 2B + L] in lane
+// order (permuted from the natural table while it is copied in); wp[h A + m] = h ? W_2A^m : 1.
+// Exchange 1 writes row k2 of pitch P1 (columns n1 < A at [0, A), the others from AH): P1 = 2 mod 4 and AH odd make the pair
+// lanes' 8-byte reads conflict-free; exchange 2 writes row n1 of odd pitch B | 1.  Tiles of 8 lines (64-byte transposed segments).
+constexpr int rowTM2_ah(int A) { return A | 1; }
+constexpr int rowTM2_p1(int A) { int p = rowTM2_ah(A) + A; while (p % 4 != 2) ++p; return p; }
+constexpr int rowTM2_cs(int A, int B) {
+    int m = 2 * A * B;
+    if (B * rowTM2_p1(A) > m) m = B * rowTM2_p1(A);
+    if (2 * A * (B | 1) > m) m = 2 * A * (B | 1);
+    return (m + 15) / 16 * 16 + 4;                  // 4 mod 16: the store phase's half-wave reads 4 rows (2 q) x 8 consecutive positions
+}
+constexpr size_t rowTM2_lds_bytes(int A, int B) { return ((size_t)6 * A * B + 2 * A + (size_t)8 * rowTM2_cs(A, B)) * 8; }
+
+__device__ __forceinline__ float tm_dpp_swap_pair(float x) {          // value of the neighbouring lane (L ^ 1)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true));
+}
+
+template <int A, int B>
+__global__ void __launch_bounds__(512, 2) rowTM2_pass_kernel(RowTJob job) {
+    constexpr int A2 = 2 * A, B2 = 2 * B, N = A2 * B, RM = A > B ? A : B, LINES = 8, NT = 512;
+    constexpr int AH = rowTM2_ah(A), P1 = rowTM2_p1(A), P2 = B | 1;
+    constexpr int CS = rowTM2_cs(A, B);
+    constexpr int TPS = LINES / 2, POS_PER_IT = NT / TPS, NIT = (N + POS_PER_IT - 1) / POS_PER_IT;
+    static_assert(A2 <= 64 && B2 <= 64, "one wave per line");
+    static_assert(P1 % 4 == 2 && P1 >= AH + A && (AH & 1), "conflict-free pair reads");
+    static_assert(fft_smooth(A) && fft_smooth(B), "radices 2, 3, 4, 5");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float2* tw1 = reinterpret_cast<float2*>(smem_raw);        // N
+    float2* tw2 = tw1 + N;                                    // N, lane order
+    float2* pl = tw2 + N;                                     // N, lane order
+    float2* wp = pl + N;                                      // 2 A
+    float2* tile = wp + A2;                                   // LINES * CS
+    const int tid = threadIdx.x;
+    for (int i = tid; i < N; i += NT) {
+        tw1[i] = job.tw[i]; tw2[i] = job.tw[N + i];
+        const int qq = i / B2, LL = i - qq * B2;              // lane-order position q 2B + L  <-  natural k = (2 q + h) B + k2
+        pl[i] = job.pl[(2 * qq + (LL & 1)) * B + (LL >> 1)];
+    }
+    for (int i = tid; i < A2; i += NT) wp[i] = job.tw[2 * N + i];
+    __syncthreads();
+    const int wv = tid >> 6, L = tid & 63;
+    const int n1c = L < A2 ? L : A2 - 1;                      // layout 1 lane (idle lanes mirror the last one)
+    const int Lc = L < B2 ? L : B2 - 2 + (L & 1);             // layout 2 lane: pairs stay pairs
+    const int k2c = Lc >> 1, hh = Lc & 1;
+    const float sgn = hh ? -1.f : 1.f;
+    const int q = tid % TPS, r0 = tid / TPS;
+    float2* myrow = tile + wv * CS;
+    float2* x1w = myrow + (n1c < A ? n1c : AH + n1c - A);     // exchange 1: write [k2 P1], read [m]
+    const float2* x1r = myrow + k2c * P1 + hh * AH;
+    float2* x2w = myrow + hh * A * P2 + k2c;                  // exchange 2: write [m P2], read [k2]
+    const float2* x2r = myrow + n1c * P2;
+    const int lblocks = (job.n_lines + LINES - 1) / LINES;
+    const int PC = job.pchunk;
+    const int pchunks = (job.n_images + PC - 1) / PC;
+    const int n_items = lblocks * pchunks;
+    const int step_lb = (int)gridDim.x / pchunks, step_pc = (int)gridDim.x % pchunks;
+    auto line_ptr = [&](int lbb, int pcc, int kk) {
+        const int Ln = min(lbb * LINES + wv, job.n_lines - 1);
+        return job.in + (long long)(pcc * PC + kk) * job.in_image_stride + (long long)Ln * job.in_pitch + n1c;
+    };
+    int item = blockIdx.x;
+    int lb = item / pchunks, pc = item - lb * pchunks, k = 0;
+    float2 vn[B];
+    if (item < n_items) {
+        const float2* r = line_ptr(lb, pc, 0);
+#pragma unroll
+        for (int j = 0; j < B; ++j) vn[j] = ld_stream(r + j * A2);
+    }
+    float2 tv[B];
+    while (item < n_items) {
+        float2 v[RM];
+#pragma unroll
+        for (int j = 0; j < B; ++j) v[j] = vn[j];
+        const int p = pc * PC + k;
+        const int cur_lb = lb;
+        if (k == 0) {
+            const float2* trow = job.trans + frame_off(job, pc * PC) + (long long)min(lb * LINES + wv, job.n_lines - 1) * N + n1c;
+#pragma unroll
+            for (int j = 0; j < B; ++j) tv[j] = ld_stream(trow + j * A2);
+        }
+        int nitem = item, nlb = lb, npc = pc, nk = k + 1;
+        if (nk >= min(PC, job.n_images - pc * PC)) {
+            nk = 0; nitem = item + (int)gridDim.x; nlb = lb + step_lb; npc = pc + step_pc;
+            if (npc >= pchunks) { npc -= pchunks; ++nlb; }
+        }
+        const bool more = nitem < n_items;
+        const float2* nptr = line_ptr(more ? nlb : lb, more ? npc : pc, more ? nk : k);
+        auto pfx = [&](auto i_c) {
+            constexpr int I = decltype(i_c)::value;
+            constexpr int LO = B * I / 4, HI = B * (I + 1) / 4;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = LO; j < HI; ++j) vn[j] = ld_stream(nptr + j * A2);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        // radix-2 step across the lane pair: v[m] <- partner + sgn * own, the odd lane's twiddle behind it (forward) or in front (inverse)
+        auto pair_step = [&](auto inv_c) {
+            constexpr bool INV = decltype(inv_c)::value;
+            constexpr int TCH = 8;
+#pragma unroll
+            for (int c = 0; c < A; c += TCH) {
+                float2 w[TCH];
+#pragma unroll
+                for (int j = 0; j < TCH; ++j) if (c + j < A) w[j] = wp[hh * A + c + j];
+#pragma unroll
+                for (int j = 0; j < TCH; ++j) if (c + j < A) {
+                    float2 o = v[c + j];
+                    if constexpr (INV) o = cmulf_conj(o, w[j]);
+                    float2 t = make_float2(fmaf(sgn, o.x, tm_dpp_swap_pair(o.x)), fmaf(sgn, o.y, tm_dpp_swap_pair(o.y)));
+                    if constexpr (!INV) t = cmulf(t, w[j]);
+                    v[c + j] = t;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        auto a_op = [&](auto i_c) {
+            constexpr int I = decltype(i_c)::value;
+            tm_fft<B, false>(v);
+            tm_mul<B, A2, false>(v, tw1 + n1c);
+            wave_lds_fence();
+#pragma unroll
+            for (int b = 0; b < B; ++b) x1w[b * P1] = v[b];
+            wave_lds_fence();
+#pragma unroll
+            for (int m = 0; m < A; ++m) v[m] = x1r[m];
+            wave_lds_fence();
+            pfx(MSL_IC(I));
+            pair_step(std::false_type{});
+            tm_fft<A, false>(v);
+            tm_mul<A, B2, false>(v, pl + Lc);
+            tm_fft<A, true>(v);
+            pair_step(std::true_type{});
+            tm_mul<A, B2, true>(v, tw2 + Lc);
+            wave_lds_fence();
+#pragma unroll
+            for (int m = 0; m < A; ++m) x2w[m * P2] = v[m];
+            wave_lds_fence();
+#pragma unroll
+            for (int b = 0; b < B; ++b) v[b] = x2r[b];
+            wave_lds_fence();
+            pfx(MSL_IC(I + 1));
+            tm_fft<B, true>(v);
+        };
+        if (job.flags & P2_PRE_A) a_op(MSL_IC(0)); else { pfx(MSL_IC(0)); pfx(MSL_IC(1)); }
+#pragma unroll
+        for (int j = 0; j < B; ++j) v[j] = cmulf(v[j], tv[j]);
+        if (job.flags & P2_POST_A) a_op(MSL_IC(2)); else { pfx(MSL_IC(2)); pfx(MSL_IC(3)); }
+        wave_lds_fence();
+#pragma unroll
+        for (int j = 0; j < B; ++j) myrow[j * A2 + n1c] = v[j];
+        lds_barrier();
+        float2* dst = job.out + (long long)p * job.out_image_stride + cur_lb * LINES;
+        int off0 = 2 * q + r0 * job.out_pitch;
+        asm volatile("" : "+v"(off0));
+        const int ostep = POS_PER_IT * job.out_pitch;
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int pos = r0 + POS_PER_IT * i;
+            if (pos < N) {
+                const float2 a = tile[(2 * q) * CS + pos], b = tile[(2 * q + 1) * CS + pos];
+                st_stream(dst + (off0 + i * ostep), a.x, a.y, b.x, b.y);
+            }
+        }
+        lds_barrier();
+        item = nitem; lb = nlb; pc = npc; k = nk;
+    }
+}
+
 // launch of the instantiation for a line length (slice_mixed_a.hip / _b.hip); false: no kernel for n.  rowTM_factors: its (A, B, G)
 bool rowTM_factors(int n, int* A, int* B, int* G);
 bool rowTM_launch(int n, const RowTJob& job, int grid, size_t lds_limit, hipStream_t stream);

@@ -8,6 +8,9 @@ bool rowTM_factors(int n, int* A, int* B, int* G) {
     MSL_ROWTM_LIST_A(X)
     MSL_ROWTM_LIST_B(X)
 #undef X
+#define X(a, b, g) if (n == 2 * (a) * (b)) { *A = (a); *B = (b); *G = (g); return true; }
+    MSL_ROWTM_LIST_C(X)
+#undef X
     return false;
 }
 
@@ -19,6 +22,9 @@ bool rowTM_launch_a(int n, const RowTJob& job, int grid, size_t lds_limit, hipSt
 }
 
 bool rowTM_launch(int n, const RowTJob& job, int grid, size_t lds_limit, hipStream_t stream) {
+    int A = 0, B = 0, G = 0;
+    if (!rowTM_factors(n, &A, &B, &G)) return false;
+    if (G == 64) return rowTM_launch_c(n, job, grid, lds_limit, stream);
     return n < 500 ? rowTM_launch_a(n, job, grid, lds_limit, stream) : rowTM_launch_b(n, job, grid, lds_limit, stream);
 }
 

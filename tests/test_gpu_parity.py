@@ -811,12 +811,16 @@ def test_lengths_513_to_1024_on_the_2048_point_wave_fft(ps, orc, nx, ny, nz, P):
 
 
 @pytest.mark.parametrize("nx,ny,nz,P", [(600, 600, 4, 3), (360, 480, 3, 2), (144, 225, 3, 2), (960, 320, 2, 1), (900, 729, 3, 1),
-                                        (500, 1024, 3, 2), (250, 810, 2, 2), (648, 405, 3, 1), (768, 150, 2, 2), (625, 997, 2, 1)])
+                                        (500, 1024, 3, 2), (250, 810, 2, 2), (648, 405, 3, 1), (768, 150, 2, 2), (625, 997, 2, 1),
+                                        (1000, 600, 3, 2), (1500, 972, 2, 1), (1728, 1200, 2, 1), (1250, 1024, 3, 1), (1080, 1536, 2, 2),
+                                        (1600, 1458, 2, 1), (1620, 2048, 2, 1), (1152, 1011, 3, 1)])
 def test_smooth_lengths_on_the_mixed_radix_pass(ps, orc, nx, ny, nz, P):
     """Lines of a smooth length A * B (A, B <= 32) run on rowTM_pass_kernel, the direct mixed-radix four-step transform
     (rowtm_pass.h): balanced and lopsided factorisations, radix 3 / 5 / 4 / 2 register transforms, groups of 16 and of 32 lanes, the
     kernels that spill a few registers (900, 729, 960), line counts that are not multiples of 16, odd and even depths, and mixes
-    with a power-of-two axis (1024), a convolution axis (997) and the small-group kernels (150, 144)."""
+    with a power-of-two axis (1024), a convolution axis (997) and the small-group kernels (150, 144).  Lengths 2 A * B up to 1728 run
+    on rowTM2_pass_kernel (one wave per line, radix-2 step across lane pairs): next to each other, to the A * B kernels, to 1024- and
+    2048-point axes and to a convolution axis (1011), line counts that are not multiples of 8."""
     from pyslice_amd.synthetic import synthetic_trajectory
     tr = synthetic_trajectory(nx, nz, 1, ny=ny, density=0.02, seed=nx + 3 * ny)
     lx, ly = tr.box_matrix[0, 0], tr.box_matrix[1, 1]
