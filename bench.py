@@ -406,8 +406,7 @@ def run(a):
         del mine, full
         if stream_done is not None:
             stream_done.set()
-    wf_view = torch.as_tensor(_native.DeviceArray(eng.device_ptr(_native.BUF_WAVEFUNCTION), (P, slots, eng.wx * eng.wy), "<c8", owner=eng),
-                              device=dev)
+    wf_view = torch.as_tensor(eng.result_view(_native.BUF_WAVEFUNCTION, "<c8"), device=dev).reshape(P, slots, eng.wx * eng.wy)
 
     # ---- BASELINE C3 as configured (N=1, after the timed region): every frame slot holds a REAL frame, the time FFT runs on them
     c3 = None
@@ -451,7 +450,7 @@ def run(a):
         if c3_full:
             # Parseval over the frequency axis, per probe: sum_w I[p,w,k] = T sum_t |Psi|^2 - |sum_t Psi|^2 (the mean subtraction of
             # tacaw_data.py:94 removes exactly the u = 0 bin); float64 sums over the resident arrays, one probe at a time
-            inten = torch.as_tensor(_native.DeviceArray(eng.device_ptr(_native.BUF_INTENSITY), (P, tacaw_T, npix), "<f4", owner=eng), device=dev)
+            inten = torch.as_tensor(eng.result_view(_native.BUF_INTENSITY, "<f4"), device=dev).reshape(P, tacaw_T, npix)
             worst = 0.0
             for pi in range(P):
                 w = wf_view[pi]

@@ -28,7 +28,8 @@
 extern "C" {
 #endif
 
-#define MSL_ABI_VERSION 2   /* 2: reduction / streaming entry points and enum values added in rounds 2-3 */
+#define MSL_ABI_VERSION 3   /* 2: reduction / streaming entry points and enum values added in rounds 2-3;
+                              * 3: line-aligned pixel pitch of the result buffers (msl_result_pitch), `ld` argument of the reductions */
 
 typedef struct msl_handle msl_handle;
 
@@ -77,8 +78,9 @@ typedef enum {
     MSL_BUF_EXIT = 1,          /* (P,nx,ny) c64     real-space exit waves of the last msl_propagate */
     MSL_BUF_POTENTIAL = 2,     /* (nz,nx,ny) f32    V of the last msl_build_potential (slice-major!) */
     MSL_BUF_TRANSMISSION = 3,  /* (nz,nx,ny) c64    exp(i sigma V)                           */
-    MSL_BUF_WAVEFUNCTION = 4,  /* (P,T_local,wx,wy) c64  fftshift(fft2(exit)) per frame slot (wx,wy = nx,ny or the k-window) */
-    MSL_BUF_INTENSITY = 5,     /* (P,T,wx,wy) f32   TACAW |FFT_t|^2 of the last msl_tacaw    */
+    MSL_BUF_WAVEFUNCTION = 4,  /* (P,T_local,pitch) c64  fftshift(fft2(exit)) per frame slot: wx*wy pixels (wx,wy = nx,ny or the
+                                *                    k-window) at a pitch of msl_result_pitch() pixels, the rest of a row is zero */
+    MSL_BUF_INTENSITY = 5,     /* (P,T,pitch) f32   TACAW |FFT_t|^2 of the last msl_tacaw (same pitch; after a stream: pitch = wx*wy) */
     MSL_BUF_FORMFACTOR = 6,    /* (n_species,nx,ny) f32 Kirkland f_Z(q^2) of the last potential build */
     /* streaming TACAW, while a stream is open (msl_tacaw_stream_begin .. _finish): the partial sums of this handle, for the
      * caller's collective when the frames of a run are sharded over several handles / processes (msl_device_ptr only) */
@@ -219,30 +221,33 @@ int  msl_tacaw_stream_finish_range(msl_handle* h, int32_t p0, int32_t count, voi
  * The TACAW reductions take a (B,F,K) float32 intensity array: d_src == NULL selects the handle's own intensity buffer
  * (B=P, F=T after msl_tacaw or n_bins after msl_tacaw_stream_finish, K=stored pixels); otherwise a caller-held device pointer with the given shape.  Results are
  * written to HOST memory; sums are accumulated in float64 like the reference's.
+ * ld = distance in elements between consecutive (b,f) rows of K pixels (0: K; ignored with d_src == NULL): the library's own
+ * result buffers keep every image at a pitch of msl_result_pitch() >= K pixels, so a pointer INTO them goes with that ld.
  *
  * msl_tacaw_spectrum: out[b*F+f] = sum_k w(k) I[b,f,k], w = 1 or mask[k] != 0 (mask: K host bytes or NULL).
  *   Replaces the k-space sums of TACAWData.spectrum (tacaw_data.py:109-143), spectrum_image (:145-179) and
  *   masked_spectrum (:256-300); the mean over probes / the frequency pick is a lookup in the (B,F) result. */
-int  msl_tacaw_spectrum(msl_handle* h, const void* d_src_f32, int64_t B, int64_t F, int64_t K, const uint8_t* mask, double* out);
+int  msl_tacaw_spectrum(msl_handle* h, const void* d_src_f32, int64_t B, int64_t F, int64_t K, int64_t ld, const uint8_t* mask, double* out);
 /* msl_tacaw_spectrum_weighted: out[b*F+f] = sum_k weight[k] I[b,f,k] with K float64 host weights: a non-boolean mask of
  *   TACAWData.masked_spectrum, which multiplies the intensity (tacaw_data.py:286-296). */
-int  msl_tacaw_spectrum_weighted(msl_handle* h, const void* d_src_f32, int64_t B, int64_t F, int64_t K, const double* weight, double* out);
+int  msl_tacaw_spectrum_weighted(msl_handle* h, const void* d_src_f32, int64_t B, int64_t F, int64_t K, int64_t ld, const double* weight, double* out);
 /* msl_tacaw_diffraction: out[k] = scale * sum_{b0<=b<b1} sum_{f0<=f<f1} I[b,f,k]   (K float64).
  *   Replaces TACAWData.diffraction (tacaw_data.py:183-217: all f, one probe or scale=1/P over all probes) and
  *   spectral_diffraction (:219-254: one f). */
-int  msl_tacaw_diffraction(msl_handle* h, const void* d_src_f32, int64_t B, int64_t F, int64_t K, int64_t b0, int64_t b1,
+int  msl_tacaw_diffraction(msl_handle* h, const void* d_src_f32, int64_t B, int64_t F, int64_t K, int64_t ld, int64_t b0, int64_t b1,
                            int64_t f0, int64_t f1, double scale, double* out);
 /* msl_tacaw_dispersion: out[(b*F+f)*n + i] = I[b,f,idx[i]] for n flat k indices (kx*ny+ky) along a path (float32).
  *   Replaces the gather loop of TACAWData.dispersion (tacaw_data.py:302-353). */
-int  msl_tacaw_dispersion(msl_handle* h, const void* d_src_f32, int64_t B, int64_t F, int64_t K, const int64_t* idx, int64_t n,
+int  msl_tacaw_dispersion(msl_handle* h, const void* d_src_f32, int64_t B, int64_t F, int64_t K, int64_t ld, const int64_t* idx, int64_t n,
                           float* out);
 /* msl_adf: out[b] = mean_t sum_k w(k) |Psi[b,t,k]| over a (B,T,K) complex64 array (NULL: the handle's wavefunction
  *   buffer); mask = the annulus q > collection_angle*1e-3/lambda as K host bytes.
  *   Replaces the masked |.| sum and frame mean of HAADFData.calculateADF (haadf_data.py:72-94). */
-int  msl_adf(msl_handle* h, const void* d_src_c64, int64_t B, int64_t T, int64_t K, const uint8_t* mask, double* out);
+int  msl_adf(msl_handle* h, const void* d_src_c64, int64_t B, int64_t T, int64_t K, int64_t ld, const uint8_t* mask, double* out);
 
 /* Copy a device buffer to the host (dst must hold `bytes` = full buffer size, see msl_buffer_bytes).
- * For MSL_BUF_WAVEFUNCTION `first`/`count` select a probe range (count==0: all). */
+ * For MSL_BUF_WAVEFUNCTION / MSL_BUF_INTENSITY the host copy is dense -- (P,T,wx,wy), bytes = P*T*wx*wy*8 or *4, the pixel
+ * pitch of the device buffer (msl_result_pitch) is dropped on the way -- and `first`/`count` select a probe range (count==0: all). */
 int  msl_download(msl_handle* h, msl_buffer what, void* dst, size_t bytes, int64_t first, int64_t count);
 /* The (P, T_local, nx, ny) result as complex128 -- the dtype the reference returns (calculators.py:161, 284-290: its arrays are
  * torch.complex128) -- for the frames [0, n_frames_used) of every probe: widened on the device chunk by chunk and copied out as
@@ -250,6 +255,13 @@ int  msl_download(msl_handle* h, msl_buffer what, void* dst, size_t bytes, int64
  * dst_c128: host, n_probes * n_frames_used * wx * wy complex128. */
 int  msl_download_wavefunction_c128(msl_handle* h, int32_t n_frames_used, void* dst_c128, size_t bytes);
 size_t msl_buffer_bytes(const msl_handle* h, msl_buffer what);
+/* Pixel pitch of the images of MSL_BUF_WAVEFUNCTION / MSL_BUF_INTENSITY: wx*wy rounded up to a multiple of 32 pixels, so that
+ * every (probe, frame) image starts on a 256-byte (c64) / 128-byte (f32) boundary and the time kernels of msl_tacaw read and
+ * write whole lines on grids with odd pixel counts too (the reference's own test grid is 501 x 491, 00_probe.py:7-8; its
+ * time FFT runs over exactly such arrays, tacaw_data.py:94-96).  The pad pixels hold zeros.  msl_download*, msl_*_frame and the
+ * reductions with d_src == NULL hide the pitch; a caller that takes msl_device_ptr() builds its view with it.
+ * The intensity buffer written by msl_tacaw_stream_finish is dense (pitch = wx*wy).  Other buffers: 0. */
+int64_t msl_result_pitch(const msl_handle* h, msl_buffer what);
 /* Raw device pointer of a library buffer, for zero-copy use by the caller's collective (RCCL). */
 void* msl_device_ptr(msl_handle* h, msl_buffer what);
 

@@ -13,6 +13,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MSL_LIB") or os.path.join(_HERE, "libmslice.so")
 
+ABI_VERSION = 3          # include/mslice.h: MSL_ABI_VERSION
 MSL_OK, MSL_ERR_INVALID, MSL_ERR_HIP, MSL_ERR_UNSUPPORTED, MSL_ERR_STATE, MSL_ERR_NOMEM = 0, -1, -2, -3, -4, -5
 (BUF_PROBES, BUF_EXIT, BUF_POTENTIAL, BUF_TRANSMISSION, BUF_WAVEFUNCTION, BUF_INTENSITY, BUF_FORMFACTOR,
  BUF_STREAM_ACC, BUF_STREAM_S1, BUF_STREAM_S2, BUF_STREAM_REF) = range(11)
@@ -21,7 +22,7 @@ EXPORTS = [
     "msl_abi_version", "msl_last_error", "msl_create", "msl_destroy", "msl_set_kirkland", "msl_set_slices",
     "msl_set_beam", "msl_resize_probes", "msl_set_probes", "msl_upload_probes", "msl_shift_probes",
     "msl_build_potential", "msl_upload_potential", "msl_propagate", "msl_propagate_frame", "msl_tacaw",
-    "msl_download", "msl_download_wavefunction_c128", "msl_download_frame", "msl_upload_frame", "msl_buffer_bytes", "msl_device_ptr", "msl_synchronize",
+    "msl_download", "msl_download_wavefunction_c128", "msl_download_frame", "msl_upload_frame", "msl_buffer_bytes", "msl_result_pitch", "msl_device_ptr", "msl_synchronize",
     "msl_get_counters",
     "msl_reset_counters", "msl_fft2_host",
     "msl_tacaw_spectrum", "msl_tacaw_spectrum_weighted", "msl_tacaw_diffraction", "msl_tacaw_dispersion", "msl_adf",
@@ -87,16 +88,17 @@ def load():
         "msl_download_wavefunction_c128": (C.c_int, [vp, i32, vp, C.c_size_t]),
         "msl_upload_frame": (C.c_int, [vp, i32, vp, C.c_size_t]),
         "msl_buffer_bytes": (C.c_size_t, [vp, C.c_int]),
+        "msl_result_pitch": (i64, [vp, C.c_int]),
         "msl_device_ptr": (vp, [vp, C.c_int]),
         "msl_synchronize": (C.c_int, [vp]),
         "msl_get_counters": (C.c_int, [vp, C.POINTER(MslCounters)]),
         "msl_reset_counters": (C.c_int, [vp]),
         "msl_fft2_host": (C.c_int, [vp, vp, vp, i32, i32]),
-        "msl_tacaw_spectrum": (C.c_int, [vp, vp, i64, i64, i64, vp, vp]),
-        "msl_tacaw_spectrum_weighted": (C.c_int, [vp, vp, i64, i64, i64, vp, vp]),
-        "msl_tacaw_diffraction": (C.c_int, [vp, vp, i64, i64, i64, i64, i64, i64, i64, dbl, vp]),
-        "msl_tacaw_dispersion": (C.c_int, [vp, vp, i64, i64, i64, vp, i64, vp]),
-        "msl_adf": (C.c_int, [vp, vp, i64, i64, i64, vp, vp]),
+        "msl_tacaw_spectrum": (C.c_int, [vp, vp, i64, i64, i64, i64, vp, vp]),
+        "msl_tacaw_spectrum_weighted": (C.c_int, [vp, vp, i64, i64, i64, i64, vp, vp]),
+        "msl_tacaw_diffraction": (C.c_int, [vp, vp, i64, i64, i64, i64, i64, i64, i64, i64, dbl, vp]),
+        "msl_tacaw_dispersion": (C.c_int, [vp, vp, i64, i64, i64, i64, vp, i64, vp]),
+        "msl_adf": (C.c_int, [vp, vp, i64, i64, i64, i64, vp, vp]),
         "msl_select_batch_slot": (C.c_int, [vp, i32]),
         "msl_propagate_frames": (C.c_int, [vp, i32, i32]),
         "msl_frame_batch": (C.c_int, [vp]),
@@ -110,6 +112,9 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
+    if lib.msl_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"{LIB_PATH} has ABI version {lib.msl_abi_version()}, this binding needs {ABI_VERSION}: rebuild it "
+                           "(python -m pyslice_amd.build_native --force)")
     _lib = lib
     return lib
 
@@ -298,16 +303,32 @@ class Engine:
         self.intensity_F = self._stream_F
         return tot
 
-    # -- reductions over resident results; src = (device pointer, B, F, K) or None for the handle's own buffer
+    # -- reductions over resident results; src = (device pointer, B, F, K[, ld]) or None for the handle's own buffer; ld = pitch
+    #    in elements between rows of K pixels (default K; a pointer into a library buffer goes with result_pitch())
     @staticmethod
     def _src(src):
         if src is None:
-            return None, 0, 0, 0
-        ptr, B, F, K = src
-        return C.c_void_p(int(ptr)), int(B), int(F), int(K)
+            return None, 0, 0, 0, 0
+        ptr, B, F, K = src[:4]
+        ld = src[4] if len(src) > 4 else K
+        return C.c_void_p(int(ptr)), int(B), int(F), int(K), int(ld)
 
     def _bfk(self, src):
-        return (self.n_probes, self.intensity_F, self.wx * self.wy) if src is None else tuple(int(v) for v in src[1:])
+        return (self.n_probes, self.intensity_F, self.wx * self.wy) if src is None else tuple(int(v) for v in src[1:4])
+
+    def result_pitch(self, what=BUF_WAVEFUNCTION):
+        """pixel pitch of the images of the wavefunction / intensity buffer (>= wx*wy, include/mslice.h: msl_result_pitch)"""
+        return int(self._lib.msl_result_pitch(self._h, int(what)))
+
+    def result_view(self, what, typestr, rows=None):
+        """DeviceArray of a result buffer as (P, rows, wx, wy) with the library's image pitch in its strides
+        (rows: n_frames for the wavefunction, intensity_F for the intensity)"""
+        pitch = self.result_pitch(what)
+        if rows is None:
+            rows = self.n_frames if what == BUF_WAVEFUNCTION else self.intensity_F
+        es = int(typestr[2:])
+        strides = (rows * pitch * es, pitch * es, self.wy * es, es)
+        return DeviceArray(self.device_ptr(what), (self.n_probes, rows, self.wx, self.wy), typestr, owner=self, strides=strides)
 
     def tacaw_spectrum(self, mask=None, src=None):
         """(B,F) float64: sum over k of the (masked) intensity."""
@@ -318,8 +339,8 @@ class Engine:
             if m.size != K:
                 raise ValueError(f"mask has {m.size} entries, k-space has {K}")
         out = np.empty((B, F), dtype=np.float64)
-        p, b, f, k = self._src(src)
-        self._chk(self._lib.msl_tacaw_spectrum(self._h, p, b, f, k, _ptr(m) if m is not None else None, _ptr(out)))
+        p, b, f, k, ld = self._src(src)
+        self._chk(self._lib.msl_tacaw_spectrum(self._h, p, b, f, k, ld, _ptr(m) if m is not None else None, _ptr(out)))
         return out
 
     def tacaw_spectrum_weighted(self, weight, src=None):
@@ -329,8 +350,8 @@ class Engine:
         if w.size != K:
             raise ValueError(f"mask has {w.size} entries, k-space has {K}")
         out = np.empty((B, F), dtype=np.float64)
-        p, b, f, k = self._src(src)
-        self._chk(self._lib.msl_tacaw_spectrum_weighted(self._h, p, b, f, k, _ptr(w), _ptr(out)))
+        p, b, f, k, ld = self._src(src)
+        self._chk(self._lib.msl_tacaw_spectrum_weighted(self._h, p, b, f, k, ld, _ptr(w), _ptr(out)))
         return out
 
     def tacaw_diffraction(self, probes=None, freqs=None, scale=1.0, src=None):
@@ -339,8 +360,8 @@ class Engine:
         b0, b1 = (0, B) if probes is None else probes
         f0, f1 = (0, F) if freqs is None else freqs
         out = np.empty(K, dtype=np.float64)
-        p, b, f, k = self._src(src)
-        self._chk(self._lib.msl_tacaw_diffraction(self._h, p, b, f, k, int(b0), int(b1), int(f0), int(f1), float(scale), _ptr(out)))
+        p, b, f, k, ld = self._src(src)
+        self._chk(self._lib.msl_tacaw_diffraction(self._h, p, b, f, k, ld, int(b0), int(b1), int(f0), int(f1), float(scale), _ptr(out)))
         return out
 
     def tacaw_dispersion(self, flat_indices, src=None):
@@ -348,8 +369,8 @@ class Engine:
         B, F, K = self._bfk(src)
         idx = np.ascontiguousarray(flat_indices, dtype=np.int64).reshape(-1)
         out = np.empty((B, F, idx.size), dtype=np.float32)
-        p, b, f, k = self._src(src)
-        self._chk(self._lib.msl_tacaw_dispersion(self._h, p, b, f, k, _ptr(idx), idx.size, _ptr(out)))
+        p, b, f, k, ld = self._src(src)
+        self._chk(self._lib.msl_tacaw_dispersion(self._h, p, b, f, k, ld, _ptr(idx), idx.size, _ptr(out)))
         return out
 
     def adf(self, mask, src=None):
@@ -359,8 +380,8 @@ class Engine:
         if m.size != K:
             raise ValueError(f"mask has {m.size} entries, k-space has {K}")
         out = np.empty(B, dtype=np.float64)
-        p, b, t, k = self._src(src)
-        self._chk(self._lib.msl_adf(self._h, p, b, t, k, _ptr(m), _ptr(out)))
+        p, b, t, k, ld = self._src(src)
+        self._chk(self._lib.msl_adf(self._h, p, b, t, k, ld, _ptr(m), _ptr(out)))
         return out
 
     # -- results
@@ -441,7 +462,14 @@ class Engine:
 class DeviceArray:
     """Zero-copy view of a library device buffer for torch (``torch.as_tensor(DeviceArray(...), device='cuda')``)."""
 
-    def __init__(self, ptr, shape, typestr, owner=None):
+    def __init__(self, ptr, shape, typestr, owner=None, strides=None):
         self._owner = owner
+        dense, acc = [], int(typestr[2:])
+        for n in reversed(shape):
+            dense.append(acc)
+            acc *= int(n)
+        if strides is not None and tuple(int(v) for v in strides) == tuple(reversed(dense)):
+            strides = None                              # C-contiguous: the interface wants None
         self.__cuda_array_interface__ = {"shape": tuple(int(s) for s in shape), "typestr": typestr,
-                                         "data": (int(ptr), False), "version": 2, "strides": None}
+                                         "data": (int(ptr), False), "version": 2,
+                                         "strides": None if strides is None else tuple(int(v) for v in strides)}

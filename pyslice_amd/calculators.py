@@ -410,9 +410,7 @@ class MultisliceCalculator:
         tac.total_diffraction = total
         tac._intensity_src = (eng, None)
         if self._output == "device":
-            ptr = eng.device_ptr(_native.BUF_INTENSITY)
-            tac.intensity = torch.as_tensor(_native.DeviceArray(ptr, (eng.n_probes, eng.intensity_F, eng.wx, eng.wy), "<f4", owner=eng),
-                                            device=f"cuda:{eng.device}")
+            tac.intensity = torch.as_tensor(eng.result_view(_native.BUF_INTENSITY, "<f4"), device=f"cuda:{eng.device}")
         else:
             tac.intensity = _as_tensor(eng.intensity().astype(np.float64))
         return tac
@@ -478,9 +476,8 @@ class MultisliceCalculator:
         T_local = len(self._frames)
         if self._world == 1 or self._gather == "none":
             if self._output == "device":
-                ptr = eng.device_ptr(_native.BUF_WAVEFUNCTION)
-                view = torch.as_tensor(_native.DeviceArray(ptr, (P, eng.n_frames, nx, ny), "<c8", owner=eng),
-                                       device=f"cuda:{eng.device}")
+                # (the images sit at the library's line-aligned pixel pitch: a strided view when nx*ny is not a multiple of 32)
+                view = torch.as_tensor(eng.result_view(_native.BUF_WAVEFUNCTION, "<c8"), device=f"cuda:{eng.device}")
                 return view[:, :T_local].unsqueeze(-1), T_local == eng.n_frames
             if self._dtype == "complex128":
                 # the reference's dtype: widened on the device and copied out as complex128 (msl_download_wavefunction_c128) --
@@ -490,9 +487,7 @@ class MultisliceCalculator:
             local = eng.wavefunction()[:, :T_local]
             return _as_tensor(np.ascontiguousarray(local[..., None])), T_local == eng.n_frames
         # multi-process: one gather of the frame shards (no collective during the frames)
-        ptr = eng.device_ptr(_native.BUF_WAVEFUNCTION)
-        local = torch.as_tensor(_native.DeviceArray(ptr, (P, eng.n_frames, nx, ny), "<c8", owner=eng),
-                                device=f"cuda:{eng.device}")[:, :T_local]
+        local = torch.as_tensor(eng.result_view(_native.BUF_WAVEFUNCTION, "<c8"), device=f"cuda:{eng.device}")[:, :T_local]
         full = distributed.gather_frames(local, self.n_frames, dst=None if self._gather == "all" else 0)
         if full is None:
             return None, False

@@ -64,6 +64,9 @@ struct msl_handle {
     // probes and the transposed transmission slices
     int wx = 0, wy = 0, wx0 = 0, wy0 = 0;   // k-window of the stored exit-wave spectra (fftshifted coordinates)
     size_t wpix = 0;               // stored pixels per exit-wave spectrum: the (binned) k-window or the whole grid
+    size_t wpitch = 0;             // pixel pitch of the images of wf / intensity: wpix rounded up to 32 pixels (pad pixels are zero: to the
+                                   // time kernels they are pixels like any other), include/mslice.h: msl_result_pitch
+    size_t intensity_ld = 0;       // pixel pitch of the resident intensity buffer: wpitch after msl_tacaw, wpix after a stream
     int bx = 1, by = 1;            // detector binning: stored pixel = sum of bx x by neighbouring pixels of the window
     float2* bin_stage = nullptr;   // binning: full-resolution window of the frames of one launch sequence, (FB*P, wx, wy)
     // streaming TACAW
@@ -619,7 +622,7 @@ int bin_frames(msl_handle* h, int slot, int groups) {
     const msl_config& c = h->cfg;
     const long long total = (long long)h->wpix * c.n_probes * groups;
     hipLaunchKernelGGL(bin_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, h->bin_stage, h->wf, c.n_probes, groups,
-                       c.n_frames, slot, h->wx, h->wy, h->bx, h->by);
+                       c.n_frames, slot, h->wx, h->wy, h->bx, h->by, (long long)h->wpitch);
     HIPCHK(h, hipGetLastError());
     return mark_launch(h, K_OTHER);
 }
@@ -630,15 +633,15 @@ int epilogue_x_pass(msl_handle* h, int slot, int groups = 1) {
     const bool binned = h->bin_stage != nullptr;
     // binning: the full-resolution window of every image goes to the staging buffer (image-major), bin_kernel sums it
     // into the frame slots -- 16 B/pixel/(probe, frame) extra against 16 B/pixel/slice-step of the loop
-    float2* dst = binned ? h->bin_stage : h->wf + (size_t)slot * h->wpix;
-    const long long out_is = binned ? (long long)h->wx * h->wy : (long long)c.n_frames * h->wpix;
+    float2* dst = binned ? h->bin_stage : h->wf + (size_t)slot * h->wpitch;
+    const long long out_is = binned ? (long long)h->wx * h->wy : (long long)c.n_frames * h->wpitch;
     const int og = binned ? 1 : groups;               // staged images stay image-major; bin_kernel regroups them by frame
     const bool windowed = (h->wx != c.nx) || (h->wy != c.ny);
     const bool fast_ok = h->Rx && (!windowed || (c.ny % 32 == 0 && h->wy % 32 == 0));
     if (fast_ok) {
         ColJob k = col_job(h, h->psi, dst, P, h->pitch, h->wy);
         k.flags = COL_FWD | COL_SHIFT; k.out_image_stride = out_is;
-        if (og > 1) { k.out_group = c.n_probes; k.out_group_stride = (long long)h->wpix; }
+        if (og > 1) { k.out_group = c.n_probes; k.out_group_stride = (long long)h->wpitch; }
         if (windowed) { k.win_c0 = h->wy0; k.win_nc = h->wy; k.win_x0 = h->wx0; k.win_nx = h->wx; }
         int rc = launch_col_fast(h, k, K_OTHER);
         return (rc || !binned) ? rc : bin_frames(h, slot, groups);
@@ -646,7 +649,7 @@ int epilogue_x_pass(msl_handle* h, int slot, int groups = 1) {
     LineArgs k = col_args(h, h->psi, dst, P, h->pitch, h->wy);
     k.fft1 = +1;
     k.out_is = out_is;
-    if (og > 1) { k.group = c.n_probes; k.out_gs = (long long)h->wpix; }
+    if (og > 1) { k.group = c.n_probes; k.out_gs = (long long)h->wpitch; }
     k.shift_n = c.nx / 2; k.shift_r = c.ny / 2;
     if (windowed) { k.win_n0 = h->wx0; k.win_nn = h->wx; k.win_r0 = h->wy0; k.win_nr = h->wy; }
     int rc = launch_lines(h, h->plan_x, k, K_OTHER);
@@ -1262,6 +1265,9 @@ int msl_create(const msl_config* cfg, msl_handle** out) {
         delete h; return rc_;
     }
     h->wpix = (size_t)(h->wx / h->bx) * (h->wy / h->by);
+    // every (probe, frame) image of the results starts on a 256-byte boundary: the time kernels read 128-byte row segments of
+    // neighbouring pixels of every frame, and with an odd pixel count (501 x 491: 245 991) all but one frame in 16 straddled two lines
+    h->wpitch = dbg_env("MSL_NO_RESULT_PITCH") ? h->wpix : ((h->wpix + 31) & ~(size_t)31);
     auto bail = [&](int rc) { g_create_error = h->err; msl_destroy(h); return rc; };
     if (hipSetDevice(cfg->device) != hipSuccess) return bail(fail(h, MSL_ERR_HIP, "hipSetDevice(%d) failed", cfg->device));
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(h, MSL_ERR_HIP, "hipStreamCreate failed"));
@@ -1516,8 +1522,8 @@ int msl_create(const msl_config* cfg, msl_handle** out) {
     if (cfg->keep_potential && (rc = dalloc(h, &h->V, npix * cfg->nz))) return bail(rc);
     if (cfg->n_frames > 0) {
         if ((h->bx > 1 || h->by > 1) && (rc = dalloc(h, &h->bin_stage, (size_t)h->wx * h->wy * cfg->n_probes * h->FB))) return bail(rc);
-        if ((rc = dalloc(h, &h->wf, h->wpix * cfg->n_probes * cfg->n_frames))) return bail(rc);
-        if (hipMemsetAsync(h->wf, 0, h->wpix * cfg->n_probes * cfg->n_frames * sizeof(float2), h->stream) != hipSuccess)
+        if ((rc = dalloc(h, &h->wf, h->wpitch * cfg->n_probes * cfg->n_frames))) return bail(rc);
+        if (hipMemsetAsync(h->wf, 0, h->wpitch * cfg->n_probes * cfg->n_frames * sizeof(float2), h->stream) != hipSuccess)
             return bail(fail(h, MSL_ERR_HIP, "memset failed"));
     }
     if ((rc = dalloc(h, &h->pxt, (size_t)cfg->nx))) return bail(rc);
@@ -2112,14 +2118,15 @@ int msl_tacaw(msl_handle* h, const void* d_src, void* d_dst, int64_t batch, int3
     float* dst = (float*)d_dst;
     if (!src) {
         if (!h->wf) return fail(h, MSL_ERR_STATE, "msl_tacaw: no wavefunction buffer");
-        src = h->wf; batch = c.n_probes; T = c.n_frames; npix = (int64_t)h->wpix;
+        // the pad pixels of an image are pixels like any other here (zeros in, zeros out)
+        src = h->wf; batch = c.n_probes; T = c.n_frames; npix = (int64_t)h->wpitch;
         size_t need = (size_t)batch * T * npix;
         if (h->intensity_elems != need) {
             int rc = dalloc(h, &h->intensity, need);
             if (rc) return rc;
             h->intensity_elems = need;
         }
-        h->intensity_F = T;
+        h->intensity_F = T; h->intensity_ld = h->wpitch;
         dst = h->intensity;
     } else if (!dst) {
         return fail(h, MSL_ERR_INVALID, "msl_tacaw: src given without dst");
@@ -2284,7 +2291,7 @@ int msl_tacaw_stream_set_reference(msl_handle* h, const void* d_ref_c64, int32_t
         HIPCHK(h, hipMemcpyAsync(h->st_ref, d_ref_c64, (size_t)c.n_probes * K * sizeof(float2), hipMemcpyDeviceToDevice, h->stream));
     } else {
         // frame slot `slot` of the (P, ring, K) buffer: P strided images
-        HIPCHK(h, hipMemcpy2DAsync(h->st_ref, K * sizeof(float2), h->wf + (size_t)slot * K, (size_t)c.n_frames * K * sizeof(float2),
+        HIPCHK(h, hipMemcpy2DAsync(h->st_ref, K * sizeof(float2), h->wf + (size_t)slot * h->wpitch, (size_t)c.n_frames * h->wpitch * sizeof(float2),
                                    K * sizeof(float2), c.n_probes, hipMemcpyDeviceToDevice, h->stream));
     }
     h->st_have_ref = true;
@@ -2302,7 +2309,7 @@ int msl_tacaw_stream_push(msl_handle* h, int32_t first_slot, int32_t count, int3
     FoldJob j{};
     j.wf = h->wf; j.acc = h->st_acc; j.s1 = h->st_s1; j.s2 = h->st_s2; j.tw = h->st_tw; j.bins = h->st_bins;
     j.ref = h->st_have_ref ? h->st_ref : nullptr;
-    j.K = (long long)h->wpix; j.ring = c.n_frames; j.first_slot = first_slot; j.count = count; j.t0 = t0; j.T = h->st_T; j.F = h->st_F;
+    j.K = (long long)h->wpix; j.wfK = (long long)h->wpitch; j.ring = c.n_frames; j.first_slot = first_slot; j.count = count; j.t0 = t0; j.T = h->st_T; j.F = h->st_F;
     const dim3 grid((unsigned)((h->wpix + 255) / 256), c.n_probes);
     for (int f0 = 0; f0 < h->st_F; f0 += MSL_FOLD_FCH) {
         j.f0 = f0;
@@ -2329,7 +2336,7 @@ int msl_tacaw_stream_finish_range(msl_handle* h, int32_t p0, int32_t count, void
             if ((rc = dalloc(h, &h->intensity, need))) return rc;
             h->intensity_elems = need;
         }
-        h->intensity_F = h->st_F;
+        h->intensity_F = h->st_F; h->intensity_ld = h->wpix;
         dst = h->intensity;
     }
     if (need) {
@@ -2363,7 +2370,7 @@ size_t msl_buffer_bytes(const msl_handle* h, msl_buffer what) {
         case MSL_BUF_PROBES: case MSL_BUF_EXIT: return npix * c.n_probes * 8;
         case MSL_BUF_POTENTIAL: return h->V ? npix * c.nz * 4 : 0;
         case MSL_BUF_TRANSMISSION: return npix * c.nz * 8;
-        case MSL_BUF_WAVEFUNCTION: return h->wf ? h->wpix * c.n_probes * c.n_frames * 8 : 0;
+        case MSL_BUF_WAVEFUNCTION: return h->wf ? h->wpitch * c.n_probes * c.n_frames * 8 : 0;
         case MSL_BUF_INTENSITY: return h->intensity_elems * 4;
         case MSL_BUF_FORMFACTOR: return npix * h->n_species * 4;
         case MSL_BUF_STREAM_ACC: return (h->st_open && h->st_acc) ? h->wpix * c.n_probes * (size_t)h->st_F * 8 : 0;
@@ -2371,6 +2378,13 @@ size_t msl_buffer_bytes(const msl_handle* h, msl_buffer what) {
         case MSL_BUF_STREAM_S2: return (h->st_open && h->st_s2) ? h->wpix * c.n_probes * 8 : 0;
         case MSL_BUF_STREAM_REF: return (h->st_open && h->st_have_ref) ? h->wpix * c.n_probes * 8 : 0;
     }
+    return 0;
+}
+
+int64_t msl_result_pitch(const msl_handle* h, msl_buffer what) {
+    if (!h) return 0;
+    if (what == MSL_BUF_WAVEFUNCTION) return h->wf ? (int64_t)h->wpitch : 0;
+    if (what == MSL_BUF_INTENSITY) return h->intensity ? (int64_t)h->intensity_ld : 0;
     return 0;
 }
 
@@ -2400,20 +2414,23 @@ static int ensure_scratch(msl_handle* h, size_t bytes) {
     return rc;
 }
 
-// resolve (src, B, F, K) for the TACAW reductions: NULL = the handle's intensity buffer
-static int intensity_source(msl_handle* h, const char* who, const void** src, int64_t* B, int64_t* F, int64_t* K) {
+// resolve (src, B, F, K, ld) for the TACAW reductions: NULL = the handle's intensity buffer
+static int intensity_source(msl_handle* h, const char* who, const void** src, int64_t* B, int64_t* F, int64_t* K, int64_t* ld) {
     if (!h) return fail(h, MSL_ERR_INVALID, "null handle");
     if (!*src) {
         if (!h->intensity || h->intensity_elems == 0) return fail(h, MSL_ERR_STATE, "%s: no intensity (call msl_tacaw)", who);
-        *src = h->intensity; *B = h->cfg.n_probes; *F = h->intensity_F; *K = (int64_t)h->wpix;
+        *src = h->intensity; *B = h->cfg.n_probes; *F = h->intensity_F; *K = (int64_t)h->wpix; *ld = (int64_t)h->intensity_ld;
+    } else if (*ld == 0) {
+        *ld = *K;
     }
     if (*B < 1 || *F < 1 || *K < 1) return fail(h, MSL_ERR_INVALID, "%s: bad shape (%lld,%lld,%lld)", who, (long long)*B, (long long)*F, (long long)*K);
+    if (*ld < *K) return fail(h, MSL_ERR_INVALID, "%s: row pitch %lld below the row length %lld", who, (long long)*ld, (long long)*K);
     if (*B * *F > 0x7fffffffLL) return fail(h, MSL_ERR_UNSUPPORTED, "%s: more than 2^31 rows", who);
     return MSL_OK;
 }
 
-// sum over K of rows of a (rows, K) array with an optional host mask; float64 result per row on the host
-static int reduce_rows(msl_handle* h, const void* src, bool complex_abs, int64_t rows, int64_t K, const uint8_t* mask, double* out) {
+// sum over K of rows of a (rows, K) array (row pitch ld) with an optional host mask; float64 result per row on the host
+static int reduce_rows(msl_handle* h, const void* src, bool complex_abs, int64_t rows, int64_t K, int64_t ld, const uint8_t* mask, double* out) {
     HIPCHK(h, hipSetDevice(h->cfg.device));
     const int64_t quads = (K + 3) / 4;
     int n_chunks = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(quads / 1024, 4096 / rows), 64));
@@ -2428,8 +2445,8 @@ static int reduce_rows(msl_handle* h, const void* src, bool complex_abs, int64_t
         HIPCHK(h, hipMemcpyAsync(d_mask, mask, (size_t)K, hipMemcpyHostToDevice, h->stream));
     }
     dim3 grid(n_chunks, (unsigned)rows);
-    if (complex_abs) hipLaunchKernelGGL(reduce_k_kernel<true>, grid, dim3(256), 0, h->stream, src, d_mask, (long long)K, n_chunks, d_part);
-    else hipLaunchKernelGGL(reduce_k_kernel<false>, grid, dim3(256), 0, h->stream, src, d_mask, (long long)K, n_chunks, d_part);
+    if (complex_abs) hipLaunchKernelGGL(reduce_k_kernel<true>, grid, dim3(256), 0, h->stream, src, d_mask, (long long)K, (long long)ld, n_chunks, d_part);
+    else hipLaunchKernelGGL(reduce_k_kernel<false>, grid, dim3(256), 0, h->stream, src, d_mask, (long long)K, (long long)ld, n_chunks, d_part);
     HIPCHK(h, hipGetLastError());
     std::vector<double> part((size_t)rows * n_chunks);
     HIPCHK(h, hipMemcpyAsync(part.data(), d_part, part_bytes, hipMemcpyDeviceToHost, h->stream));
@@ -2442,22 +2459,22 @@ static int reduce_rows(msl_handle* h, const void* src, bool complex_abs, int64_t
     return MSL_OK;
 }
 
-int msl_tacaw_spectrum(msl_handle* h, const void* d_src_f32, int64_t B, int64_t F, int64_t K, const uint8_t* mask, double* out) {
+int msl_tacaw_spectrum(msl_handle* h, const void* d_src_f32, int64_t B, int64_t F, int64_t K, int64_t ld, const uint8_t* mask, double* out) {
     if (!out) return fail(h, MSL_ERR_INVALID, "msl_tacaw_spectrum: null output");
-    int rc = intensity_source(h, "msl_tacaw_spectrum", &d_src_f32, &B, &F, &K);
+    int rc = intensity_source(h, "msl_tacaw_spectrum", &d_src_f32, &B, &F, &K, &ld);
     if (rc) return rc;
     if (B * F > 65535) {                       // grid.y limit: go probe by probe
         if (F > 65535) return fail(h, MSL_ERR_UNSUPPORTED, "msl_tacaw_spectrum: more than 65535 frequencies");
         for (int64_t b = 0; b < B; ++b)
-            if ((rc = reduce_rows(h, (const float*)d_src_f32 + b * F * K, false, F, K, mask, out + b * F))) return rc;
+            if ((rc = reduce_rows(h, (const float*)d_src_f32 + b * F * ld, false, F, K, ld, mask, out + b * F))) return rc;
         return MSL_OK;
     }
-    return reduce_rows(h, d_src_f32, false, B * F, K, mask, out);
+    return reduce_rows(h, d_src_f32, false, B * F, K, ld, mask, out);
 }
 
-int msl_tacaw_spectrum_weighted(msl_handle* h, const void* d_src_f32, int64_t B, int64_t F, int64_t K, const double* weight, double* out) {
+int msl_tacaw_spectrum_weighted(msl_handle* h, const void* d_src_f32, int64_t B, int64_t F, int64_t K, int64_t ld, const double* weight, double* out) {
     if (!out || !weight) return fail(h, MSL_ERR_INVALID, "msl_tacaw_spectrum_weighted: null argument");
-    int rc = intensity_source(h, "msl_tacaw_spectrum_weighted", &d_src_f32, &B, &F, &K);
+    int rc = intensity_source(h, "msl_tacaw_spectrum_weighted", &d_src_f32, &B, &F, &K, &ld);
     if (rc) return rc;
     HIPCHK(h, hipSetDevice(h->cfg.device));
     const int64_t rows_per = std::min<int64_t>(B * F, 32768);
@@ -2470,8 +2487,8 @@ int msl_tacaw_spectrum_weighted(msl_handle* h, const void* d_src_f32, int64_t B,
     std::vector<double> part((size_t)rows_per * n_chunks);
     for (int64_t r0 = 0; r0 < B * F; r0 += rows_per) {
         const int64_t rows = std::min<int64_t>(rows_per, B * F - r0);
-        hipLaunchKernelGGL(reduce_kw_kernel, dim3(n_chunks, (unsigned)rows), dim3(256), 0, h->stream, (const float*)d_src_f32 + r0 * K, d_w,
-                           (long long)K, n_chunks, d_part);
+        hipLaunchKernelGGL(reduce_kw_kernel, dim3(n_chunks, (unsigned)rows), dim3(256), 0, h->stream, (const float*)d_src_f32 + r0 * ld, d_w,
+                           (long long)K, (long long)ld, n_chunks, d_part);
         HIPCHK(h, hipGetLastError());
         HIPCHK(h, hipMemcpyAsync(part.data(), d_part, (size_t)rows * n_chunks * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -2484,17 +2501,19 @@ int msl_tacaw_spectrum_weighted(msl_handle* h, const void* d_src_f32, int64_t B,
     return MSL_OK;
 }
 
-int msl_adf(msl_handle* h, const void* d_src_c64, int64_t B, int64_t T, int64_t K, const uint8_t* mask, double* out) {
+int msl_adf(msl_handle* h, const void* d_src_c64, int64_t B, int64_t T, int64_t K, int64_t ld, const uint8_t* mask, double* out) {
     if (!h || !out) return fail(h, MSL_ERR_INVALID, "msl_adf: null argument");
     if (!d_src_c64) {
         if (!h->wf) return fail(h, MSL_ERR_STATE, "msl_adf: no wavefunction buffer");
-        d_src_c64 = h->wf; B = h->cfg.n_probes; T = h->cfg.n_frames; K = (int64_t)h->wpix;
+        d_src_c64 = h->wf; B = h->cfg.n_probes; T = h->cfg.n_frames; K = (int64_t)h->wpix; ld = (int64_t)h->wpitch;
+    } else if (ld == 0) {
+        ld = K;
     }
-    if (B < 1 || T < 1 || K < 1) return fail(h, MSL_ERR_INVALID, "msl_adf: bad shape");
+    if (B < 1 || T < 1 || K < 1 || ld < K) return fail(h, MSL_ERR_INVALID, "msl_adf: bad shape");
     if (T > 65535) return fail(h, MSL_ERR_UNSUPPORTED, "msl_adf: more than 65535 frames");
     std::vector<double> rows((size_t)T);
     for (int64_t b = 0; b < B; ++b) {
-        int rc = reduce_rows(h, (const float2*)d_src_c64 + b * T * K, true, T, K, mask, rows.data());
+        int rc = reduce_rows(h, (const float2*)d_src_c64 + b * T * ld, true, T, K, ld, mask, rows.data());
         if (rc) return rc;
         double s = 0;
         for (double v : rows) s += v;
@@ -2503,10 +2522,10 @@ int msl_adf(msl_handle* h, const void* d_src_c64, int64_t B, int64_t T, int64_t 
     return MSL_OK;
 }
 
-int msl_tacaw_diffraction(msl_handle* h, const void* d_src_f32, int64_t B, int64_t F, int64_t K, int64_t b0, int64_t b1,
+int msl_tacaw_diffraction(msl_handle* h, const void* d_src_f32, int64_t B, int64_t F, int64_t K, int64_t ld, int64_t b0, int64_t b1,
                           int64_t f0, int64_t f1, double scale, double* out) {
     if (!out) return fail(h, MSL_ERR_INVALID, "msl_tacaw_diffraction: null output");
-    int rc = intensity_source(h, "msl_tacaw_diffraction", &d_src_f32, &B, &F, &K);
+    int rc = intensity_source(h, "msl_tacaw_diffraction", &d_src_f32, &B, &F, &K, &ld);
     if (rc) return rc;
     if (b0 < 0 || b1 > B || b0 >= b1 || f0 < 0 || f1 > F || f0 >= f1)
         return fail(h, MSL_ERR_INVALID, "msl_tacaw_diffraction: range [%lld,%lld) x [%lld,%lld) outside (%lld,%lld)", (long long)b0,
@@ -2514,22 +2533,22 @@ int msl_tacaw_diffraction(msl_handle* h, const void* d_src_f32, int64_t B, int64
     HIPCHK(h, hipSetDevice(h->cfg.device));
     if ((rc = ensure_scratch(h, (size_t)K * sizeof(double)))) return rc;
     double* d_out = (double*)h->scratch;
-    const bool vec = (K % 4 == 0);
+    const bool vec = (K % 4 == 0) && (ld % 4 == 0);
     const long long threads = vec ? K / 4 : K;
     const unsigned grid = (unsigned)((threads + 255) / 256);
     if (vec) hipLaunchKernelGGL(reduce_bf_kernel<true>, dim3(grid), dim3(256), 0, h->stream, (const float*)d_src_f32, (long long)F, (long long)K,
-                                (long long)b0, (long long)b1, (long long)f0, (long long)f1, scale, d_out);
+                                (long long)ld, (long long)b0, (long long)b1, (long long)f0, (long long)f1, scale, d_out);
     else hipLaunchKernelGGL(reduce_bf_kernel<false>, dim3(grid), dim3(256), 0, h->stream, (const float*)d_src_f32, (long long)F, (long long)K,
-                            (long long)b0, (long long)b1, (long long)f0, (long long)f1, scale, d_out);
+                            (long long)ld, (long long)b0, (long long)b1, (long long)f0, (long long)f1, scale, d_out);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpyAsync(out, d_out, (size_t)K * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return MSL_OK;
 }
 
-int msl_tacaw_dispersion(msl_handle* h, const void* d_src_f32, int64_t B, int64_t F, int64_t K, const int64_t* idx, int64_t n, float* out) {
+int msl_tacaw_dispersion(msl_handle* h, const void* d_src_f32, int64_t B, int64_t F, int64_t K, int64_t ld, const int64_t* idx, int64_t n, float* out) {
     if (!out || !idx) return fail(h, MSL_ERR_INVALID, "msl_tacaw_dispersion: null argument");
-    int rc = intensity_source(h, "msl_tacaw_dispersion", &d_src_f32, &B, &F, &K);
+    int rc = intensity_source(h, "msl_tacaw_dispersion", &d_src_f32, &B, &F, &K, &ld);
     if (rc) return rc;
     if (n < 1) return fail(h, MSL_ERR_INVALID, "msl_tacaw_dispersion: empty path");
     for (int64_t i = 0; i < n; ++i)
@@ -2542,7 +2561,7 @@ int msl_tacaw_dispersion(msl_handle* h, const void* d_src_f32, int64_t B, int64_
     HIPCHK(h, hipMemcpyAsync(d_idx, idx, idx_bytes, hipMemcpyHostToDevice, h->stream));
     const long long tot = (long long)B * F * n;
     hipLaunchKernelGGL(gather_k_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, (const float*)d_src_f32,
-                       (long long)(B * F), (long long)K, d_idx, (long long)n, d_out);
+                       (long long)(B * F), (long long)ld, d_idx, (long long)n, d_out);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -2571,12 +2590,28 @@ int msl_download(msl_handle* h, msl_buffer what, void* dst, size_t bytes, int64_
         HIPCHK(h, hipGetLastError());
     }
     size_t off = 0, len = total;
-    if (count > 0) {
-        if (what != MSL_BUF_WAVEFUNCTION && what != MSL_BUF_INTENSITY)
-            return fail(h, MSL_ERR_INVALID, "msl_download: ranges only for wavefunction/intensity");
-        size_t per = total / h->cfg.n_probes;
-        if (first < 0 || first + count > h->cfg.n_probes) return fail(h, MSL_ERR_INVALID, "msl_download: probe range out of bounds");
-        off = per * first; len = per * count;
+    if (count > 0 && what != MSL_BUF_WAVEFUNCTION && what != MSL_BUF_INTENSITY)
+        return fail(h, MSL_ERR_INVALID, "msl_download: ranges only for wavefunction/intensity");
+    if (what == MSL_BUF_WAVEFUNCTION || what == MSL_BUF_INTENSITY) {
+        // (P, rows, ld) on the device -> dense (P, rows, wx*wy) on the host
+        const size_t es = what == MSL_BUF_WAVEFUNCTION ? sizeof(float2) : sizeof(float);
+        const size_t ld = what == MSL_BUF_WAVEFUNCTION ? h->wpitch : h->intensity_ld;
+        const size_t rows_per_probe = total / es / ld / h->cfg.n_probes;
+        size_t n_probes = h->cfg.n_probes;
+        if (count > 0) {
+            if (first < 0 || first + count > h->cfg.n_probes) return fail(h, MSL_ERR_INVALID, "msl_download: probe range out of bounds");
+            off = (size_t)first * rows_per_probe * ld * es; n_probes = (size_t)count;
+        }
+        const size_t rows = n_probes * rows_per_probe;
+        len = rows * h->wpix * es;
+        if (bytes != len) return fail(h, MSL_ERR_INVALID, "msl_download: dst holds %zu bytes, buffer slice is %zu", bytes, len);
+        if (ld == h->wpix) {
+            HIPCHK(h, hipMemcpyAsync(dst, src + off, len, hipMemcpyDeviceToHost, h->stream));
+        } else {
+            HIPCHK(h, hipMemcpy2DAsync(dst, h->wpix * es, src + off, ld * es, h->wpix * es, rows, hipMemcpyDeviceToHost, h->stream));
+        }
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        return MSL_OK;
     }
     if (bytes != len) return fail(h, MSL_ERR_INVALID, "msl_download: dst holds %zu bytes, buffer slice is %zu", bytes, len);
     if ((what == MSL_BUF_PROBES || what == MSL_BUF_EXIT) && h->pitch != h->cfg.ny) {
@@ -2599,12 +2634,12 @@ static int frame_copy(msl_handle* h, int32_t slot, void* host, size_t bytes, boo
     if (bytes != npix * c.n_probes * sizeof(float2)) return fail(h, MSL_ERR_INVALID, "frame copy: buffer holds %zu bytes, a frame is %zu", bytes, npix * c.n_probes * sizeof(float2));
     HIPCHK(h, hipSetDevice(c.device));
     // (P, T, wx, wy) device <-> (P, wx, wy) host: P strided blocks of one image
-    float2* dev = h->wf + (size_t)slot * npix;
+    float2* dev = h->wf + (size_t)slot * h->wpitch;
     if (to_host)
-        HIPCHK(h, hipMemcpy2DAsync(host, npix * sizeof(float2), dev, (size_t)c.n_frames * npix * sizeof(float2), npix * sizeof(float2),
+        HIPCHK(h, hipMemcpy2DAsync(host, npix * sizeof(float2), dev, (size_t)c.n_frames * h->wpitch * sizeof(float2), npix * sizeof(float2),
                                    c.n_probes, hipMemcpyDeviceToHost, h->stream));
     else
-        HIPCHK(h, hipMemcpy2DAsync(dev, (size_t)c.n_frames * npix * sizeof(float2), host, npix * sizeof(float2), npix * sizeof(float2),
+        HIPCHK(h, hipMemcpy2DAsync(dev, (size_t)c.n_frames * h->wpitch * sizeof(float2), host, npix * sizeof(float2), npix * sizeof(float2),
                                    c.n_probes, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return MSL_OK;
@@ -2620,21 +2655,27 @@ int msl_download_wavefunction_c128(msl_handle* h, int32_t n_frames_used, void* d
         return fail(h, MSL_ERR_INVALID, "msl_download_wavefunction_c128: dst holds %zu bytes, the result has %zu", bytes, (size_t)c.n_probes * per_probe * sizeof(double2));
     HIPCHK(h, hipSetDevice(c.device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    // chunks of at most 256 MB of complex128 through the scratch buffer, probe by probe (a probe's used frames are contiguous)
+    // chunks of at most 256 MB of complex128 through the scratch buffer, probe by probe (a probe's used frames follow each other
+    // at the image pitch); a chunk is a whole number of images or a piece of one
     size_t chunk = std::min<size_t>(per_probe, (size_t)(256u << 20) / sizeof(double2));
+    if (chunk > h->wpix) chunk -= chunk % h->wpix;
     if (const char* e = dbg_env("MSL_C128_CHUNK")) chunk = std::max<size_t>(1, std::min<size_t>(chunk, (size_t)atoll(e)));      // (tests: several chunks per probe)
     int rc = ensure_scratch(h, chunk * sizeof(double2));
     if (rc) return rc;
     for (int p = 0; p < c.n_probes; ++p) {
-        const float2* src = h->wf + (size_t)p * c.n_frames * h->wpix;
+        const float2* src = h->wf + (size_t)p * c.n_frames * h->wpitch;
         double2* out = (double2*)dst + (size_t)p * per_probe;
-        for (size_t o = 0; o < per_probe; o += chunk) {
-            const size_t n = std::min(chunk, per_probe - o);
+        for (size_t o = 0; o < per_probe; ) {
+            // dense offset o = image o / wpix, pixel o % wpix; a piece that starts inside an image ends with it
+            const size_t img = o / h->wpix, px = o % h->wpix;
+            const size_t n = std::min(px ? std::min(chunk, h->wpix - px) : chunk, per_probe - o);
             const int grid = (int)std::min<size_t>((n + 255) / 256, (size_t)h->n_cus * 8);
-            hipLaunchKernelGGL(widen_c64_kernel, dim3(grid), dim3(256), 0, h->stream, src + o, (double2*)h->scratch, (long long)n);
+            hipLaunchKernelGGL(widen_c64_kernel, dim3(grid), dim3(256), 0, h->stream, src + img * h->wpitch + px, (double2*)h->scratch, (long long)n,
+                               (long long)h->wpix, (long long)h->wpitch);
             HIPCHK(h, hipGetLastError());
             HIPCHK(h, hipMemcpyAsync(out + o, h->scratch, n * sizeof(double2), hipMemcpyDeviceToHost, h->stream));
             HIPCHK(h, hipStreamSynchronize(h->stream));
+            o += n;
         }
     }
     return MSL_OK;

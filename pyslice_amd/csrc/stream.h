@@ -17,9 +17,9 @@
 
 namespace msl {
 
-// out[(p * T + slot0 + f) * (ox*oy) + X*oy + Y] = sum_{i<bx, j<by} stage[((f*P + p) * wx + X*bx + i) * wy + Y*by + j]
+// out[(p * T + slot0 + f) * opitch + X*oy + Y] = sum_{i<bx, j<by} stage[((f*P + p) * wx + X*bx + i) * wy + Y*by + j]
 __global__ void __launch_bounds__(256) bin_kernel(const float2* __restrict__ stage, float2* __restrict__ out, int P, int groups,
-                                                  int T, int slot0, int wx, int wy, int bx, int by) {
+                                                  int T, int slot0, int wx, int wy, int bx, int by, long long opitch) {
     const int ox = wx / bx, oy = wy / by;
     const long long opix = (long long)ox * oy;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -32,20 +32,20 @@ __global__ void __launch_bounds__(256) bin_kernel(const float2* __restrict__ sta
     float sx = 0.f, sy = 0.f;
     for (int a = 0; a < bx; ++a)
         for (int b = 0; b < by; ++b) { const float2 v = src[(long long)a * wy + b]; sx += v.x; sy += v.y; }
-    out[((long long)p * T + slot0 + f) * opix + o] = make_float2(sx, sy);
+    out[((long long)p * T + slot0 + f) * opitch + o] = make_float2(sx, sy);
 }
 
 #define MSL_FOLD_FCH 16        // frequency bins accumulated in registers per pass over the frame tile
 
 struct FoldJob {
-    const float2* wf;          // (P, ring, K): frame slots of the ring
+    const float2* wf;          // (P, ring, wfK): frame slots of the ring, K pixels at a pitch of wfK
     float2* acc;               // (P, F, K) accumulators
     double2* s1;               // (P, K)  sum_t Psi            (updated by the launch with f0 == 0)
     double* s2;                // (P, K)  sum_t |Psi|^2        (float64: T s2 - |s1|^2 cancels to the thermal part)
     const float2* tw;          // (T) exp(-2 pi i m / T)
     const int* bins;           // (F) unshifted FFT bin u_f of every accumulated frequency
     const float2* ref;         // (P, K) reference pattern subtracted from every frame before it is folded, or null
-    long long K;
+    long long K, wfK;
     int ring, first_slot, count, t0, T, F, f0;
 };
 
@@ -61,13 +61,13 @@ __global__ void __launch_bounds__(256) tacaw_fold_kernel(FoldJob job) {
     for (int f = 0; f < MSL_FOLD_FCH; ++f) a[f] = (f < nf) ? accp[(long long)f * job.K] : make_float2(0.f, 0.f);
     const bool sums = (job.f0 == 0);
     double s1x = 0.0, s1y = 0.0, s2 = 0.0;
-    const float2* src = job.wf + ((long long)p * job.ring + job.first_slot) * job.K + k;
+    const float2* src = job.wf + ((long long)p * job.ring + job.first_slot) * job.wfK + k;
     // Any time-independent offset only changes the u = 0 bin (sum_t exp(-2 pi i u t / T) = 0 otherwise), which the mean
     // subtraction zeroes anyway (tacaw_data.py:94): folding Psi_t - ref keeps the float32 accumulators at the size of the
     // thermal part instead of the Bragg amplitude, whose T terms would have to cancel.  S1 / S2 take the frames as they are.
     const float2 r = job.ref ? job.ref[(long long)p * job.K + k] : make_float2(0.f, 0.f);
     for (int i = 0; i < job.count; ++i) {
-        float2 v = src[(long long)i * job.K];
+        float2 v = src[(long long)i * job.wfK];
         const int t = job.t0 + i;                    // uniform
         if (sums) { s1x += (double)v.x; s1y += (double)v.y; s2 += (double)v.x * v.x + (double)v.y * v.y; }
         v.x -= r.x; v.y -= r.y;

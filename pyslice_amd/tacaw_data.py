@@ -54,9 +54,7 @@ class TACAWData(WFData):
             eng.tacaw()
             self._intensity_src = (eng, None)          # reductions read the library's own buffer
             if self.__dict__.get("_output") == "device":
-                ptr = eng.device_ptr(_native.BUF_INTENSITY)
-                shape = (eng.n_probes, eng.intensity_F, eng.wx, eng.wy)
-                self.intensity = torch.as_tensor(_native.DeviceArray(ptr, shape, "<f4", owner=eng), device=f"cuda:{eng.device}")
+                self.intensity = torch.as_tensor(eng.result_view(_native.BUF_INTENSITY, "<f4"), device=f"cuda:{eng.device}")
             else:
                 self.intensity = _as_tensor(eng.intensity().astype(np.float64))
             return
@@ -87,9 +85,8 @@ class TACAWData(WFData):
         from . import distributed as D
         n_frames, t_local = shard
         P, nx, ny = eng.n_probes, eng.wx, eng.wy
-        ptr = eng.device_ptr(_native.BUF_WAVEFUNCTION)
         dev = torch.device("cuda", eng.device)
-        local = torch.as_tensor(_native.DeviceArray(ptr, (P, eng.n_frames, nx, ny), "<c8", owner=eng), device=dev)[:, :t_local]
+        local = torch.as_tensor(eng.result_view(_native.BUF_WAVEFUNCTION, "<c8"), device=dev)[:, :t_local]
         mine = D.frames_to_probes(local.reshape(P, t_local, nx * ny), n_frames)         # (P_r, T, npix)
         out = torch.empty(mine.shape, dtype=torch.float32, device=dev)
         if mine.shape[0] > 0:
@@ -104,11 +101,13 @@ class TACAWData(WFData):
 
     # ---- reductions over intensity(P, F, kx, ky): device kernels behind the reference's method signatures -------
     def _source(self):
-        """(engine, src) for the reduction entry points; src = None (library buffer) or (ptr, B, F, K)."""
+        """(engine, src, (B, F, K), ptr, ld) for the reduction entry points; src = None (library buffer) or (ptr, B, F, K);
+        ld = elements between the rows of K pixels behind ptr (the library's buffer keeps its images at a line-aligned pitch)."""
         d = self.__dict__
         eng, dev = d.get("_intensity_src", (None, None))
         if dev is None and eng is not None:
-            return eng, None, (eng.n_probes, eng.intensity_F, eng.wx * eng.wy), eng.device_ptr(_native.BUF_INTENSITY)
+            return (eng, None, (eng.n_probes, eng.intensity_F, eng.wx * eng.wy), eng.device_ptr(_native.BUF_INTENSITY),
+                    eng.result_pitch(_native.BUF_INTENSITY))
         if dev is None:
             # intensity assembled elsewhere: stage a float32 copy on the device once
             if not TORCH_AVAILABLE or not torch.cuda.is_available():
@@ -125,12 +124,12 @@ class TACAWData(WFData):
         torch.cuda.synchronize(dev.device)
         B, F = int(dev.shape[0]), int(dev.shape[1])
         K = int(np.prod(dev.shape[2:]))
-        return eng, (dev.data_ptr(), B, F, K), (B, F, K), dev.data_ptr()
+        return eng, (dev.data_ptr(), B, F, K), (B, F, K), dev.data_ptr(), K
 
     def _rows(self, b, f0, f1, mask=None):
         """sum over k of I[b, f0:f1] -> (f1-f0,) float64"""
-        eng, _, (B, F, K), ptr = self._source()
-        return eng.tacaw_spectrum(mask, src=(ptr + 4 * (b * F + f0) * K, 1, f1 - f0, K))[0]
+        eng, _, (B, F, K), ptr, ld = self._source()
+        return eng.tacaw_spectrum(mask, src=(ptr + 4 * (b * F + f0) * ld, 1, f1 - f0, K, ld))[0]
 
     def _check_probe(self, probe_index):
         if probe_index >= len(self.probe_positions):
@@ -138,7 +137,7 @@ class TACAWData(WFData):
 
     def spectrum(self, probe_index: int = None) -> np.ndarray:
         """reference tacaw_data.py:109-143"""
-        eng, src, (B, F, K), _ = self._source()
+        eng, src, (B, F, K), _, _ = self._source()
         if probe_index is None:
             return eng.tacaw_spectrum(src=src)[:len(self.probe_positions)].mean(axis=0)
         self._check_probe(probe_index)
@@ -153,7 +152,7 @@ class TACAWData(WFData):
 
     def diffraction(self, probe_index: int = None) -> np.ndarray:
         """reference tacaw_data.py:183-217"""
-        eng, src, (B, F, K), _ = self._source()
+        eng, src, (B, F, K), _, _ = self._source()
         shape = (len(self.kxs), len(self.kys))
         if probe_index is None:
             n = len(self.probe_positions)
@@ -164,7 +163,7 @@ class TACAWData(WFData):
     def spectral_diffraction(self, frequency: float, probe_index: int = None) -> np.ndarray:
         """reference tacaw_data.py:219-254"""
         fi = int(np.argmin(np.abs(self.frequencies - frequency)))
-        eng, src, (B, F, K), _ = self._source()
+        eng, src, (B, F, K), _, _ = self._source()
         shape = (len(self.kxs), len(self.kys))
         if probe_index is None:
             n = len(self.probe_positions)
@@ -178,12 +177,12 @@ class TACAWData(WFData):
         kernel, any other mask the float64-weighted sum (msl_tacaw_spectrum_weighted)."""
         if mask.shape != (len(self.kxs), len(self.kys)):
             raise ValueError(f"Mask shape {mask.shape} doesn't match k-space shape ({len(self.kxs)}, {len(self.kys)})")
-        eng, src, (B, F, K), ptr = self._source()
+        eng, src, (B, F, K), ptr, ld = self._source()
         mask = np.asarray(mask)
         binary = mask.dtype == np.bool_ or bool(np.all((mask == 0) | (mask == 1)))
 
         def masked(b0, nb):
-            s = (ptr + 4 * b0 * F * K, nb, F, K)
+            s = (ptr + 4 * b0 * F * ld, nb, F, K, ld)
             return eng.tacaw_spectrum(mask != 0, src=s) if binary else eng.tacaw_spectrum_weighted(mask, src=s)
 
         if probe_index is None:
@@ -197,7 +196,7 @@ class TACAWData(WFData):
         ix = np.array([int(np.argmin(np.abs(kxs - v))) for v in kx_path], dtype=np.int64)
         iy = np.array([int(np.argmin(np.abs(kys - v))) for v in ky_path], dtype=np.int64)
         n = min(len(ix), len(iy))
-        eng, src, (B, F, K), _ = self._source()
+        eng, src, (B, F, K), _, _ = self._source()
         if probe_index is not None:
             self._check_probe(probe_index)
         out = np.zeros((len(self.frequencies), len(ix)))          # zip() semantics: columns past the shorter path stay 0

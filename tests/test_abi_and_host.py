@@ -25,7 +25,7 @@ def test_header_symbols_exported(lib):
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in mslice.h but not exported"
     assert declared == set(_native.EXPORTS)
-    assert lib.msl_abi_version() == 2
+    assert lib.msl_abi_version() == 3
 
 
 def test_struct_layouts_match_header(lib):

@@ -1476,3 +1476,72 @@ def test_tacaw_time_axis_256_frames(ps, orc):
     finally:
         del os.environ["MSL_TACAW_GENERIC"], os.environ["MSL_DEBUG"]
     assert rel_l2(got, gen) < 1e-5
+
+
+@pytest.mark.parametrize("nx,ny,T,P,window", [(45, 37, 20, 3, None), (64, 64, 12, 2, (21, 19)), (33, 31, 100, 2, None)])
+def test_results_on_odd_pixel_counts_sit_at_a_line_aligned_pitch(ps, orc, nx, ny, T, P, window):
+    """Library-owned (P,T,wx,wy) results keep every image at msl_result_pitch() pixels (a multiple of 32), so that the time
+    kernels move whole lines on grids like the reference's 501 x 491 (00_probe.py:7-8; tacaw_data.py:94-104 runs over exactly
+    such arrays).  Everything that hides or carries the pitch, against the oracle: dense downloads (complex64, complex128, one
+    frame), the strided zero-copy views (output='device'), the time FFT, every reduction from the library's own buffer and
+    through a pointer into it, ADF, and the frame up/download used by the cache."""
+    import torch
+    from pyslice_amd import _native
+    from pyslice_amd.synthetic import synthetic_trajectory
+    tr = synthetic_trajectory(nx, 3, T, ny=ny, density=0.08, seed=5 + T)
+    lx, ly = tr.box_matrix[0, 0], tr.box_matrix[1, 1]
+    pp = [tuple(v) for v in np.random.default_rng(3).random((P, 2)) * [lx, ly]]
+    want = orc.run_frames(tr.box_matrix, tr.positions, tr.atom_types, 30.0, 100e3, pp)["wavefunction_data"]
+    if window:
+        x0, y0 = nx // 2 - window[0] // 2, ny // 2 - window[1] // 2
+        want = want[:, :, x0:x0 + window[0], y0:y0 + window[1]]
+    wx, wy = want.shape[2], want.shape[3]
+    f, inten = orc.tacaw(want, np.arange(T) * tr.timestep)
+    calc = ps.MultisliceCalculator(progress=False, output="device", k_window=window)
+    calc.setup(tr, aperture=30.0, voltage_eV=100e3, probe_positions=pp)
+    wf = calc.run()
+    eng = calc._engine
+    pitch = eng.result_pitch(_native.BUF_WAVEFUNCTION)
+    assert pitch % 32 == 0 and wx * wy <= pitch < wx * wy + 32 and (wx * wy) % 32 != 0
+    assert eng.buffer_bytes(_native.BUF_WAVEFUNCTION) == P * T * pitch * 8
+    view = wf.wavefunction_data                                     # strided zero-copy view, (P, T, wx, wy, 1)
+    assert tuple(view.shape) == (P, T, wx, wy, 1) and view.stride()[1] == pitch and not view.is_contiguous()
+    assert rel_l2(npy(view), want) < 1e-4
+    host = eng.wavefunction()
+    assert np.array_equal(host, npy(view)[..., 0])
+    assert np.array_equal(eng.wavefunction(first=1, count=P - 1), host[1:])
+    assert np.array_equal(eng.wavefunction_c128(T - 1), host[:, :T - 1].astype(np.complex128))
+    assert np.array_equal(eng.frame(T // 2), host[:, T // 2])
+    # pad pixels hold zeros, before and after the time FFT
+    raw = torch.as_tensor(_native.DeviceArray(eng.device_ptr(_native.BUF_WAVEFUNCTION), (P, T, pitch), "<c8", owner=eng), device="cuda")
+    assert float(raw[:, :, wx * wy:].abs().max()) == 0.0
+    tac = ps.TACAWData(wf)
+    got = npy(tac.intensity)
+    assert got.shape == inten.shape and rel_l2(got, inten) < TACAW_TOL
+    assert eng.result_pitch(_native.BUF_INTENSITY) == pitch and not tac.intensity.is_contiguous()
+    assert np.array_equal(eng.intensity(), got.astype(np.float32))
+    assert np.array_equal(eng.intensity(first=P - 1, count=1), got[P - 1:].astype(np.float32))
+    kxs, kys = npy(wf.kxs), npy(wf.kys)
+    mask = np.hypot(kxs[:, None], kys[None, :]) < 0.6 * max(np.abs(kxs).max(), np.abs(kys).max())
+    soft = np.exp(-(kxs[:, None] ** 2 + kys[None, :] ** 2) / 3.0)
+    I = inten
+    assert rel_l2(tac.spectrum(None), I.sum(axis=(2, 3)).mean(axis=0)) < TACAW_TOL
+    assert rel_l2(tac.spectrum(P - 1), I[P - 1].sum(axis=(1, 2))) < TACAW_TOL
+    assert rel_l2(tac.diffraction(None), I.sum(axis=1).mean(axis=0)) < TACAW_TOL
+    assert rel_l2(tac.diffraction(1), I[1].sum(axis=0)) < TACAW_TOL
+    fq = float(f[T // 2 + 2])
+    assert rel_l2(tac.spectral_diffraction(fq, 0), I[0, T // 2 + 2]) < TACAW_TOL
+    assert rel_l2(tac.spectrum_image(fq), I[:, T // 2 + 2].sum(axis=(1, 2))) < TACAW_TOL
+    assert rel_l2(tac.masked_spectrum(mask, 1), (I[1] * mask[None]).sum(axis=(1, 2))) < TACAW_TOL
+    assert rel_l2(tac.masked_spectrum(mask), (I * mask[None, None]).sum(axis=(2, 3)).mean(axis=0)) < TACAW_TOL
+    assert rel_l2(tac.masked_spectrum(soft, P - 1), (I[P - 1] * soft[None]).sum(axis=(1, 2))) < TACAW_TOL
+    ix, iy = [0, wx // 2, wx - 1], [wy - 1, wy // 3, 0]
+    assert rel_l2(tac.dispersion(kxs[ix], kys[iy], 1), I[1][:, ix, iy]) < TACAW_TOL
+    # ADF over the resident exit waves (haadf_data.py:72-94) with the last pixel of an image inside the mask
+    m = np.ones((wx, wy), dtype=bool); m[: wx // 2] = False
+    assert rel_l2(eng.adf(m), (np.abs(want[..., 0]) * m).sum(axis=(2, 3)).mean(axis=1)) < 1e-4
+    # the cache path: a frame written back lands where it came from
+    frame = (host[:, 3] * 2).astype(np.complex64)
+    eng.upload_frame(3, frame)
+    assert np.array_equal(eng.frame(3), frame) and np.array_equal(eng.frame(2), host[:, 2]) and np.array_equal(eng.frame(4), host[:, 4])
+    assert float(raw[:, :, wx * wy:].abs().max()) == 0.0
