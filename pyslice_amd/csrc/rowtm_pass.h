@@ -17,6 +17,16 @@
 #pragma once
 #include "rowt_pass.h"
 
+// the next line is prefetched in MSL_TM_PFQ parts, behind the first MSL_TM_PFQ of the four exchanges of an iteration
+#ifndef MSL_TM_PFQ
+#define MSL_TM_PFQ 4
+#endif
+// ablation bits of tools/rowtm_bench.hip (timing only, results wrong): 1 no exchanges, 2 no table products, 4 no register transforms,
+// 8 no tile / barriers / store phase, 16 no prefetch loads
+#ifndef MSL_TM_ABL
+#define MSL_TM_ABL 0
+#endif
+
 namespace msl {
 
 // tile line pitch in float2: room for both exchange images and the line itself; 2 mod 32 (rowT_pass_kernel)
@@ -32,6 +42,7 @@ constexpr size_t rowTM_lds_bytes(int A, int B) { return ((size_t)3 * A * B + (si
 template <int NP, bool INV, int RM>
 __device__ __forceinline__ void tm_fft(float2 (&v)[RM]) {
     static_assert(NP <= RM, "register file of the line");
+    if constexpr ((MSL_TM_ABL & 4) != 0) return;
     dif<NP, 1, INV>(v);
     float2 t[NP];
     unscramble<NP, 0>(v, t);
@@ -43,6 +54,7 @@ __device__ __forceinline__ void tm_fft(float2 (&v)[RM]) {
 template <int NP, int STRIDE, bool CONJ, int RM>
 __device__ __forceinline__ void tm_mul(float2 (&v)[RM], const float2* tab) {
     constexpr int TCH = 8;
+    if constexpr ((MSL_TM_ABL & 2) != 0) return;
 #pragma unroll
     for (int c = 0; c < NP; c += TCH) {
         float2 w[TCH];
@@ -59,6 +71,7 @@ template <int NA, int NB, int RM>
 __device__ __forceinline__ void tm_exchange(float2 (&v)[RM], float2* x, int ln) {
     constexpr int PA = NA | 1;
     const int la = ln < NA ? ln : NA - 1, lb = ln < NB ? ln : NB - 1;
+    if constexpr ((MSL_TM_ABL & 1) != 0) return;
     wave_lds_fence();
 #pragma unroll
     for (int b = 0; b < NB; ++b) x[b * PA + la] = v[b];
@@ -126,10 +139,10 @@ __global__ void __launch_bounds__(16 * G, 2) rowTM_pass_kernel(RowTJob job) {
         const float2* nptr = line_ptr(more ? nlb : lb, more ? npc : pc, more ? nk : k);
         auto pfx = [&](auto i_c) {
             constexpr int I = decltype(i_c)::value;
-            constexpr int LO = B * I / 4, HI = B * (I + 1) / 4;
+            constexpr int LO = I < MSL_TM_PFQ ? B * I / MSL_TM_PFQ : B, HI = I < MSL_TM_PFQ ? B * (I + 1) / MSL_TM_PFQ : B;
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = LO; j < HI; ++j) vn[j] = ld_stream(nptr + j * A);
+            for (int j = LO; j < HI; ++j) if constexpr ((MSL_TM_ABL & 16) == 0) vn[j] = ld_stream(nptr + j * A);
             __builtin_amdgcn_sched_barrier(0);
         };
         // A = ifft_N . P . fft_N, layout 1 in and out; two prefetch slots
@@ -151,6 +164,14 @@ __global__ void __launch_bounds__(16 * G, 2) rowTM_pass_kernel(RowTJob job) {
 #pragma unroll
         for (int j = 0; j < B; ++j) v[j] = cmulf(v[j], tv[j]);
         if (job.flags & P2_POST_A) a_op(MSL_IC(2)); else { pfx(MSL_IC(2)); pfx(MSL_IC(3)); }
+        if constexpr ((MSL_TM_ABL & 8) != 0) {                      // keep the result alive: one store per lane
+            float2 acc = v[0];
+#pragma unroll
+            for (int j = 1; j < B; ++j) { acc.x += v[j].x; acc.y += v[j].y; }
+            if (acc.x == 12345.678f) job.out[tid] = acc;
+            item = nitem; lb = nlb; pc = npc; k = nk;
+            continue;
+        }
         wave_lds_fence();
 #pragma unroll
         for (int j = 0; j < B; ++j) myrow[j * A + lnA] = v[j];
@@ -270,10 +291,10 @@ __global__ void __launch_bounds__(512, 2) rowTM2_pass_kernel(RowTJob job) {
         const float2* nptr = line_ptr(more ? nlb : lb, more ? npc : pc, more ? nk : k);
         auto pfx = [&](auto i_c) {
             constexpr int I = decltype(i_c)::value;
-            constexpr int LO = B * I / 4, HI = B * (I + 1) / 4;
+            constexpr int LO = I < MSL_TM_PFQ ? B * I / MSL_TM_PFQ : B, HI = I < MSL_TM_PFQ ? B * (I + 1) / MSL_TM_PFQ : B;
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = LO; j < HI; ++j) vn[j] = ld_stream(nptr + j * A2);
+            for (int j = LO; j < HI; ++j) if constexpr ((MSL_TM_ABL & 16) == 0) vn[j] = ld_stream(nptr + j * A2);
             __builtin_amdgcn_sched_barrier(0);
         };
         // radix-2 step across the lane pair: v[m] <- partner + sgn * own, the odd lane's twiddle behind it (forward) or in front (inverse)
@@ -300,6 +321,7 @@ __global__ void __launch_bounds__(512, 2) rowTM2_pass_kernel(RowTJob job) {
             constexpr int I = decltype(i_c)::value;
             tm_fft<B, false>(v);
             tm_mul<B, A2, false>(v, tw1 + n1c);
+            if constexpr ((MSL_TM_ABL & 1) == 0) {
             wave_lds_fence();
 #pragma unroll
             for (int b = 0; b < B; ++b) x1w[b * P1] = v[b];
@@ -307,6 +329,7 @@ __global__ void __launch_bounds__(512, 2) rowTM2_pass_kernel(RowTJob job) {
 #pragma unroll
             for (int m = 0; m < A; ++m) v[m] = x1r[m];
             wave_lds_fence();
+            }
             pfx(MSL_IC(I));
             pair_step(std::false_type{});
             tm_fft<A, false>(v);
@@ -314,6 +337,7 @@ __global__ void __launch_bounds__(512, 2) rowTM2_pass_kernel(RowTJob job) {
             tm_fft<A, true>(v);
             pair_step(std::true_type{});
             tm_mul<A, B2, true>(v, tw2 + Lc);
+            if constexpr ((MSL_TM_ABL & 1) == 0) {
             wave_lds_fence();
 #pragma unroll
             for (int m = 0; m < A; ++m) x2w[m * P2] = v[m];
@@ -321,6 +345,7 @@ __global__ void __launch_bounds__(512, 2) rowTM2_pass_kernel(RowTJob job) {
 #pragma unroll
             for (int b = 0; b < B; ++b) v[b] = x2r[b];
             wave_lds_fence();
+            }
             pfx(MSL_IC(I + 1));
             tm_fft<B, true>(v);
         };
@@ -328,6 +353,14 @@ __global__ void __launch_bounds__(512, 2) rowTM2_pass_kernel(RowTJob job) {
 #pragma unroll
         for (int j = 0; j < B; ++j) v[j] = cmulf(v[j], tv[j]);
         if (job.flags & P2_POST_A) a_op(MSL_IC(2)); else { pfx(MSL_IC(2)); pfx(MSL_IC(3)); }
+        if constexpr ((MSL_TM_ABL & 8) != 0) {
+            float2 acc = v[0];
+#pragma unroll
+            for (int j = 1; j < B; ++j) { acc.x += v[j].x; acc.y += v[j].y; }
+            if (acc.x == 12345.678f) job.out[tid] = acc;
+            item = nitem; lb = nlb; pc = npc; k = nk;
+            continue;
+        }
         wave_lds_fence();
 #pragma unroll
         for (int j = 0; j < B; ++j) myrow[j * A2 + n1c] = v[j];

@@ -1,7 +1,8 @@
 """Two ranks on one MI355X (gloo rehearsal of the one-process-per-GPU path): frames are sharded over the ranks, each
 rank propagates its shard on the device, WFData is gathered on rank 0, and TACAWData re-shards frames -> probes with
-the all-to-all, runs the device time FFT per rank and gathers the intensities.  RCCL itself needs >= 2 GPUs and is
-exercised by `bench.py --gpus N`; the exchange logic, shard arithmetic and device plumbing are the same code."""
+the all-to-all, runs the device time FFT per rank and gathers the intensities.  RCCL itself needs one GPU per rank and is
+exercised by `bench.py --gpus N`; the exchange logic, shard arithmetic and device plumbing are the same code, and the last test
+runs the grouped send / receive on RCCL with the rank as its own peer."""
 import os
 import socket
 
@@ -298,3 +299,59 @@ def test_bench_single_gpu_line_and_c3_full_block():
     assert c3["parseval_rel"] < 1e-4 and c3["time_fft_worst_series_rel_l2"] < 2e-4
     assert j["tacaw"]["frames"] == 64 and "real frames" in j["tacaw"]["note"]
     assert len(c3["spectrum_peak_THz"]) == 3 and min(abs(p - 25.0) for p in c3["spectrum_peak_THz"]) <= c3["frequency_resolution_THz"]
+
+
+_RCCL_LOOPBACK = r'''
+import os, sys
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+import numpy as np, torch, torch.distributed as dist
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+from pyslice_amd import _native, distributed as D
+# a library-owned result buffer (hipMalloc of libmslice, not torch's allocator) on an odd pixel count: strided zero-copy view
+P, T, nx, ny = 3, 4, 9, 7
+eng = _native.Engine(nx, ny, 1, 0.1, 0.1, 0.5, 0.037, 1e-3, n_probes=P, n_frames=T, device=0)
+rng = np.random.default_rng(5)
+frames = (rng.standard_normal((P, T, nx, ny)) + 1j * rng.standard_normal((P, T, nx, ny))).astype(np.complex64)
+for t in range(T):
+    eng.upload_frame(t, frames[:, t])
+view = torch.as_tensor(eng.result_view(_native.BUF_WAVEFUNCTION, "<c8"), device="cuda")
+assert not view.is_contiguous()
+# the grouped point-to-point launch of every exchange plan (distributed._run: batch_isend_irecv = ncclGroupStart/End), here with
+# the rank as its own peer: probe 1's frames [1, 3) out of the library buffer, into a torch tensor
+dst = torch.zeros((2, nx, ny, 2), dtype=torch.float32, device="cuda")
+src_real, cplx, dev = D._as_real(view)
+ops = [D.Op("recv", 0, 0, dst.numel(), 0, ("dst",)), D.Op("send", 0, 0, dst.numel(), 0, ("src",))]
+D._run(ops, lambda w: dst if w[0] == "dst" else D._chunk(src_real[1, 1:3]))
+torch.cuda.synchronize()
+got = torch.view_as_complex(dst).cpu().numpy()
+assert np.array_equal(got, frames[1, 1:3]), "RCCL self-exchange out of the library buffer"
+# ... and INTO the library buffer (receives land in the destination, no staging): frame slot 0 of probe 2, one dense image row at a time
+new = torch.view_as_real(torch.from_numpy(frames[0, 3]).cuda().contiguous())
+rows = torch.view_as_real(view)[2, 0]
+assert rows.is_contiguous()                     # one image = nx*ny pixels at the start of its pitch
+ops = [D.Op("recv", 0, 0, rows.numel(), 0, ("into",)), D.Op("send", 0, 0, rows.numel(), 0, ("from",))]
+D._run(ops, lambda w: rows if w[0] == "into" else new)
+torch.cuda.synchronize()
+assert np.array_equal(eng.frame(0)[2], frames[0, 3]) and np.array_equal(eng.frame(0)[1], frames[1, 0])
+# the collectives bench.py's timing protocol uses
+t = torch.tensor([3.5], device="cuda")
+dist.barrier()
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+assert float(t) == 3.5
+print("rccl-loopback-ok", torch.cuda.nccl.version())
+dist.destroy_process_group()
+'''
+
+
+def test_rccl_executes_the_grouped_exchange_on_library_buffers():
+    """RCCL needs one GPU per rank, so the multi-rank tests above run on gloo.  What one GPU can show of the real transport: a
+    world-size-1 "nccl" group runs distributed._run's grouped send/receive (the rank as its own peer) out of and into the library's
+    own hipMalloc'ed result buffer through the strided zero-copy view, plus the barrier / max-reduce of bench.py's timing."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), PYTHONPATH=repo)
+    r = subprocess.run([sys.executable, "-c", _RCCL_LOOPBACK], env=env, capture_output=True, text=True, timeout=240, cwd=repo)
+    assert r.returncode == 0 and "rccl-loopback-ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
