@@ -66,6 +66,20 @@ def _worker(rank, world, port, q):
             out["diffraction_win"] = tac3.diffraction(1)
         else:
             assert tac3.intensity is None
+        # an odd pixel count (21 x 19 = 399 pixels at a pitch of 416): the shards are STRIDED views of the library's buffers
+        for tag, gather in (("odd", "rank0"), ("odd_none", "none")):
+            calc4 = ps.MultisliceCalculator(device=0, progress=False, gather=gather, output="device", k_window=(21, 19))
+            calc4.setup(tr, aperture=30.0, voltage_eV=100e3, probe_positions=pp)
+            wf4 = calc4.run()
+            assert calc4._engine.result_pitch() == 416
+            if gather == "rank0":
+                if rank == 0:
+                    out["wf_odd"] = wf4.wavefunction_data.cpu().numpy()
+                continue
+            tac4 = ps.TACAWData(wf4)
+            if rank == 0:
+                out["intensity_odd"] = tac4.intensity.cpu().numpy()
+                out["spectrum_odd"] = tac4.spectrum(2)
         q.put((rank, out))
     finally:
         dist.destroy_process_group()
@@ -107,6 +121,10 @@ def test_two_ranks_frame_sharding_gather_and_tacaw():
     assert np.linalg.norm(res[0]["intensity_win"] - win) / np.linalg.norm(win) < 2e-4
     assert rel_l2(res[0]["spectrum_win"], win.sum(axis=(2, 3)).mean(axis=0)) < 2e-4
     assert rel_l2(res[0]["diffraction_win"], win[1].sum(axis=0)) < 2e-4
+    odd = (slice(128 - 10, 128 - 10 + 21), slice(128 - 9, 128 - 9 + 19))
+    assert rel_l2(res[0]["wf_odd"], want[:, :, odd[0], odd[1]]) < 1e-4
+    assert rel_l2(res[0]["intensity_odd"], inten[:, :, odd[0], odd[1]]) < 2e-4
+    assert rel_l2(res[0]["spectrum_odd"], inten[2][:, odd[0], odd[1]].sum(axis=(1, 2))) < 2e-4
 
 
 def _stream_worker(rank, world, port, q):
