@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libmslice.so")
 # translation units, compiled in parallel (the 70 time-kernel instantiations are two thirds of the compile time)
-SOURCES = ["mslice.hip", "slice_pass.hip", "slice_mixed_a.hip", "slice_mixed_b.hip", "slice_mixed_c.hip", "tacaw_direct.hip", "tacaw_split.hip", "tacaw_split2.hip"]
+SOURCES = ["mslice.hip", "slice_pass.hip", "slice_mixed_a.hip", "slice_mixed_b.hip", "slice_mixed_c.hip", "slice_mixed_d.hip", "slice_mixed_e.hip", "slice_mixed_f.hip", "tacaw_direct.hip", "tacaw_split.hip", "tacaw_split2.hip"]
 def _deps():
     """every source and header of csrc/ plus the public header"""
     return sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))) + [os.path.join("..", "..", "include", "mslice.h")]

@@ -96,15 +96,21 @@ MSL_HD cf twiddle_mul(cf t) {
 // Radix plan of the decimation-in-frequency network: radix 4 while the length allows it, then one radix-2 stage
 // (32 = 4.4.2, 16 = 4.4).  Half as many twiddle multiplications on every input-to-output path as a pure radix-2
 // network: the rounding error of a transform, which accumulates linearly over the slices of a multislice run, halves.
-// Other lengths (the per-lane time transform of tacaw_time.h: 100 = 4.5.5 frames, 96 = 4.4.2.3 ...) continue with radix 5 and 3;
-// a length with another prime factor has no plan (fft_smooth).
-constexpr int fft_radix(int n) { return (n % 4 == 0) ? 4 : (n % 2 == 0) ? 2 : (n % 5 == 0) ? 5 : 3; }
+// Other lengths (the per-lane time transform of tacaw_time.h: 100 = 4.5.5 frames, 96 = 4.4.2.3 ...) continue with radix 5, 3 and 7
+// (7: the mixed-radix slice-loop passes of rowtm_pass.h); a length with another prime factor has no plan.
+// fft_smooth: factors 2, 3, 5 (what the time kernels are instantiated for); fft_smooth7: 7 as well.
+constexpr int fft_radix(int n) { return (n % 4 == 0) ? 4 : (n % 2 == 0) ? 2 : (n % 5 == 0) ? 5 : (n % 3 == 0) ? 3 : 7; }
 constexpr bool fft_smooth(int n) {
     if (n < 1) return false;
     while (n % 2 == 0) n /= 2;
     while (n % 3 == 0) n /= 3;
     while (n % 5 == 0) n /= 5;
     return n == 1;
+}
+constexpr bool fft_smooth7(int n) {
+    if (n < 1) return false;
+    while (n % 7 == 0) n /= 7;
+    return fft_smooth(n);
 }
 
 // frequency index held at position i after dif<N>: block q = i / (N/r) holds the sub-transform of the outputs r m + q
@@ -187,6 +193,40 @@ MSL_HD void dif5_level(cf* v) {
     }
 }
 
+// radix 7 on the sums and differences of the pairs (1,6), (2,5), (3,4): y_k = a0 + sum_j cos(2 pi j k / 7) p_j -+ i sum_j sin(2 pi j k / 7) d_j
+template <int N, int S, bool INV, int K, bool FENCE = false>
+MSL_HD void dif7_level(cf* v) {
+    if constexpr (K < N / 7) {
+        constexpr int Q = N / 7;
+        constexpr float c1 = 0.62348980185873353053f, c2 = -0.22252093395631440429f, c3 = -0.90096886790241912624f;   // cos(2 pi k / 7)
+        constexpr float s1 = 0.78183148246802980871f, s2 = 0.97492791218182360702f, s3 = 0.43388373911755812048f;    // sin(2 pi k / 7)
+        const cf a0 = v[K * S], a1 = v[(K + Q) * S], a2 = v[(K + 2 * Q) * S], a3 = v[(K + 3 * Q) * S], a4 = v[(K + 4 * Q) * S],
+                 a5 = v[(K + 5 * Q) * S], a6 = v[(K + 6 * Q) * S];
+        const cf p1 = mk(a1.x + a6.x, a1.y + a6.y), d1 = mk(a1.x - a6.x, a1.y - a6.y);
+        const cf p2 = mk(a2.x + a5.x, a2.y + a5.y), d2 = mk(a2.x - a5.x, a2.y - a5.y);
+        const cf p3 = mk(a3.x + a4.x, a3.y + a4.y), d3 = mk(a3.x - a4.x, a3.y - a4.y);
+        const cf m1 = mk(a0.x + c1 * p1.x + c2 * p2.x + c3 * p3.x, a0.y + c1 * p1.y + c2 * p2.y + c3 * p3.y);
+        const cf m2 = mk(a0.x + c2 * p1.x + c3 * p2.x + c1 * p3.x, a0.y + c2 * p1.y + c3 * p2.y + c1 * p3.y);
+        const cf m3 = mk(a0.x + c3 * p1.x + c1 * p2.x + c2 * p3.x, a0.y + c3 * p1.y + c1 * p2.y + c2 * p3.y);
+        const cf n1 = mk(s1 * d1.x + s2 * d2.x + s3 * d3.x, s1 * d1.y + s2 * d2.y + s3 * d3.y);
+        const cf n2 = mk(s2 * d1.x - s3 * d2.x - s1 * d3.x, s2 * d1.y - s3 * d2.y - s1 * d3.y);
+        const cf n3 = mk(s3 * d1.x - s1 * d2.x + s2 * d3.x, s3 * d1.y - s1 * d2.y + s2 * d3.y);
+        // forward: y_k = m_k - i n_k, y_{7-k} = m_k + i n_k; the inverse swaps the signs
+        const cf r1 = INV ? mk(-n1.y, n1.x) : mk(n1.y, -n1.x);
+        const cf r2 = INV ? mk(-n2.y, n2.x) : mk(n2.y, -n2.x);
+        const cf r3 = INV ? mk(-n3.y, n3.x) : mk(n3.y, -n3.x);
+        v[K * S] = mk(a0.x + p1.x + p2.x + p3.x, a0.y + p1.y + p2.y + p3.y);
+        v[(K + Q) * S] = twiddle_mul<N, K, INV>(mk(m1.x + r1.x, m1.y + r1.y));
+        v[(K + 2 * Q) * S] = twiddle_mul<N, 2 * K, INV>(mk(m2.x + r2.x, m2.y + r2.y));
+        v[(K + 3 * Q) * S] = twiddle_mul<N, 3 * K, INV>(mk(m3.x + r3.x, m3.y + r3.y));
+        v[(K + 4 * Q) * S] = twiddle_mul<N, 4 * K, INV>(mk(m3.x - r3.x, m3.y - r3.y));
+        v[(K + 5 * Q) * S] = twiddle_mul<N, 5 * K, INV>(mk(m2.x - r2.x, m2.y - r2.y));
+        v[(K + 6 * Q) * S] = twiddle_mul<N, 6 * K, INV>(mk(m1.x - r1.x, m1.y - r1.y));
+        fft_fence<FENCE>();
+        dif7_level<N, S, INV, K + 1, FENCE>(v);
+    }
+}
+
 template <int N, int S, bool INV, int Q, bool FENCE = false>
 MSL_HD void dif_blocks(cf* v);
 
@@ -197,7 +237,8 @@ MSL_HD void dif(cf* v) {
         if constexpr (fft_radix(N) == 4) dif4_level<N, S, INV, 0, FENCE>(v);
         else if constexpr (fft_radix(N) == 2) dif2_level<N, S, INV, 0, FENCE>(v);
         else if constexpr (fft_radix(N) == 5) dif5_level<N, S, INV, 0, FENCE>(v);
-        else dif3_level<N, S, INV, 0, FENCE>(v);
+        else if constexpr (fft_radix(N) == 3) dif3_level<N, S, INV, 0, FENCE>(v);
+        else dif7_level<N, S, INV, 0, FENCE>(v);
         dif_blocks<N, S, INV, 0, FENCE>(v);
     }
 }

@@ -1,4 +1,4 @@
-// The transposing slice-loop pass for lines of a smooth length N = A * B (A, B <= 32, factors 2, 3, 5): a DIRECT mixed-radix
+// The transposing slice-loop pass for lines of a smooth length N = A * B (A, B <= 32, factors 2, 3, 5, 7): a DIRECT mixed-radix
 // four-step transform on the register FFTs of fft_regs.h instead of the 2-4 x zero-padded power-of-two convolution of
 // rowTB_pass_kernel / rowTB2_pass_kernel (reference Propagate, src/multislice/multislice.py:278-294; the reference's grids are
 // int(L / sampling) + 1 points, src/multislice/potentials.py:123-125, so a user who wants a fast grid picks a smooth length).
@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(16 * G, 2) rowTM_pass_kernel(RowTJob job) {
     constexpr int CS = rowTM_cs(A, B);
     constexpr int TPS = LINES / 2, POS_PER_IT = NT / TPS, NIT = (N + POS_PER_IT - 1) / POS_PER_IT;
     static_assert(A <= G && B <= G && 64 % G == 0, "a line's lanes inside one wave");
-    static_assert(fft_smooth(A) && fft_smooth(B), "radices 2, 3, 4, 5");
+    static_assert(fft_smooth7(A) && fft_smooth7(B), "radices 2, 3, 4, 5, 7");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float2* tw1 = reinterpret_cast<float2*>(smem_raw);        // [k2 A + n1] = W_N^{n1 k2}
     float2* tw2 = tw1 + N;                                    // [n1 B + k2] = W_N^{n1 k2}
@@ -227,7 +227,7 @@ __global__ void __launch_bounds__(512, 2) rowTM2_pass_kernel(RowTJob job) {
     constexpr int TPS = LINES / 2, POS_PER_IT = NT / TPS, NIT = (N + POS_PER_IT - 1) / POS_PER_IT;
     static_assert(A2 <= 64 && B2 <= 64, "one wave per line");
     static_assert(P1 % 4 == 2 && P1 >= AH + A && (AH & 1), "conflict-free pair reads");
-    static_assert(fft_smooth(A) && fft_smooth(B), "radices 2, 3, 4, 5");
+    static_assert(fft_smooth7(A) && fft_smooth7(B), "radices 2, 3, 4, 5, 7");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float2* tw1 = reinterpret_cast<float2*>(smem_raw);        // N
     float2* tw2 = tw1 + N;                                    // N, lane order

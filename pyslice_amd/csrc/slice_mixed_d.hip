@@ -1,0 +1,13 @@
+// Mixed-radix transposing pass, line lengths A * B below 400 with a factor 7 (rowtm_launch.h).
+#include "rowtm_launch.h"
+
+namespace msl {
+
+bool rowTM_launch_d(int n, const RowTJob& job, int grid, size_t lds_limit, hipStream_t stream) {
+#define X(a, b, g) if (n == (a) * (b)) return rowTM_launch_one<a, b, g>(job, grid, lds_limit, stream);
+    MSL_ROWTM_LIST_D(X)
+#undef X
+    return false;
+}
+
+}  // namespace msl

@@ -833,6 +833,26 @@ def test_smooth_lengths_on_the_mixed_radix_pass(ps, orc, nx, ny, nz, P):
     assert ref_residual(got, want) < RESID_TOL
 
 
+@pytest.mark.parametrize("nx,ny,nz,P", [(700, 700, 4, 3), (448, 336, 3, 2), (196, 147, 3, 2), (896, 504, 2, 1), (784, 840, 2, 1),
+                                        (175, 189, 3, 2), (441, 420, 3, 2), (567, 997, 2, 1), (1400, 1120, 2, 1), (1680, 1568, 2, 1),
+                                        (1050, 630, 3, 2), (1512, 1024, 2, 1), (210, 1176, 2, 2)])
+def test_lengths_with_a_factor_7_on_the_mixed_radix_pass(ps, orc, nx, ny, nz, P):
+    """7-smooth line lengths (mixed radix 3, 5, 7) on the same direct passes with the radix-7 register butterfly
+    (fft_regs.h: dif7_level): the factor 7 in the lane count, in the register count or in both (441, 784), 7 x 7 = 49 nowhere (factors
+    <= 32), groups of 16 lanes (196) and of 32, the kernels that spill a few registers (784, 896; 1512, 1568, 1680), the 2 A B form on one
+    wave per line (1050 .. 1680), next to 5-smooth, power-of-two and convolution axes, line counts that are not multiples of the tile."""
+    from pyslice_amd.synthetic import synthetic_trajectory
+    tr = synthetic_trajectory(nx, nz, 1, ny=ny, density=0.02, seed=nx + 5 * ny)
+    lx, ly = tr.box_matrix[0, 0], tr.box_matrix[1, 1]
+    pp = [tuple(v) for v in np.random.default_rng(13).random((P, 2)) * [lx, ly]]
+    calc = ps.MultisliceCalculator(progress=False, dtype="complex64")
+    calc.setup(tr, aperture=30.0, voltage_eV=100e3, probe_positions=pp)
+    got = npy(calc.run().wavefunction_data)
+    want = orc.run_frames(tr.box_matrix, tr.positions, tr.atom_types, 30.0, 100e3, pp)["wavefunction_data"]
+    assert rel_l2(got, want) < WAVE_TOL
+    assert ref_residual(got, want) < RESID_TOL
+
+
 @pytest.mark.parametrize("nz", [3, 2])
 def test_transmission_functions_2048_grid(ps, orc, nz):
     """exp(i sigma V) on the C5 grid straight against the oracle: quadrant structure factor, half-spectrum inverse transform on the

@@ -152,6 +152,15 @@ int main() {
     rep("fft_regs<120> fwd", check_regs<120, false>(), 1e-6);
     rep("fft_regs<125> fwd", check_regs<125, false>(), 1e-6);
     rep("fft_regs<128> fwd", check_regs<128, false>(), 1e-6);
+    // radix 7: the mixed-radix slice-loop passes of rowtm_pass.h (7-smooth factors up to 32)
+    rep("fft_regs<7> fwd", check_regs<7, false>(), 1e-6);
+    rep("fft_regs<7> inv", check_regs<7, true>(), 1e-6);
+    rep("fft_regs<14> fwd", check_regs<14, false>(), 1e-6);
+    rep("fft_regs<21> inv", check_regs<21, true>(), 1e-6);
+    rep("fft_regs<21> fwd", check_regs<21, false>(), 1e-6);
+    rep("fft_regs<28> fwd", check_regs<28, false>(), 1e-6);
+    rep("fft_regs<28> inv", check_regs<28, true>(), 1e-6);
+    rep("fft_regs<49> fwd", check_regs<49, false>(), 1e-6);
     rep("dit<2> fwd", check_dit<2, false, 0>(), 1e-6);
     rep("dit<4> inv", check_dit<4, true, 0>(), 1e-6);
     rep("dit<8> fwd", check_dit<8, false, 0>(), 1e-6);
