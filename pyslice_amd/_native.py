@@ -19,7 +19,7 @@ MSL_OK, MSL_ERR_INVALID, MSL_ERR_HIP, MSL_ERR_UNSUPPORTED, MSL_ERR_STATE, MSL_ER
  BUF_STREAM_ACC, BUF_STREAM_S1, BUF_STREAM_S2, BUF_STREAM_REF) = range(11)
 
 EXPORTS = [
-    "msl_abi_version", "msl_last_error", "msl_create", "msl_destroy", "msl_set_kirkland", "msl_set_slices",
+    "msl_abi_version", "msl_line_kernel_class", "msl_last_error", "msl_create", "msl_destroy", "msl_set_kirkland", "msl_set_slices",
     "msl_set_beam", "msl_resize_probes", "msl_set_probes", "msl_upload_probes", "msl_shift_probes",
     "msl_build_potential", "msl_upload_potential", "msl_propagate", "msl_propagate_frame", "msl_tacaw",
     "msl_download", "msl_download_wavefunction_c128", "msl_download_frame", "msl_upload_frame", "msl_buffer_bytes", "msl_result_pitch", "msl_device_ptr", "msl_synchronize",
@@ -67,6 +67,7 @@ def load():
     vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
     sig = {
         "msl_abi_version": (C.c_int, []),
+        "msl_line_kernel_class": (C.c_int, [i32]),
         "msl_last_error": (C.c_char_p, [vp]),
         "msl_create": (C.c_int, [C.POINTER(MslConfig), C.POINTER(vp)]),
         "msl_destroy": (C.c_int, [vp]),
@@ -117,6 +118,16 @@ def load():
                            "(python -m pyslice_amd.build_native --force)")
     _lib = lib
     return lib
+
+
+def line_kernel_class(n: int) -> int:
+    """2: power-of-two register kernel, 1: direct mixed-radix pass, 0: zero-padded convolution / generic kernel (msl_line_kernel_class)"""
+    return int(load().msl_line_kernel_class(int(n)))
+
+
+def fast_lengths(lo: int = 144, hi: int = 2048):
+    """line lengths in [lo, hi] that run on a direct slice-loop kernel"""
+    return [n for n in range(int(lo), int(hi) + 1) if line_kernel_class(n) > 0]
 
 
 def _raise(rc, msg):

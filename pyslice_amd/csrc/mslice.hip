@@ -1230,6 +1230,12 @@ extern "C" {
 
 int msl_abi_version(void) { return MSL_ABI_VERSION; }
 
+int msl_line_kernel_class(int32_t n) {
+    if (n == 256 || n == 512 || n == 1024 || n == 2048) return 2;
+    int A = 0, B = 0, G = 0;
+    return rowTM_factors(n, &A, &B, &G) ? 1 : 0;
+}
+
 const char* msl_last_error(const msl_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
 int msl_create(const msl_config* cfg, msl_handle** out) {

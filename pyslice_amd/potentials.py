@@ -59,6 +59,54 @@ def gridFromTrajectory(trajectory, sampling=0.1, slice_thickness=0.5):
     return xs, ys, zs, lx, ly, lz
 
 
+def _line_cost(n: int) -> float:
+    """modelled cost per point of a slice-loop pass along lines of n points = 1 / (fraction of the HBM peak measured for that
+    kernel family): power-of-two register kernels 0.39-0.54, direct mixed-radix passes 0.27-0.33, any other
+    length a zero-padded convolution on the next register transform M >= 2 n - 1, i.e. that transform's fraction times n / M"""
+    from . import _native
+    cls = _native.line_kernel_class(n)
+    if cls == 2:
+        return 1.0 / {256: 0.50, 512: 0.49, 1024: 0.54, 2048: 0.386}[n]
+    if cls == 1:
+        return 1.0 / (0.33 if n < 972 else 0.27)
+    for m, base in ((256, 0.50), (1024, 0.56), (2048, 0.386), (4096, 0.27)):
+        if 2 * n - 1 <= m or (m == 4096 and n <= 2047):
+            return m / (base * n)
+    return 20.0                                               # generic LDS kernel
+
+
+def suggest_sampling(trajectory, sampling=0.1, max_refine=0.15, min_gain=1.15):
+    """A finer `sampling` whose grid is modelled at least `min_gain` times cheaper in the slice loop, or None.
+
+    The grid is int(L / sampling) + 1 points per axis (reference potentials.py:123-125), so the line lengths are whatever the box
+    gives; a length without a kernel of its own (msl_line_kernel_class == 0) runs as a zero-padded convolution on the next
+    power-of-two transform, which costs little just below a power of two (501 on 1024) and up to 4 x just above one (520 on 2048).
+    Returns (sampling', nx', ny') with sampling (1 - max_refine) <= sampling' <= sampling and both axes on direct kernels: the
+    candidate with the lowest modelled cost nx ny (cost(nx) + cost(ny)), if that beats the current grid by min_gain."""
+    from . import _native
+    box = trajectory.box_matrix
+    lx, ly = float(box[0, 0]), float(box[1, 1])
+    n_of = lambda L, s: int(L / s) + 1
+    total = lambda a, b: a * b * (_line_cost(a) + _line_cost(b))
+    now = total(n_of(lx, sampling), n_of(ly, sampling))
+    best = None
+    for L, other in ((lx, ly), (ly, lx)):
+        n0 = n_of(L, sampling)
+        for n in range(n0, int(n0 / (1.0 - max_refine)) + 2):
+            if _native.line_kernel_class(n) == 0:
+                continue
+            s = L / (n - 0.5)                                   # the middle of the interval of samplings that give n points
+            if not (sampling * (1.0 - max_refine) <= s <= sampling) or n_of(L, s) != n:
+                continue
+            if _native.line_kernel_class(n_of(other, s)) > 0:
+                c = total(n_of(lx, s), n_of(ly, s))
+                if best is None or c < best[0]:
+                    best = (c, s, n_of(lx, s), n_of(ly, s))
+    if best is None or best[0] * min_gain > now:
+        return None
+    return best[1:]
+
+
 def slice_edges(coords: np.ndarray):
     """[lo, hi) per slice, the reference's masks (potentials.py:302-307), evaluated in float64."""
     n = len(coords)

@@ -203,3 +203,30 @@ def test_default_frame_batch_rule():
     assert default_frame_batch(1, 50, 256, 256) == 256            # C1
     assert default_frame_batch(16, 400, 2048, 2048) == 1          # C5: one frame's stacks are 27 GB
     assert default_frame_batch(300, 10, 64, 64) == 1
+
+
+def test_line_kernel_classes_and_sampling_hint(lib):
+    """msl_line_kernel_class (no device needed) and the sampling hint built on it: the reference's own 501 x 491 grid
+    (00_probe.py:7-8) has no direct kernel on either axis; a sampling at most 8 % finer puts both axes on one."""
+    import types
+    from pyslice_amd import _native
+    from pyslice_amd.potentials import suggest_sampling
+    assert [_native.line_kernel_class(n) for n in (256, 512, 1024, 2048)] == [2, 2, 2, 2]
+    assert all(_native.line_kernel_class(n) == 1 for n in (144, 600, 700, 768, 960, 1000, 1400, 1500, 1728))
+    assert all(_native.line_kernel_class(n) == 0 for n in (100, 143, 501, 491, 997, 1023, 1792, 2047, 4096))
+    fast = _native.fast_lengths(144, 2048)
+    assert len(fast) == 97 + 4 and all(any(n % p == 0 for p in (2, 3, 5, 7)) for n in fast)
+    def smooth7(n):
+        for p in (2, 3, 5, 7):
+            while n % p == 0:
+                n //= p
+        return n == 1
+    assert all(smooth7(n) for n in fast)
+    # 501 x 491 sits just below 512: its convolution on the 1024-point transform is modelled no dearer than a finer direct grid
+    tr = types.SimpleNamespace(box_matrix=np.diag([50.05, 49.05, 49.75]))
+    assert (int(50.05 / 0.1) + 1, int(49.05 / 0.1) + 1) == (501, 491) and suggest_sampling(tr, 0.1) is None
+    # 520 x 520 sits just above it (2048-point transform, 4 x the work per point): a sampling 1 % finer gives 525 x 525
+    tr = types.SimpleNamespace(box_matrix=np.diag([51.95, 51.95, 49.75]))
+    s, nx, ny = suggest_sampling(tr, 0.1)
+    assert 0.085 <= s <= 0.1 and (int(51.95 / s) + 1, int(51.95 / s) + 1) == (nx, ny) == (525, 525)
+    assert suggest_sampling(types.SimpleNamespace(box_matrix=np.diag([102.35, 102.35, 99.75])), 0.1) is None      # 1024 x 1024 already
