@@ -1565,3 +1565,27 @@ def test_results_on_odd_pixel_counts_sit_at_a_line_aligned_pitch(ps, orc, nx, ny
     eng.upload_frame(3, frame)
     assert np.array_equal(eng.frame(3), frame) and np.array_equal(eng.frame(2), host[:, 2]) and np.array_equal(eng.frame(4), host[:, 4])
     assert float(raw[:, :, wx * wy:].abs().max()) == 0.0
+
+
+def test_streaming_tacaw_on_an_odd_pixel_window(ps, orc):
+    """The frame ring of a streaming run keeps its images at the line-aligned pixel pitch too (21 x 19 = 399 pixels at 416): the fold
+    reads the ring with that pitch, the reference pattern is copied out of it row by row, the accumulators and the finished
+    intensity are dense (tacaw_data.py:89-104 on a k-window)."""
+    from pyslice_amd import _native
+    from pyslice_amd.synthetic import synthetic_trajectory
+    n, T, P, win, tile = 64, 10, 2, (21, 19), 4
+    tr = synthetic_trajectory(n, 3, T, density=0.08, seed=77)
+    lx, ly = tr.box_matrix[0, 0], tr.box_matrix[1, 1]
+    pp = [tuple(v) for v in np.random.default_rng(8).random((P, 2)) * [lx, ly]]
+    full = orc.run_frames(tr.box_matrix, tr.positions, tr.atom_types, 30.0, 100e3, pp)["wavefunction_data"]
+    x0, y0 = n // 2 - win[0] // 2, n // 2 - win[1] // 2
+    f, inten = orc.tacaw(full[:, :, x0:x0 + win[0], y0:y0 + win[1]], np.arange(T) * tr.timestep)
+    calc = ps.MultisliceCalculator(progress=False, stream_tile=tile, k_window=win)
+    calc.setup(tr, aperture=30.0, voltage_eV=100e3, probe_positions=pp)
+    assert calc._engine.result_pitch(_native.BUF_WAVEFUNCTION) == 416
+    tac = calc.run_streaming_tacaw()
+    got = npy(tac.intensity)
+    assert got.shape == inten.shape and rel_l2(got, inten) < TACAW_TOL
+    assert rel_l2(tac.total_diffraction, inten.sum(axis=1)) < TACAW_TOL
+    assert rel_l2(tac.spectrum(1), inten[1].sum(axis=(1, 2))) < TACAW_TOL
+    assert rel_l2(tac.diffraction(0), inten[0].sum(axis=0)) < TACAW_TOL
