@@ -499,6 +499,135 @@ __global__ void __launch_bounds__(256, 1) structure_factor_stream_bf16_kernel(fl
     }
 }
 
+// ---- two tiles per wave ------------------------------------------------------------------------------------------------------------
+// The kernel above is bound by its table reads out of the L2, not by the splits or the matrix pipe: every 32 x 32 tile reads 64 columns
+// of every atom of its slice (2048^2: 56 GB per frame at the L2; with tables pre-split into bf16 pieces -- 1.5 x the bytes, no split
+// instructions -- it ran 1.45 x slower, profiles/r04_sf_presplit_tables.txt).  Here a wave owns TWO tiles along kx (columns kx0 .. kx0 + 63
+// of ex) that share the ey operand planes: 96 table columns per 2 tiles instead of 128, 48 matrix instructions per trip against 264
+// split instructions (24 against 176), and the four waves of a workgroup take four neighbouring ky tiles of the same kx pair, so their
+// ex reads coincide in the L1.  Species weights are fetched when a species starts (its accumulation hides the latency); the species
+// totals of the eight accumulators (128 values per lane) live in the LDS -- 32 KB per wave, touched at the two or three species
+// boundaries of a work item only -- because accumulators + totals + operands of two tiles do not fit the vector registers.
+// n_pairs = ceil(tiles_x / 2) tiles_y work items per slice; the second tile of the last pair of an odd tile count recomputes clamped
+// columns and stores nothing.
+__global__ void __launch_bounds__(256, 1) structure_factor_stream_bf16x2_kernel(float2* __restrict__ recip, const float2* __restrict__ ex,
+                                                                             const float2* __restrict__ ey, const float* __restrict__ ff,
+                                                                             const int* __restrict__ start, int n_species, int nx, int ny,
+                                                                             int tiles_y, int n_pairs, int n_rows, int write_mx, int px_pitch,
+                                                                             int py_pitch, int n_slices) {
+    extern __shared__ float sf_tot[];                               // 4 waves x 128 totals x 64 lanes
+    const int xcd = blockIdx.x & 7, jw = blockIdx.x >> 3, wg_x = gridDim.x >> 3;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hx = nx / 2, hy = ny / 2;
+    const int i = lane & 31, kk = lane >> 5;
+    const int G = (n_pairs + 3) / 4, Mx = (n_slices + 7) / 8;
+    for (int q = jw; q < Mx * G; q += wg_x) {
+        const int m = q / G, g = q - m * G;
+        const int s = xcd + 8 * m, pair = 4 * g + wave;
+        if (s >= n_slices || pair >= n_pairs) continue;
+        const int kx0 = (pair / tiles_y) * 64, ky0 = (pair % tiles_y) * 32;
+        const int lx0 = min(kx0 + i, hx), lx1 = min(kx0 + 32 + i, hx), ly = min(ky0 + i, hy);
+        const int* st = start + s * n_species;
+        const int S0 = __builtin_amdgcn_readfirstlane(st[0]), S1 = __builtin_amdgcn_readfirstlane(st[n_species]);
+        const int H = (S1 - S0) >> 4;                   // whole trips of 16 rows: every bin is padded to a multiple of 16
+        const unsigned rows_left = (unsigned)(n_rows - S0);
+        const msl_i4v rx = make_raw_rsrc(ex + (size_t)S0 * px_pitch, (unsigned)((unsigned long long)rows_left * px_pitch * 8ull < 0xfffffff0ull ? (unsigned long long)rows_left * px_pitch * 8ull : 0xfffffff0ull));
+        const msl_i4v ry = make_raw_rsrc(ey + (size_t)S0 * py_pitch, (unsigned)((unsigned long long)rows_left * py_pitch * 8ull < 0xfffffff0ull ? (unsigned long long)rows_left * py_pitch * 8ull : 0xfffffff0ull));
+        const int vox0 = (8 * kk * px_pitch + lx0) * 8, vox1 = (8 * kk * px_pitch + lx1) * 8, voy = (8 * kk * py_pitch + ly) * 8;
+        // (accumulators: every definition is a matrix instruction, so that the eight tuples stay in the accumulation registers --
+        // zeroed by a product of zeros; with ordinary assignments the allocator kept them in vector registers and spilled)
+        f32x16 A0, B0, C0, D0, A1, B1, C1, D1;
+        const sf_u32x4 z4 = {0u, 0u, 0u, 0u};
+        // (wait states by hand around it: the compiler does not know that the statement is a matrix instruction, and without them a
+        // second work item of a workgroup read NaNs -- the species flush in front of it reads the same registers with vector moves)
+        auto zero_acc = [&](f32x16& acc) { asm volatile("s_nop 15\n\ts_nop 15\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %1, 0\n\ts_nop 15\n\ts_nop 15" : "=a"(acc) : "v"(z4)); };
+        zero_acc(A0); zero_acc(B0); zero_acc(C0); zero_acc(D0); zero_acc(A1); zero_acc(B1); zero_acc(C1); zero_acc(D1);
+        float* tot = sf_tot + (wave * 128) * 64 + lane;            // [plane 0..7][r][lane]: plane = 4 tile + (A, B, C, D)
+#pragma unroll
+        for (int r = 0; r < 128; ++r) tot[r * 64] = 0.f;
+        int sp = -1, seg1 = S0;
+        auto next_of = [&](int& k, int& e) { const int from = e; do { ++k; if (k >= n_species) return; e = st[k + 1]; } while (e <= from); };
+        float w0[16], w1[16];
+        auto load_w = [&](int spc) {
+            const float* f = ff + (size_t)spc * nx * ny;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
+                w0[r] = f[(size_t)min(kx0 + row, hx) * ny + ly];
+                w1[r] = f[(size_t)min(kx0 + 32 + row, hx) * ny + ly];
+            }
+        };
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { w0[r] = 0.f; w1[r] = 0.f; }
+        next_of(sp, seg1);
+        if (sp < n_species) load_w(sp);
+        auto flush = [&]() {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float* t = tot + r * 64;
+                t[0 * 1024] = fmaf(w0[r], A0[r], t[0 * 1024]); t[1 * 1024] = fmaf(w0[r], B0[r], t[1 * 1024]);
+                t[2 * 1024] = fmaf(w0[r], C0[r], t[2 * 1024]); t[3 * 1024] = fmaf(w0[r], D0[r], t[3 * 1024]);
+                t[4 * 1024] = fmaf(w1[r], A1[r], t[4 * 1024]); t[5 * 1024] = fmaf(w1[r], B1[r], t[5 * 1024]);
+                t[6 * 1024] = fmaf(w1[r], C1[r], t[6 * 1024]); t[7 * 1024] = fmaf(w1[r], D1[r], t[7 * 1024]);
+            }
+            zero_acc(A0); zero_acc(B0); zero_acc(C0); zero_acc(D0); zero_acc(A1); zero_acc(B1); zero_acc(C1); zero_acc(D1);
+            next_of(sp, seg1);
+            if (sp < n_species) load_w(sp);
+        };
+        auto load16 = [&](int h, float2 (&xa)[8], float2 (&xb)[8], float2 (&y)[8]) {
+            const int r0 = __builtin_amdgcn_readfirstlane(16 * h);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const msl_f2v a = msl_raw_buffer_load_f2(rx, vox0, (r0 + u) * px_pitch * 8, 0);
+                const msl_f2v c = msl_raw_buffer_load_f2(rx, vox1, (r0 + u) * px_pitch * 8, 0);
+                const msl_f2v b = msl_raw_buffer_load_f2(ry, voy, (r0 + u) * py_pitch * 8, 0);
+                xa[u] = make_float2(a.x, a.y); xb[u] = make_float2(c.x, c.y); y[u] = make_float2(b.x, b.y);
+            }
+        };
+        auto mma = [&](f32x16& acc, const sf_u32x4& a, const sf_u32x4& b) { asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b)); };
+        auto mma6 = [&](f32x16& acc, const sf_u32x4 (&p)[3], const sf_u32x4 (&qq)[3]) {
+            mma(acc, p[0], qq[0]); mma(acc, p[0], qq[1]); mma(acc, p[1], qq[0]);
+            mma(acc, p[0], qq[2]); mma(acc, p[2], qq[0]); mma(acc, p[1], qq[1]);
+        };
+        auto conv = [&](sf_u32x4 (&o)[3], const float2 (&v)[8], bool imag) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                unsigned p0, p1, p2;
+                sf_split3(imag ? v[2 * u].y : v[2 * u].x, imag ? v[2 * u + 1].y : v[2 * u + 1].x, p0, p1, p2);
+                o[0][u] = p0; o[1][u] = p1; o[2][u] = p2;
+            }
+        };
+        // one set of split operands (72 registers) and two raw sets (96): the schedule of the kernel above with both tiles side by side --
+        //     A0 A1 (cx, cy)  [sy, sx0, sx1 of THIS trip]   C0 C1 (cx, sy)  [cx0, cx1 of the next]   D0 D1 (sx, cy)  [cy of the next]   B0 B1 (sx, sy)
+        sf_u32x4 cx0[3], sx0[3], cx1[3], sx1[3], cy[3], sy[3];
+        auto trip = [&](int h, float2 (&xa)[8], float2 (&xb)[8], float2 (&y)[8], const float2 (&xan)[8], const float2 (&xbn)[8], const float2 (&yn)[8]) {
+            if (S0 + 16 * h == seg1) flush();               // the species ended with the previous trip
+            mma6(A0, cx0, cy); mma6(A1, cx1, cy); conv(sy, y, true); conv(sx0, xa, true); conv(sx1, xb, true); __builtin_amdgcn_sched_barrier(0);
+            load16(h + 2, xa, xb, y); __builtin_amdgcn_sched_barrier(0);
+            mma6(C0, cx0, sy); mma6(C1, cx1, sy); conv(cx0, xan, false); conv(cx1, xbn, false); __builtin_amdgcn_sched_barrier(0);
+            mma6(D0, sx0, cy); mma6(D1, sx1, cy); conv(cy, yn, false); __builtin_amdgcn_sched_barrier(0);
+            mma6(B0, sx0, sy); mma6(B1, sx1, sy); __builtin_amdgcn_sched_barrier(0);
+        };
+        float2 xa0[8], xb0[8], y0[8], xa1[8], xb1[8], y1[8];
+        if (H > 0) { load16(0, xa0, xb0, y0); load16(1, xa1, xb1, y1); conv(cx0, xa0, false); conv(cx1, xb0, false); conv(cy, y0, false); }
+        for (int h = 0; h < H; h += 2) {
+            trip(h, xa0, xb0, y0, xa1, xb1, y1);
+            if (h + 1 < H) trip(h + 1, xa1, xb1, y1, xa0, xb0, y0);
+        }
+        if (H > 0) flush();
+        float2* out = recip + (size_t)s * nx * ny;
+        const int my = ky0 + i;
+        if (my > hy) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int mx = kx0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+            const float* t = tot + r * 64;
+            if (mx <= hx) store_quad_bin(out, nx, ny, mx, my, t[0 * 1024], t[1 * 1024], t[2 * 1024], t[3 * 1024], write_mx);
+            if (mx + 32 <= hx) store_quad_bin(out, nx, ny, mx + 32, my, t[4 * 1024], t[5 * 1024], t[6 * 1024], t[7 * 1024], write_mx);
+        }
+    }
+}
+
 // (The tiled kernel for few atoms per bin keeps the exact-f32 instruction: with 4-5 trips per bin the splits are not hidden and trips of
 // 16 rows waste a fifth of them -- a split-bf16 form of it measured 7 % slower on 512^2 / 501^2 / 256^2 single-probe runs.)
 
