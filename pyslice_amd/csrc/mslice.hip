@@ -1835,7 +1835,7 @@ static int build_potentials(msl_handle* h, const double* pos, const int32_t* Z, 
                                        h->d_start, nsp, c.nx, c.ny, tiles_y, n_tiles, (int)rows_pad, half_rows ? 0 : 1, cx, cy, n_slices);
                 // two kx tiles per wave sharing the ey planes (potential.h) where a slice's tables outgrow an XCD's L2: 2048^2 x 50 potential
                 // 8.67 -> 8.17 ms per frame, 1024^2 (C3) 3.72 -> 3.69 (kept on the one-tile kernel)
-                else if (n_tiles >= 512 && !dbg_env("MSL_SF_ONE_TILE"))
+                else if ((n_tiles >= 512 || (tiles_x >= 2 && dbg_env("MSL_SF_TWO_TILES"))) && !dbg_env("MSL_SF_ONE_TILE"))
                     hipLaunchKernelGGL(structure_factor_stream_bf16x2_kernel, dim3((unsigned)n_pers), dim3(256), 4 * 128 * 64 * sizeof(float), h->stream, TR, h->d_ex, h->d_ey, h->d_ff,
                                        h->d_start, nsp, c.nx, c.ny, tiles_y, ((tiles_x + 1) / 2) * tiles_y, (int)rows_pad, half_rows ? 0 : 1, cx, cy, n_slices);
                 else

@@ -588,16 +588,24 @@ def test_randomised_potential_sweep(ps, orc):
         assert err < POT_TOL, (cfg, err)
 
 
-@pytest.mark.parametrize("nx,ny,nz,n_atoms,batch", [(96, 80, 3, 1500, 1), (128, 128, 2, 2100, 3), (64, 250, 1, 400, 1), (256, 256, 4, 1100, 2)])
-def test_structure_factor_stream_kernel_dense_slices(ps, orc, nx, ny, nz, n_atoms, batch):
+@pytest.mark.parametrize("two_tiles", [False, True])
+@pytest.mark.parametrize("nx,ny,nz,n_atoms,batch", [(96, 80, 3, 1500, 1), (128, 128, 2, 2100, 3), (64, 250, 1, 400, 1), (256, 256, 4, 1100, 2),
+                                                    (320, 200, 17, 9000, 1), (512, 512, 48, 21000, 1)])
+def test_structure_factor_stream_kernel_dense_slices(ps, orc, nx, ny, nz, n_atoms, batch, two_tiles, monkeypatch):
     """From 128 atoms per (slice, species) on the potential takes structure_factor_stream_bf16_kernel (three-way bf16 split of
     every factor on the matrix instruction, f32 accumulation; measured 1.1e-7 .. 1.3e-7 of max|V|, the same as the f32 kernel;
     persistent, the rows of every bin
     padded to whole half-trips of 8, species flushed at half-trip boundaries): three species of which one is missing from a
     slice and one slice holds a single species, bin sizes that are and are not multiples of 8, several frames per build, odd grid
     lengths; and just below the threshold the tiled kernel on the same kind of input.  Transmission functions against the
-    oracle's potential."""
+    oracle's potential.  two_tiles: the kernel of the large grids (two tiles along kx per wave, species totals in the LDS,
+    structure_factor_stream_bf16x2_kernel) forced onto the same inputs -- an odd number of tile columns (96, 320: the second tile of the
+    last pair stores nothing), and 48 slices of 512 x 512 (48 work items for the 32 workgroups of an XCD: every workgroup runs several, the case in
+    which the accumulators' zeroing between items needed its wait states)."""
     from pyslice_amd import _native
+    if two_tiles:
+        monkeypatch.setenv("MSL_DEBUG", "1")
+        monkeypatch.setenv("MSL_SF_TWO_TILES", "1")
     from pyslice_amd.potentials import loadKirkland
     rng = np.random.default_rng(nx + n_atoms)
     dx, dy, dz = 0.1, 0.09, 0.5
