@@ -562,6 +562,9 @@ __global__ void __launch_bounds__(256, 1) structure_factor_stream_bf16x2_kernel(
         next_of(sp, seg1);
         if (sp < n_species) load_w(sp);
         auto flush = [&]() {
+            // (the sums are read by vector moves the compiler places without knowing that inline assembly wrote them: let the last
+            // matrix instructions finish first -- 16 passes of 4 cycles and their write-back)
+            asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float* t = tot + r * 64;
