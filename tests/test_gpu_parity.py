@@ -1386,7 +1386,8 @@ def test_tacaw_row_offsets_near_the_32_bit_limit(ps, T, npix):
     assert err.max() < 5e-5, (T, npix, err.max())
 
 
-TDIR_LENGTHS = [16, 18, 20, 24, 25, 27, 30, 32, 36, 40, 45, 48, 50, 54, 60, 64, 72, 75, 80, 81, 90, 96, 100, 108, 120, 125, 128]
+TDIR_LENGTHS = [16, 18, 20, 24, 25, 27, 30, 32, 36, 40, 45, 48, 50, 54, 60, 64, 72, 75, 80, 81, 90, 96, 100, 108, 120, 125, 128,
+                21, 28, 35, 42, 49, 56, 63, 70, 84, 98, 105, 112, 126]        # (second line: with a factor 7)
 TSPLIT2_LENGTHS = [540, 576, 600, 640, 648, 720, 750, 768, 800, 864, 960, 1000, 1024]       # two blocks per wave
 TSPLIT_LENGTHS = [135, 144, 150, 160, 162, 180, 192, 200, 216, 225, 240, 243, 250, 256, 270, 288, 300, 320, 324, 360, 375, 384, 400, 405,
                   432, 450, 480, 486, 500, 512]
@@ -1394,7 +1395,7 @@ TSPLIT_LENGTHS = [135, 144, 150, 160, 162, 180, 192, 200, 216, 225, 240, 243, 25
 
 @pytest.mark.parametrize("shape", [(7, 9), (20, 30)])
 def test_tacaw_smooth_frame_counts_on_the_per_lane_kernel(ps, shape):
-    """time_direct_kernel: every 2-3-5-smooth frame count from 16 to 128 (radix-4 / 2 / 5 / 3 register network, one lane per pixel;
+    """time_direct_kernel: every 2-3-5-7-smooth frame count from 16 to 128 (radix-4 / 2 / 5 / 3 / 7 register network, one lane per pixel;
     100 = 4.5.5 is the reference notebook's run, example.ipynb:578), and time_split_kernel: every smooth count from 129 to 512 as
     L x TP over the L = 2 .. 6 waves of a workgroup (256 = 2 x 128, 500 = 4 x 125, 486 = 6 x 81 ...) and thirteen counts up to 1024
     as 8 x TP / 6 x TP with two blocks per wave (1000 = 8 x 125).  63 pixels (one ragged tile) and 600 (ragged last tile; with 3 probes more tiles than one per
