@@ -432,6 +432,9 @@ __global__ void __launch_bounds__(256, 1) structure_factor_stream_bf16_kernel(fl
         spn = sp; segn1 = seg1;
         if (sp < n_species) { load_w(sp, wc); next_of(spn, segn1); if (spn < n_species) load_w(spn, wn); }
         auto flush = [&]() {
+            // (wait states by hand: the sums below are read by vector moves of accumulators that inline-assembly matrix instructions wrote --
+            // the compiler's hazard recognizer does not know them to be such; 19 would do for a 16-pass instruction)
+            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 tA[r] = fmaf(wc[r], A[r], tA[r]); tB[r] = fmaf(wc[r], B[r], tB[r]);
