@@ -108,7 +108,7 @@ typedef struct {
 int  msl_abi_version(void);
 /* Which slice-loop kernel a line of n points gets (the reference's grids are int(L / sampling) + 1 points, potentials.py:123-125,
  * so a user picks the line lengths with `sampling`): 2 = power-of-two register kernel (256, 512, 1024, 2048), 1 = direct
- * mixed-radix pass (97 lengths 144 ... 1728 with factors 2, 3, 5, 7), 0 = any other length: zero-padded convolution on the next
+ * mixed-radix pass (99 lengths 135 ... 1728 with factors 2, 3, 5, 7), 0 = any other length: zero-padded convolution on the next
  * power-of-two transform (2-4 x the work per point) or the generic LDS kernel.  No handle, no device needed. */
 int  msl_line_kernel_class(int32_t n);
 /* Message of the last failure on this handle (or of the last failed msl_create when h==NULL). */

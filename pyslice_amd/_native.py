@@ -125,7 +125,7 @@ def line_kernel_class(n: int) -> int:
     return int(load().msl_line_kernel_class(int(n)))
 
 
-def fast_lengths(lo: int = 144, hi: int = 2048):
+def fast_lengths(lo: int = 129, hi: int = 2048):
     """line lengths in [lo, hi] that run on a direct slice-loop kernel"""
     return [n for n in range(int(lo), int(hi) + 1) if line_kernel_class(n) > 0]
 

@@ -8,7 +8,7 @@
 #include "rowtm_pass.h"
 
 #define MSL_ROWTM_LIST_A(X) \
-    X(12, 12, 16) X(15, 10, 16) X(16, 10, 16) X(15, 12, 16) X(16, 12, 16) X(20, 10, 32) X(18, 12, 32) X(15, 15, 16) X(16, 15, 16) \
+    X(15, 9, 16) X(12, 12, 16) X(15, 10, 16) X(16, 10, 16) X(15, 12, 16) X(16, 12, 16) X(20, 10, 32) X(18, 12, 32) X(15, 15, 16) X(16, 15, 16) \
     X(25, 10, 32) X(18, 15, 32) X(18, 16, 32) X(20, 15, 32) X(20, 16, 32) X(18, 18, 32) X(20, 18, 32) X(25, 15, 32) X(24, 16, 32) \
     X(20, 20, 32) X(27, 15, 32) X(24, 18, 32) X(25, 18, 32) X(24, 20, 32) X(27, 18, 32)
 #define MSL_ROWTM_LIST_B(X) \
@@ -20,7 +20,7 @@
 
 // lengths with a factor 7 (radix-7 register butterfly, fft_regs.h: dif7_level): A * B below / from 400, and 2 A * B on one wave per line
 #define MSL_ROWTM_LIST_D(X) \
-    X(21, 7, 32) X(14, 12, 16) X(25, 7, 32) X(21, 9, 32) X(14, 14, 16) X(15, 14, 16) X(16, 14, 16) X(18, 14, 32) X(20, 14, 32) X(21, 14, 32) X(21, 15, 32) X(21, 16, 32) X(25, 14, 32) X(21, 18, 32) X(28, 14, 32)
+    X(14, 10, 16) X(21, 7, 32) X(14, 12, 16) X(25, 7, 32) X(21, 9, 32) X(14, 14, 16) X(15, 14, 16) X(16, 14, 16) X(18, 14, 32) X(20, 14, 32) X(21, 14, 32) X(21, 15, 32) X(21, 16, 32) X(25, 14, 32) X(21, 18, 32) X(28, 14, 32)
 #define MSL_ROWTM_LIST_E(X) \
     X(21, 20, 32) X(21, 21, 32) X(28, 16, 32) X(24, 21, 32) X(25, 21, 32) X(28, 20, 32) X(27, 21, 32) X(28, 21, 32) X(30, 21, 32) X(28, 24, 32) X(28, 25, 32) X(28, 27, 32) X(28, 28, 32) X(30, 28, 32) X(32, 28, 32)
 #define MSL_ROWTM_LIST_F(X) \

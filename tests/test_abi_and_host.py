@@ -212,10 +212,10 @@ def test_line_kernel_classes_and_sampling_hint(lib):
     from pyslice_amd import _native
     from pyslice_amd.potentials import suggest_sampling
     assert [_native.line_kernel_class(n) for n in (256, 512, 1024, 2048)] == [2, 2, 2, 2]
-    assert all(_native.line_kernel_class(n) == 1 for n in (144, 600, 700, 768, 960, 1000, 1400, 1500, 1728))
+    assert all(_native.line_kernel_class(n) == 1 for n in (135, 140, 144, 600, 700, 768, 960, 1000, 1400, 1500, 1728))
     assert all(_native.line_kernel_class(n) == 0 for n in (100, 143, 501, 491, 997, 1023, 1792, 2047, 4096))
-    fast = _native.fast_lengths(144, 2048)
-    assert len(fast) == 97 + 4 and all(any(n % p == 0 for p in (2, 3, 5, 7)) for n in fast)
+    fast = _native.fast_lengths(129, 2048)
+    assert len(fast) == 99 + 4 and all(any(n % p == 0 for p in (2, 3, 5, 7)) for n in fast)
     def smooth7(n):
         for p in (2, 3, 5, 7):
             while n % p == 0:

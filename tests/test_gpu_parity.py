@@ -844,7 +844,7 @@ def test_smooth_lengths_on_the_mixed_radix_pass(ps, orc, nx, ny, nz, P):
 
 
 @pytest.mark.parametrize("nx,ny,nz,P", [(700, 700, 4, 3), (448, 336, 3, 2), (196, 147, 3, 2), (896, 504, 2, 1), (784, 840, 2, 1),
-                                        (175, 189, 3, 2), (441, 420, 3, 2), (567, 997, 2, 1), (1400, 1120, 2, 1), (1680, 1568, 2, 1),
+                                        (175, 189, 3, 2), (140, 135, 3, 2), (441, 420, 3, 2), (567, 997, 2, 1), (1400, 1120, 2, 1), (1680, 1568, 2, 1),
                                         (1050, 630, 3, 2), (1512, 1024, 2, 1), (210, 1176, 2, 2)])
 def test_lengths_with_a_factor_7_on_the_mixed_radix_pass(ps, orc, nx, ny, nz, P):
     """7-smooth line lengths (mixed radix 3, 5, 7) on the same direct passes with the radix-7 register butterfly
